@@ -1,0 +1,174 @@
+// ec29.cuh -- Stark-curve group law (y^2 = x^3 + x + b over F_p) on top of fe29.cuh.
+//
+// Jacobian (X:Y:Z), identity <=> all limbs of Z are literally zero (every producer below writes
+// exact zeros for the identity).  Affine (x, y) in Montgomery form; identity is (0, 0), which is
+// not on the curve (b != 0) and matches the all-zero boundary encoding (reference
+// src/util.rs:274-289).  All formulas are COMPLETE: P+P, P+(-P), identity operands and the
+// B == B_blinding duplicate of reference src/generators.rs:61-70 take the (rare, divergent) slow
+// paths guarded by the one-limb filter fp_maybe_zero().
+//
+// Replaces mpc-stark's StarkPoint add / double / scalar-mul.
+#pragma once
+#include "fe29.cuh"
+
+namespace bp {
+
+struct Jac { Fp X, Y, Z; };
+struct Aff { Fp x, y; };
+
+BP_HD Jac jac_inf() {
+  Jac r;
+  r.X = fe_one<FP>(); r.Y = fe_one<FP>(); r.Z = fe_zero<FP>();
+  return r;
+}
+BP_HD bool jac_is_inf(const Jac &p) { return is_zero_limbs(p.Z); }
+BP_HD bool aff_is_inf(const Aff &p) { return is_zero_limbs(p.x) && is_zero_limbs(p.y); }
+BP_HD Jac jac_from_aff(const Aff &a) {
+  Jac r;
+  if (aff_is_inf(a)) return jac_inf();
+  r.X = a.x; r.Y = a.y; r.Z = fe_one<FP>();
+  return r;
+}
+BP_HD Aff aff_neg(const Aff &a) { Aff r; r.x = a.x; r.y = neg(a.y); return r; }
+BP_HD Jac jac_neg(const Jac &a) { Jac r = a; r.Y = neg(a.Y); return r; }
+
+// dbl-2007-bl with a = 1 and Z3 = 2*Y*Z: 7S + 2M
+BP_HD Jac jac_dbl(const Jac &p) {
+  if (jac_is_inf(p)) return jac_inf();
+  if (fp_maybe_zero(p.Y) && is_zero_exact(p.Y)) return jac_inf();   // order-2 points do not exist (odd order), kept for completeness
+  Fp XX = sqr(p.X), YY = sqr(p.Y), YYYY = sqr(YY), ZZ = sqr(p.Z);
+  Fp t = sqr(add(p.X, YY));
+  Fp S = mul_small<2>(norm(sub_nr(sub_nr(t, XX), YYYY)));
+  Fp M = add(norm(add_nr(add_nr(XX, XX), XX)), sqr(ZZ));           // 3 XX + a ZZ^2, a = 1
+  Fp T = norm(sub_nr(sub_nr(sqr(M), S), S));
+  Jac r;
+  r.X = T;
+  r.Y = sub(mul(M, sub(S, T)), mul_small<8>(YYYY));
+  r.Z = mul_small<2>(mul(p.Y, p.Z));
+  return r;
+}
+
+// mixed addition (Z2 = 1): 8M + 3S
+BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
+  if (aff_is_inf(q)) return p;
+  if (jac_is_inf(p)) { Jac r; r.X = q.x; r.Y = q.y; r.Z = fe_one<FP>(); return r; }
+  Fp Z1Z1 = sqr(p.Z);
+  Fp U2 = mul(q.x, Z1Z1);
+  Fp S2 = mul(q.y, mul(p.Z, Z1Z1));
+  Fp H = sub(U2, p.X);
+  Fp rr = sub(S2, p.Y);
+  if (fp_maybe_zero(H) && is_zero_exact(H)) {
+    if (is_zero_exact(rr)) { Jac t; t.X = q.x; t.Y = q.y; t.Z = fe_one<FP>(); return jac_dbl(t); }
+    return jac_inf();
+  }
+  Fp HH = sqr(H), HHH = mul(H, HH), V = mul(p.X, HH);
+  Jac r;
+  r.X = norm(sub_nr(sub_nr(sub_nr(sqr(rr), HHH), V), V));
+  r.Y = sub(mul(rr, sub(V, r.X)), mul(p.Y, HHH));
+  r.Z = mul(p.Z, H);
+  return r;
+}
+
+// general addition: 12M + 4S
+BP_HD Jac jac_add(const Jac &p, const Jac &q) {
+  if (jac_is_inf(p)) return q;
+  if (jac_is_inf(q)) return p;
+  Fp Z1Z1 = sqr(p.Z), Z2Z2 = sqr(q.Z);
+  Fp U1 = mul(p.X, Z2Z2), U2 = mul(q.X, Z1Z1);
+  Fp S1 = mul(p.Y, mul(q.Z, Z2Z2)), S2 = mul(q.Y, mul(p.Z, Z1Z1));
+  Fp H = sub(U2, U1);
+  Fp rr = sub(S2, S1);
+  if (fp_maybe_zero(H) && is_zero_exact(H)) {
+    if (is_zero_exact(rr)) return jac_dbl(p);
+    return jac_inf();
+  }
+  Fp HH = sqr(H), HHH = mul(H, HH), V = mul(U1, HH);
+  Jac r;
+  r.X = norm(sub_nr(sub_nr(sub_nr(sqr(rr), HHH), V), V));
+  r.Y = sub(mul(rr, sub(V, r.X)), mul(S1, HHH));
+  r.Z = mul(mul(p.Z, q.Z), H);
+  return r;
+}
+
+// Jacobian -> affine with a known 1/Z
+BP_HD Aff jac_to_aff_with_zinv(const Jac &p, const Fp &zinv) {
+  Aff a;
+  Fp zi2 = sqr(zinv);
+  a.x = mul(p.X, zi2);
+  a.y = mul(p.Y, mul(zi2, zinv));
+  return a;
+}
+BP_HD Aff jac_to_aff(const Jac &p) {
+  if (jac_is_inf(p)) { Aff a; a.x = fe_zero<FP>(); a.y = fe_zero<FP>(); return a; }
+  return jac_to_aff_with_zinv(p, inv(p.Z));
+}
+// y^2 == x^3 + x + b ?
+BP_HD bool aff_on_curve(const Aff &a) {
+  Fp B;
+  constexpr int32_t C[NL] = CURVE_B_MONT;
+  for (int j = 0; j < NL; j++) B.v[j] = C[j];
+  Fp lhs = sqr(a.y);
+  Fp rhs = norm(add_nr(add_nr(mul(sqr(a.x), a.x), a.x), B));
+  return is_zero_exact(sub(lhs, rhs));
+}
+BP_HD Aff aff_generator() {
+  Aff g;
+  constexpr int32_t X[NL] = CURVE_GX_MONT, Y[NL] = CURVE_GY_MONT;
+  for (int j = 0; j < NL; j++) { g.x.v[j] = X[j]; g.y.v[j] = Y[j]; }
+  return g;
+}
+
+// ---- packed HBM formats -------------------------------------------------------------------------
+// packed field element = 8 x u32 (256-bit canonical integer).  "Boundary" = plain integer (the C-ABI
+// byte encoding); "device" = Montgomery residue (x * 2^261 mod m), also canonical.
+struct PackedAff { uint32_t x[8], y[8]; };   // 64 B
+struct PackedJac { uint32_t X[8], Y[8], Z[8]; };  // 96 B
+
+BP_HD Aff aff_load_dev(const PackedAff &s) { Aff a; a.x = unpack<FP>(s.x); a.y = unpack<FP>(s.y); return a; }
+BP_HD void aff_store_dev(PackedAff &d, const Aff &a) { pack(d.x, canon(a.x)); pack(d.y, canon(a.y)); }
+BP_HD Jac jac_load_dev(const PackedJac &s) { Jac a; a.X = unpack<FP>(s.X); a.Y = unpack<FP>(s.Y); a.Z = unpack<FP>(s.Z); return a; }
+BP_HD void jac_store_dev(PackedJac &d, const Jac &a) {
+  pack(d.X, canon(a.X)); pack(d.Y, canon(a.Y)); pack(d.Z, canon(a.Z));
+}
+// boundary (plain, x||y little-endian; zeros = identity) -> device Montgomery affine; false if invalid
+BP_HD bool aff_from_boundary(Aff &out, const uint32_t xy[16]) {
+  uint32_t o = 0;
+  for (int j = 0; j < 16; j++) o |= xy[j];
+  if (o == 0) { out.x = fe_zero<FP>(); out.y = fe_zero<FP>(); return true; }
+  if (!words_lt_mod<FP>(xy) || !words_lt_mod<FP>(xy + 8)) return false;
+  out.x = to_mont(unpack<FP>(xy));
+  out.y = to_mont(unpack<FP>(xy + 8));
+  return aff_on_curve(out);
+}
+BP_HD void aff_to_boundary(uint32_t xy[16], const Aff &a) {
+  if (aff_is_inf(a)) { for (int j = 0; j < 16; j++) xy[j] = 0; return; }
+  pack(xy, from_mont(a.x));
+  pack(xy + 8, from_mont(a.y));
+}
+
+// 256-bit scalar integer helpers (canonical words): signed fixed-window digits via the "+K" trick:
+// s' = s + sum_w 2^(c-1) 2^(cw); digit_w = window_w(s') - 2^(c-1) in [-2^(c-1), 2^(c-1)-1].
+template <int C> BP_HD constexpr int num_windows() { return 252 / C + 1; }
+// sp has 9 words (288 bits) so that the top window of any C <= 16 is representable
+template <int C> BP_HD void recode_add_k(uint32_t out[9], const uint32_t s[8]) {
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    uint32_t kw = 0;
+#pragma unroll
+    for (int w = 0; w < 252 / C + 1; w++) {
+      const int bit = C * w + C - 1;
+      if ((bit >> 5) == j) kw |= 1u << (bit & 31);
+    }
+    uint64_t t = (uint64_t)(j < 8 ? s[j] : 0u) + kw + carry;
+    out[j] = (uint32_t)t;
+    carry = t >> 32;
+  }
+}
+template <int C> BP_HD int recode_digit(const uint32_t sp[9], int w) {
+  const int bit = C * w, k = bit >> 5, sft = bit & 31;
+  uint64_t two = (uint64_t)sp[k] | (k + 1 < 9 ? (uint64_t)sp[k + 1] << 32 : 0);
+  return (int)((two >> sft) & ((1u << C) - 1)) - (1 << (C - 1));
+}
+
+}  // namespace bp

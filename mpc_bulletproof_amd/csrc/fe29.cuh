@@ -1,0 +1,281 @@
+// fe29.cuh -- F_p / F_n arithmetic for gfx950: 9 signed limbs of 29 bits, lazy Montgomery (R = 2^261).
+//
+// Why this shape (CDNA4 has no carry-chained multiply-add; v_mad_i64_i32 gives a full 32x32+64):
+//   * limbs |x_j| <~ 2^29 in int32 registers; a 9x9 schoolbook product is exactly 81 v_mad_i64_i32
+//     into int64 column accumulators with NO carry handling (9 * 2^58 < 2^63);
+//   * add / sub are 9 independent VALU ops (no v_addc chains) + a 3-op/limb parallel carry;
+//   * R = 2^261 is 2^10 larger than the 252-bit moduli, so a product of two values < 2^256
+//     reduces to (-eps*m, (1+eps)*m) without any conditional subtraction: values stay lazy
+//     (small signed multiples of m) until `canon()` at an output / equality test;
+//   * p = 2^251 + 17*2^192 + 1 has limbs [1,0,0,0,0,0,17<<18,0,1<<19] and -p^-1 = -1 mod 2^29:
+//     one Montgomery step for F_p is a negate, an add and two MADs.
+//
+// Representation invariants ("T" = tight): lower limbs in [0, 2^29), top limb small signed.
+// "T'" (after norm()): lower limbs in [-8, 2^29 + 8).  mul/sqr accept T' x T' and limbs up to
+// 1.5 * 2^29 against T'; they return T.  Values: every mul input must satisfy |v| < 2^256.
+//
+// Replaces (device side) mpc-stark's Scalar / base-field arithmetic used at the call sites listed in
+// SURVEY.md K1-K10; parity is established against oracle/ (tests/).
+#pragma once
+#include <stdint.h>
+#include "fe29_consts.h"
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BP_HD __host__ __device__ __forceinline__
+#else
+#define BP_HD inline __attribute__((always_inline))
+#endif
+
+namespace bp {
+
+constexpr int NL = 9;
+constexpr int LB = 29;
+constexpr int32_t LMASK = (1 << LB) - 1;
+
+struct FP { static constexpr bool sparse = true; };   // base field of the Stark curve
+struct FN { static constexpr bool sparse = false; };  // scalar field (group order)
+
+template <class F> struct Fe { int32_t v[NL]; };
+typedef Fe<FP> Fp;
+typedef Fe<FN> Fn;
+
+template <class F> BP_HD Fe<F> fe_zero() {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) r.v[j] = 0;
+  return r;
+}
+template <class F> BP_HD Fe<F> fe_one() {  // Montgomery form of 1
+  Fe<F> r;
+  if constexpr (F::sparse) { constexpr int32_t C[NL] = FP_ONE; for (int j = 0; j < NL; j++) r.v[j] = C[j]; }
+  else { constexpr int32_t C[NL] = FN_ONE; for (int j = 0; j < NL; j++) r.v[j] = C[j]; }
+  return r;
+}
+template <class F> BP_HD Fe<F> fe_r2() {
+  Fe<F> r;
+  if constexpr (F::sparse) { constexpr int32_t C[NL] = FP_R2; for (int j = 0; j < NL; j++) r.v[j] = C[j]; }
+  else { constexpr int32_t C[NL] = FN_R2; for (int j = 0; j < NL; j++) r.v[j] = C[j]; }
+  return r;
+}
+
+// parallel (non-rippling) carry: any limbs with |x_j| < 2^31 -> T'
+template <class F> BP_HD Fe<F> norm(const Fe<F> &x) {
+  Fe<F> r;
+  r.v[0] = x.v[0] & LMASK;
+#pragma unroll
+  for (int j = 1; j < NL - 1; j++) r.v[j] = (x.v[j] & LMASK) + (x.v[j - 1] >> LB);
+  r.v[NL - 1] = x.v[NL - 1] + (x.v[NL - 2] >> LB);
+  return r;
+}
+// no-reduce forms: chain at most 3 tight terms before norm()
+template <class F> BP_HD Fe<F> add_nr(const Fe<F> &a, const Fe<F> &b) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) r.v[j] = a.v[j] + b.v[j];
+  return r;
+}
+template <class F> BP_HD Fe<F> sub_nr(const Fe<F> &a, const Fe<F> &b) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) r.v[j] = a.v[j] - b.v[j];
+  return r;
+}
+template <class F> BP_HD Fe<F> add(const Fe<F> &a, const Fe<F> &b) { return norm(add_nr(a, b)); }
+template <class F> BP_HD Fe<F> sub(const Fe<F> &a, const Fe<F> &b) { return norm(sub_nr(a, b)); }
+template <class F> BP_HD Fe<F> neg(const Fe<F> &a) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) r.v[j] = -a.v[j];
+  return norm(r);
+}
+// k * a for small k (|k| <= 16), through int64 so that tight limbs cannot overflow int32
+template <int K, class F> BP_HD Fe<F> mul_small(const Fe<F> &a) {
+  int64_t t[NL];
+#pragma unroll
+  for (int j = 0; j < NL; j++) t[j] = (int64_t)a.v[j] * K;
+  Fe<F> r;
+  r.v[0] = (int32_t)(t[0] & LMASK);
+#pragma unroll
+  for (int j = 1; j < NL - 1; j++) r.v[j] = (int32_t)((t[j] & LMASK) + (t[j - 1] >> LB));
+  r.v[NL - 1] = (int32_t)(t[NL - 1] + (t[NL - 2] >> LB));
+  return r;
+}
+
+// one Montgomery step on column i (column i is complete when this runs)
+template <class F> BP_HD void mont_step(int64_t *c, int i) {
+  if constexpr (F::sparse) {
+    uint32_t m = (0u - (uint32_t)c[i]) & (uint32_t)LMASK;   // -p^-1 = -1 (mod 2^29)
+    c[i] += (int64_t)m;                                       // p[0] = 1
+    c[i + 6] += (int64_t)m * 4456448;                         // p[6] = 17 << 18
+    c[i + 8] += (int64_t)m * 524288;                          // p[8] = 1 << 19
+  } else {
+    constexpr int32_t MOD[NL] = FN_MOD;
+    uint32_t m = ((uint32_t)c[i] * FN_N0) & (uint32_t)LMASK;
+#pragma unroll
+    for (int j = 0; j < NL; j++) c[i + j] += (int64_t)m * MOD[j];
+  }
+  c[i + 1] += c[i] >> LB;
+}
+template <class F> BP_HD Fe<F> mont_finish(int64_t *c) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL - 1; j++) {
+    r.v[j] = (int32_t)(c[NL + j] & LMASK);
+    c[NL + j + 1] += c[NL + j] >> LB;
+  }
+  r.v[NL - 1] = (int32_t)c[2 * NL - 1];
+  return r;
+}
+// a * b / R  (81 MADs + reduction)
+template <class F> BP_HD Fe<F> mul(const Fe<F> &a, const Fe<F> &b) {
+  int64_t c[2 * NL];
+#pragma unroll
+  for (int j = 0; j < 2 * NL; j++) c[j] = 0;
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+#pragma unroll
+    for (int j = 0; j < NL; j++) c[i + j] += (int64_t)a.v[j] * (int64_t)b.v[i];
+    mont_step<F>(c, i);
+  }
+  return mont_finish<F>(c);
+}
+// a * a / R  (45 MADs + reduction)
+template <class F> BP_HD Fe<F> sqr(const Fe<F> &a) {
+  int64_t c[2 * NL];
+  int32_t a2[NL];
+#pragma unroll
+  for (int j = 0; j < 2 * NL; j++) c[j] = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) a2[j] = 2 * a.v[j];
+#pragma unroll
+  for (int i = 0; i < NL; i++) {
+    c[2 * i] += (int64_t)a.v[i] * (int64_t)a.v[i];
+#pragma unroll
+    for (int j = i + 1; j < NL; j++) c[i + j] += (int64_t)a.v[i] * (int64_t)a2[j];
+    mont_step<F>(c, i);
+  }
+  return mont_finish<F>(c);
+}
+
+// unique representative in [0, m): all limbs in [0, 2^29).  Accepts |value| < 16m.
+template <class F> BP_HD Fe<F> canon(const Fe<F> &x) {
+  int32_t MOD[NL];
+  if constexpr (F::sparse) { constexpr int32_t C[NL] = FP_MOD; for (int j = 0; j < NL; j++) MOD[j] = C[j]; }
+  else { constexpr int32_t C[NL] = FN_MOD; for (int j = 0; j < NL; j++) MOD[j] = C[j]; }
+  Fe<F> r;
+  int64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {   // x + 16m >= 0, rippling carry
+    int64_t t = (int64_t)x.v[j] + 16 * (int64_t)MOD[j] + carry;
+    if (j < NL - 1) { r.v[j] = (int32_t)(t & LMASK); carry = t >> LB; }
+    else r.v[j] = (int32_t)t;
+  }
+#pragma unroll
+  for (int k = 16; k >= 1; k >>= 1) {   // value in [0, 32m): subtract 16m, 8m, 4m, 2m, m when possible
+    Fe<F> t;
+    int64_t br = 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      int64_t d = (int64_t)r.v[j] - (int64_t)k * MOD[j] + br;
+      if (j < NL - 1) { t.v[j] = (int32_t)(d & LMASK); br = d >> LB; }
+      else t.v[j] = (int32_t)d;
+    }
+    bool ge = t.v[NL - 1] >= 0;
+#pragma unroll
+    for (int j = 0; j < NL; j++) r.v[j] = ge ? t.v[j] : r.v[j];
+  }
+  return r;
+}
+template <class F> BP_HD bool is_zero_exact(const Fe<F> &x) {
+  Fe<F> c = canon(x);
+  int32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) o |= c.v[j];
+  return o == 0;
+}
+// all limbs literally zero (the encoding of "Z = 0" for the point at infinity; producers guarantee it)
+template <class F> BP_HD bool is_zero_limbs(const Fe<F> &x) {
+  int32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) o |= x.v[j];
+  return o == 0;
+}
+// Cheap necessary condition for x == 0 (mod p) when |value| <= 16p: k*p = k (mod 2^29).  F_p only.
+BP_HD bool fp_maybe_zero(const Fp &x) { return (uint32_t)((x.v[0] + 16) & LMASK) <= 32u; }
+
+// 8 x u32 little-endian words (a 256-bit integer < 2^253) <-> limbs
+template <class F> BP_HD Fe<F> unpack(const uint32_t w[8]) {
+  Fe<F> r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    const int bit = LB * j, k = bit >> 5, s = bit & 31;
+    uint64_t two = (uint64_t)w[k] | (k + 1 < 8 ? (uint64_t)w[k + 1] << 32 : 0);
+    r.v[j] = (int32_t)((two >> s) & (j < NL - 1 ? (uint32_t)LMASK : 0xFFFFFFFFu));
+  }
+  return r;
+}
+// requires canonical limbs (canon() output)
+template <class F> BP_HD void pack(uint32_t w[8], const Fe<F> &x) {
+  uint64_t acc = 0;
+  int fill = 0, k = 0;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    acc |= (uint64_t)(uint32_t)x.v[j] << fill;
+    fill += LB;
+    if (fill >= 32) { w[k++] = (uint32_t)acc; acc >>= 32; fill -= 32; }
+  }
+  if (k < 8) w[k] = (uint32_t)acc;
+}
+template <class F> BP_HD Fe<F> to_mont(const Fe<F> &plain) { return mul(plain, fe_r2<F>()); }
+template <class F> BP_HD Fe<F> from_mont(const Fe<F> &m) {   // -> canonical plain integer limbs
+  Fe<F> one = fe_zero<F>();
+  one.v[0] = 1;
+  return canon(mul(m, one));
+}
+// is the 256-bit integer < modulus ?
+template <class F> BP_HD bool words_lt_mod(const uint32_t w[8]) {
+  uint32_t M[8];
+  if constexpr (F::sparse) { constexpr uint32_t C[8] = FP_MOD_W; for (int j = 0; j < 8; j++) M[j] = C[j]; }
+  else { constexpr uint32_t C[8] = FN_MOD_W; for (int j = 0; j < 8; j++) M[j] = C[j]; }
+  bool lt = false, decided = false;
+#pragma unroll
+  for (int j = 7; j >= 0; j--) {
+    bool l = w[j] < M[j], g = w[j] > M[j];
+    lt = decided ? lt : l;
+    decided = decided || l || g;
+  }
+  return lt;
+}
+
+// x^e for a 256-bit exponent (little-endian words), left-to-right binary
+template <class F> BP_HD Fe<F> fe_pow(const Fe<F> &x, const uint32_t e[8]) {
+  Fe<F> acc = fe_one<F>();
+  for (int i = 255; i >= 0; i--) {
+    acc = sqr(acc);
+    if ((e[i >> 5] >> (i & 31)) & 1) acc = mul(acc, x);
+  }
+  return acc;
+}
+// Field inversion by Fermat (0 -> 0).  F_p: p - 2 = (2^59 + 16) * 2^192 + (2^192 - 1).
+template <class F> BP_HD Fe<F> inv(const Fe<F> &x) {
+  if constexpr (F::sparse) {
+    Fe<F> x2 = sqr(x), x3 = mul(x2, x), x6 = sqr(x3), x7 = mul(x6, x), x14 = sqr(x7), x15 = mul(x14, x);
+    Fe<F> t = x;
+    for (int i = 0; i < 55; i++) t = sqr(t);
+    t = mul(t, x);                          // x^(2^55 + 1)
+    for (int i = 0; i < 4; i++) t = sqr(t); // x^(2^59 + 16)
+    for (int i = 0; i < 48; i++) {          // 192 one-bits, 4 at a time
+      t = sqr(t); t = sqr(t); t = sqr(t); t = sqr(t);
+      t = mul(t, x15);
+    }
+    return t;
+  } else {
+    constexpr uint32_t E[8] = FN_EXP_INV_W;
+    uint32_t e[8];
+    for (int j = 0; j < 8; j++) e[j] = E[j];
+    return fe_pow(x, e);
+  }
+}
+
+}  // namespace bp
