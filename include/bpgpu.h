@@ -1,0 +1,142 @@
+/*
+ * bpgpu.h -- C ABI of the MI355X-native Bulletproofs hot path (Stark curve).
+ *
+ * Drop-in boundary for renegade-fi/mpc-bulletproof: the reference has no FFI; its hot path calls
+ * free functions of the external crate mpc-stark (Scalar, StarkPoint) at the sites cited below
+ * (paths relative to the reference root).  A Rust shim binds these symbols in place of those calls
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - scalar : 32-byte little-endian canonical integer < n (group order).  Non-canonical -> BPGPU_E_ARG.
+ *   - point  : affine x || y, 32-byte little-endian canonical each (< p); 64 zero bytes = identity
+ *              (the encoding the reference absorbs into the transcript, src/util.rs:274-289).
+ *              Off-curve / non-canonical -> BPGPU_E_ARG.
+ *   - all pointers are caller-owned; nothing allocated here crosses the boundary except opaque
+ *     handles released by the matching *_destroy; functions never throw; return 0 or BPGPU_E_*.
+ *   - thread-safe: a bpgpu_ctx may be shared by threads (calls on one ctx are serialised by an
+ *     internal mutex; use one ctx per thread for concurrency) -- the reference calls msm from rayon
+ *     workers and MPC-fabric executor threads (src/inner_product_proof.rs:233-247, src/transcript.rs:155-161).
+ *   - `_dev` variants take device pointers obtained from bpgpu_malloc (or any HIP allocation of the
+ *     same device, e.g. a torch tensor's data_ptr) and enqueue on the ctx stream without a host sync.
+ *   - no CPU fallback exists: without a usable HIP device every call returns BPGPU_E_DEVICE.
+ */
+#ifndef BPGPU_H
+#define BPGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPGPU_OK 0
+#define BPGPU_E_ARG (-1)     /* malformed input: non-canonical scalar, off-curve point, null pointer */
+#define BPGPU_E_LEN (-2)     /* length mismatch / not a power of two where required (reference panics: inner_product_proof.rs:62-70) */
+#define BPGPU_E_DEVICE (-3)  /* HIP error / no device */
+#define BPGPU_E_OOM (-4)
+#define BPGPU_E_GENS (-5)    /* generator capacity too small: R1CSError::InvalidGeneratorsLength (verifier.rs:421-423) */
+
+typedef struct bpgpu_ctx bpgpu_ctx;
+typedef struct bpgpu_gens bpgpu_gens;       /* resident generators + fixed-base tables */
+typedef struct bpgpu_circuit bpgpu_circuit; /* resident constraint weights (column-major) */
+
+/* ---- context ------------------------------------------------------------------------------- */
+int bpgpu_device_count(void);
+int bpgpu_create(int device, bpgpu_ctx **out);
+void bpgpu_destroy(bpgpu_ctx *ctx);
+const char *bpgpu_strerror(int code);
+const char *bpgpu_last_error(bpgpu_ctx *ctx);   /* text of the last HIP failure on this ctx */
+int bpgpu_sync(bpgpu_ctx *ctx);
+void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for event timing) */
+/* after a `_dev` call: synchronise and report whether any input of it was malformed (1) */
+int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
+
+/* device memory plumbing */
+int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);
+int bpgpu_free(bpgpu_ctx *ctx, void *dptr);
+int bpgpu_upload(bpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int bpgpu_download(bpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+
+/* ---- scalar field --------------------------------------------------------------------------
+ * Scalar::batch_inverse(&mut [Scalar])   -- src/inner_product_proof.rs:283
+ * Scalar::inverse()                      -- src/inner_product_proof.rs:123,181; r1cs/prover.rs:593; r1cs/verifier.rs:468
+ * In place.  A zero element -> BPGPU_E_ARG (mpc-stark/ark-ff leave zeros untouched; the reference
+ * only passes non-zero challenges). */
+int bpgpu_batch_inverse(bpgpu_ctx *ctx, uint8_t *scalars, size_t n);
+/* inner_product(a, b)                    -- src/inner_product_proof.rs:463-472 (panics on length
+ * mismatch: here the single n makes that unrepresentable) */
+int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t n, uint8_t out[32]);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------------
+ * StarkPoint::msm_iter(scalars, points) / StarkPoint::msm(&[..], &[..])
+ *   -- src/r1cs/prover.rs:465,477,485,535,546,555; src/inner_product_proof.rs:90,103,159,166,226-227,353;
+ *      src/r1cs/verifier.rs:516.  Accepts identity points, zero scalars, duplicate points, n == 0. */
+int bpgpu_msm(bpgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[64]);
+/* nb independent MSMs of n terms each (term-major within an MSM); out = nb points */
+int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
+                    uint8_t *out);
+
+/* ---- resident generators ---------------------------------------------------------------------
+ * BulletproofGens::share(0).G(n) / .H(n) and PedersenGens{B, B_blinding}
+ *   -- src/generators.rs:32-37,158-167,310-320.  Uploads the points once and precomputes signed
+ * fixed-window tables (window_bits in {4..16}; table bytes = (2*cap+2) * (252/c+1) * 2^(c-1) * 64). */
+int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t gens_capacity,
+                      const uint8_t B[64], const uint8_t B_blinding[64], int window_bits,
+                      bpgpu_gens **out);
+void bpgpu_gens_destroy(bpgpu_ctx *ctx, bpgpu_gens *g);
+size_t bpgpu_gens_capacity(const bpgpu_gens *g);
+/* sum_i s_i * X_i over the resident set, nb independent scalar vectors.  Layout of one vector:
+ * [B, B_blinding, G_0..G_{n-1}, H_0..H_{n-1}] (2 + 2n scalars), n <= capacity.
+ *   -- the generator part of prover.rs:465-494 and verifier.rs:525-530,541-544 */
+int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars,
+                   uint8_t *out);
+
+/* ---- inner-product argument ------------------------------------------------------------------
+ * InnerProductProof::fold_witness  -- src/inner_product_proof.rs:202-248
+ * Inputs hold [L half || R half] (2n entries each); outputs n entries:
+ *   a' = a_L u + u^-1 a_R ; b' = b_L u^-1 + u b_R ; G' = u^-1 G_L + u G_R ; H' = u H_L + u^-1 H_R */
+int bpgpu_fold_witness(bpgpu_ctx *ctx, size_t n, const uint8_t u[32], const uint8_t u_inv[32],
+                       const uint8_t *a, const uint8_t *b, const uint8_t *G, const uint8_t *H,
+                       uint8_t *a_out, uint8_t *b_out, uint8_t *G_out, uint8_t *H_out);
+/* arithmetic half of InnerProductProof::verification_scalars -- src/inner_product_proof.rs:280-309
+ * challenges u_1..u_k (creation order) -> u_sq[k], u_inv_sq[k], s[n], n == 2^k else BPGPU_E_LEN
+ * (the transcript replay of :271-278 stays on the host). */
+int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t k, size_t n,
+                               uint8_t *u_sq, uint8_t *u_inv_sq, uint8_t *s);
+
+/* ---- R1CS ------------------------------------------------------------------------------------
+ * Constraint rows as the reference holds them (Vec<LinearCombination>, r1cs/prover.rs:31,
+ * r1cs/verifier.rs:38): CSR with row_ptr[q+1]; per term kind (0 MultiplierLeft, 1 MultiplierRight,
+ * 2 MultiplierOutput, 3 Committed, 4 One -- linear_combination.rs:15-28), index, coefficient. */
+int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind,
+                         const uint32_t *idx, const uint8_t *coeff, size_t n_multipliers,
+                         size_t m_commitments, bpgpu_circuit **out);
+void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c);
+/* Prover/Verifier::flattened_constraints(z) -- r1cs/prover.rs:342-379, r1cs/verifier.rs:323-362.
+ * nb challenges z (one per proof) -> wL,wR,wO (nb x n), wV (nb x m), wc (nb) ; wc may be NULL (prover). */
+int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z,
+                              uint8_t *wL, uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc);
+
+/* Batched Verifier::verify arithmetic -- r1cs/verifier.rs:457-553 for nb proofs of ONE circuit.
+ * Per proof p (all arrays proof-major):
+ *   points     : (11 + m + 2k) x 64 B : A_I1 A_O1 S1 A_I2 A_O2 S2 | V_0..V_{m-1} | T_1 T_3 T_4 T_5 T_6 | L_0..L_{k-1} | R_0..R_{k-1}
+ *   scalars    : 5 x 32 B             : t_x t_x_blinding e_blinding a b
+ *   challenges : (6 + k) x 32 B       : y z u x w r u_1..u_k   (from the host transcript, verifier.rs:432-455,506)
+ * n1 = phase-1 multipliers (verifier.rs:400); padded_n = 2^k.
+ * Outputs: ok[p] = 1 iff mega_check is the identity (verifier.rs:549); mega (optional, nb x 64 B) the
+ * mega_check point itself; msm_scalars (optional, nb x nterms x 32 B) the scalars of verifier.rs:517-532
+ * in that order, nterms = 13 + m + 2*padded_n + 2k.
+ * The identity checks of transcript.rs:101-113 belong to the host transcript replay. */
+int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
+                            size_t n1, size_t k, const uint8_t *points, const uint8_t *scalars,
+                            const uint8_t *challenges, int32_t *ok, uint8_t *mega, uint8_t *msm_scalars);
+/* same with device-resident inputs/outputs (mega_dev / msm_scalars_dev may be NULL); asynchronous */
+int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
+                                size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
+                                const void *challenges_dev, void *ok_dev, void *mega_dev,
+                                void *msm_scalars_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

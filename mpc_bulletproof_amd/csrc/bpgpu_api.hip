@@ -1,0 +1,645 @@
+// bpgpu_api.hip -- the C ABI of include/bpgpu.h on top of the HIP kernels.
+// No CPU fallback: every entry point needs a live HIP device and fails with BPGPU_E_DEVICE otherwise.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+#include "kernels.h"
+#include "fe29.cuh"
+
+using namespace bpk;
+
+namespace {
+
+struct Slot { void *p = nullptr; size_t cap = 0; };
+
+}  // namespace
+
+struct bpgpu_ctx {
+  int device = 0;
+  hipStream_t st = nullptr, st2 = nullptr;
+  hipEvent_t ev1 = nullptr, ev2 = nullptr;
+  std::mutex mu;
+  std::string err;
+  int *d_flag = nullptr;          // device int: bad-input flag
+  Slot ws[16];                    // grow-only workspace slots
+};
+struct bpgpu_gens {
+  size_t cap = 0;
+  int c = 0;
+  AffDev *points = nullptr;       // [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}]
+  AffDev *table = nullptr;        // (2 + 2 cap) * W * 2^(c-1)
+};
+struct bpgpu_circuit {
+  size_t q = 0, n = 0, m = 0, nnz = 0;
+  uint32_t *col_ptr = nullptr, *row = nullptr;
+  Words8 *coeff = nullptr;
+};
+
+#define HIPCK(ctx, call)                                                                    \
+  do {                                                                                      \
+    hipError_t e__ = (call);                                                                \
+    if (e__ != hipSuccess) {                                                                \
+      (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e__);                      \
+      return e__ == hipErrorOutOfMemory ? BPGPU_E_OOM : BPGPU_E_DEVICE;                     \
+    }                                                                                       \
+  } while (0)
+#define CK(x)                \
+  do {                       \
+    int rc__ = (x);          \
+    if (rc__ != BPGPU_OK) return rc__; \
+  } while (0)
+
+static int ws_get(bpgpu_ctx *ctx, int slot, size_t bytes, void **out) {
+  Slot &s = ctx->ws[slot];
+  if (bytes < 256) bytes = 256;
+  if (s.cap < bytes) {
+    if (s.p) { HIPCK(ctx, hipStreamSynchronize(ctx->st)); HIPCK(ctx, hipStreamSynchronize(ctx->st2)); HIPCK(ctx, hipFree(s.p)); s.p = nullptr; s.cap = 0; }
+    size_t want = bytes + bytes / 4;
+    HIPCK(ctx, hipMalloc(&s.p, want));
+    s.cap = want;
+  }
+  *out = s.p;
+  return BPGPU_OK;
+}
+static int flag_reset(bpgpu_ctx *ctx) { HIPCK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->st)); return BPGPU_OK; }
+static int flag_read(bpgpu_ctx *ctx, int *v) {
+  HIPCK(ctx, hipMemcpyAsync(v, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+static int h2d(bpgpu_ctx *ctx, void *d, const void *h, size_t n) {
+  if (n) HIPCK(ctx, hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, ctx->st));
+  return BPGPU_OK;
+}
+static int d2h(bpgpu_ctx *ctx, void *h, const void *d, size_t n) {
+  if (n) HIPCK(ctx, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, ctx->st));
+  return BPGPU_OK;
+}
+static int launch_ok(bpgpu_ctx *ctx) { HIPCK(ctx, hipGetLastError()); return BPGPU_OK; }
+
+// ---- small device helpers that live with the API ------------------------------------------------
+__global__ void k_coeff_to_mont(Words8 *io, size_t n, int *bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  for (int j = 0; j < 8; j++) w[j] = io[i].w[j];
+  if (!bp::words_lt_mod<bp::FN>(w)) { atomicOr(bad, 1); return; }
+  bp::Fn x = bp::canon(bp::to_mont(bp::unpack<bp::FN>(w)));
+  bp::pack(w, x);
+  for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
+}
+// expand [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] scalars (2 + 2n per MSM) to table-row order when n < cap
+__global__ void k_expand_gens_scalars(const uint32_t *in, uint32_t *out, size_t n, size_t cap, size_t nb) {
+  size_t per_out = 2 + 2 * cap;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * per_out) return;
+  size_t b = t / per_out, g = t % per_out;
+  long src = -1;
+  if (g < 2) src = (long)g;
+  else if (g < 2 + cap) { if (g - 2 < n) src = (long)g; }
+  else { if (g - 2 - cap < n) src = (long)(2 + n + (g - 2 - cap)); }
+  for (int j = 0; j < 8; j++) out[t * 8 + j] = src >= 0 ? in[(b * (2 + 2 * n) + (size_t)src) * 8 + j] : 0u;
+}
+static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
+                        hipStream_t st) {
+  size_t ng = 2 + 2 * g->cap;
+  if (n == g->cap) {
+    fixed_msm(st, g->c, g->table, ng, dsc, ng * 8, dres, nb);
+  } else {
+    void *dexp;
+    CK(ws_get(ctx, 12, nb * ng * 32, &dexp));
+    size_t tot = nb * ng;
+    hipLaunchKernelGGL(k_expand_gens_scalars, dim3((tot + 255) / 256), dim3(256), 0, st, dsc, (uint32_t *)dexp, n,
+                       g->cap, nb);
+    fixed_msm(st, g->c, g->table, ng, (const uint32_t *)dexp, ng * 8, dres, nb);
+  }
+  return BPGPU_OK;
+}
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int bpgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+const char *bpgpu_strerror(int code) {
+  switch (code) {
+    case BPGPU_OK: return "ok";
+    case BPGPU_E_ARG: return "malformed argument (non-canonical scalar, off-curve point, null pointer)";
+    case BPGPU_E_LEN: return "length mismatch";
+    case BPGPU_E_DEVICE: return "HIP device error (no CPU fallback exists)";
+    case BPGPU_E_OOM: return "out of device memory";
+    case BPGPU_E_GENS: return "generator capacity too small";
+    default: return "unknown";
+  }
+}
+int bpgpu_create(int device, bpgpu_ctx **out) {
+  if (!out) return BPGPU_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) return BPGPU_E_DEVICE;
+  bpgpu_ctx *ctx = new (std::nothrow) bpgpu_ctx();
+  if (!ctx) return BPGPU_E_OOM;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess ||
+      hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess) {
+    delete ctx;
+    return BPGPU_E_DEVICE;
+  }
+  *out = ctx;
+  return BPGPU_OK;
+}
+void bpgpu_destroy(bpgpu_ctx *ctx) {
+  if (!ctx) return;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->st);
+  hipStreamSynchronize(ctx->st2);
+  for (auto &s : ctx->ws) if (s.p) hipFree(s.p);
+  hipFree(ctx->d_flag);
+  hipEventDestroy(ctx->ev1);
+  hipEventDestroy(ctx->ev2);
+  hipStreamDestroy(ctx->st);
+  hipStreamDestroy(ctx->st2);
+  delete ctx;
+}
+const char *bpgpu_last_error(bpgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+int bpgpu_sync(bpgpu_ctx *ctx) {
+  if (!ctx) return BPGPU_E_ARG;
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  return BPGPU_OK;
+}
+void *bpgpu_stream(bpgpu_ctx *ctx) { return ctx ? (void *)ctx->st : nullptr; }
+int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad) {
+  if (!ctx || !bad) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  return flag_read(ctx, bad);
+}
+int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr) {
+  if (!ctx || !dptr) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  HIPCK(ctx, hipMalloc(dptr, bytes ? bytes : 4));
+  return BPGPU_OK;
+}
+int bpgpu_free(bpgpu_ctx *ctx, void *dptr) {
+  if (!ctx) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  if (dptr) HIPCK(ctx, hipFree(dptr));
+  return BPGPU_OK;
+}
+int bpgpu_upload(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CK(h2d(ctx, dst, src, bytes));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_download(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  CK(d2h(ctx, dst, src, bytes));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- scalar field */
+int bpgpu_batch_inverse(bpgpu_ctx *ctx, uint8_t *scalars, size_t n) {
+  if (!ctx || (n && !scalars)) return BPGPU_E_ARG;
+  if (!n) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *d;
+  CK(ws_get(ctx, 0, n * 32, &d));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, d, scalars, n * 32));
+  scalars_check(ctx->st, (Words8 *)d, n, ctx->d_flag);
+  batch_inverse(ctx->st, (Words8 *)d, n, ctx->d_flag);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, scalars, d, n * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size_t n, uint8_t out[32]) {
+  if (!ctx || !out || (n && (!a || !b))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *da, *db, *dout, *scr;
+  CK(ws_get(ctx, 0, n * 32, &da));
+  CK(ws_get(ctx, 1, n * 32, &db));
+  CK(ws_get(ctx, 2, 32, &dout));
+  CK(ws_get(ctx, 3, inner_product_scratch_bytes(n), &scr));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, da, a, n * 32));
+  CK(h2d(ctx, db, b, n * 32));
+  scalars_check(ctx->st, (Words8 *)da, n, ctx->d_flag);
+  scalars_check(ctx->st, (Words8 *)db, n, ctx->d_flag);
+  inner_product(ctx->st, (Words8 *)da, (Words8 *)db, n, (Words8 *)dout, scr);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- MSM (general points) */
+static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
+                            uint8_t *out) {
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t tot = nb * n;
+  if (!nb) return BPGPU_OK;
+  if (!n) { memset(out, 0, nb * 64); return BPGPU_OK; }
+  void *dsc, *dxy, *dpts, *dres, *dsum, *dout;
+  CK(ws_get(ctx, 0, tot * 32, &dsc));
+  CK(ws_get(ctx, 1, tot * 64, &dxy));
+  CK(ws_get(ctx, 2, tot * sizeof(AffDev), &dpts));
+  CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
+  CK(ws_get(ctx, 4, nb * sizeof(JacRaw), &dsum));
+  CK(ws_get(ctx, 5, nb * 64, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dsc, scalars, tot * 32));
+  CK(h2d(ctx, dxy, points, tot * 64));
+  scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
+  points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, tot, ctx->d_flag);
+  StrausArgs a{};
+  a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
+  a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
+  straus(ctx->st, 1, a, (JacRaw *)dres, tot);
+  segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nb, n);
+  jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nb);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, nb * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_msm(bpgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && (!scalars || !points))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return msm_batch_locked(ctx, 1, n, scalars, points, out);
+}
+int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
+                    uint8_t *out) {
+  if (!ctx || (nb && !out) || (nb && n && (!scalars || !points))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return msm_batch_locked(ctx, nb, n, scalars, points, out);
+}
+
+/* ---------------------------------------------------------------- resident generators */
+int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t cap, const uint8_t B[64],
+                      const uint8_t Bb[64], int c, bpgpu_gens **out) {
+  if (!ctx || !out || !B || !Bb || (cap && (!G || !H))) return BPGPU_E_ARG;
+  if (!(c == 4 || c == 8 || c == 10 || c == 12 || c == 14 || c == 16)) return BPGPU_E_ARG;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t ng = 2 + 2 * cap;
+  bpgpu_gens *g = new (std::nothrow) bpgpu_gens();
+  if (!g) return BPGPU_E_OOM;
+  g->cap = cap;
+  g->c = c;
+  std::vector<uint8_t> host(ng * 64);
+  memcpy(&host[0], B, 64);
+  memcpy(&host[64], Bb, 64);
+  if (cap) { memcpy(&host[128], G, cap * 64); memcpy(&host[128 + cap * 64], H, cap * 64); }
+  size_t entries = fixed_table_entries(c, ng);
+  size_t W = 252 / c + 1;
+  void *dxy = nullptr, *scratch = nullptr;
+  auto fail = [&](int rc) {
+    if (dxy) hipFree(dxy);
+    if (scratch) hipFree(scratch);
+    if (g->points) hipFree(g->points);
+    if (g->table) hipFree(g->table);
+    delete g;
+    return rc;
+  };
+#define GCK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(e__); return fail(e__ == hipErrorOutOfMemory ? BPGPU_E_OOM : BPGPU_E_DEVICE); } } while (0)
+  GCK(hipMalloc(&dxy, ng * 64));
+  GCK(hipMalloc((void **)&g->points, ng * sizeof(AffDev)));
+  GCK(hipMalloc((void **)&g->table, entries * sizeof(AffDev)));
+  GCK(hipMalloc(&scratch, (ng * W + entries) * sizeof(JacRaw)));
+  GCK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->st));
+  GCK(hipMemcpyAsync(dxy, host.data(), ng * 64, hipMemcpyHostToDevice, ctx->st));
+  points_from_boundary(ctx->st, (Words8 *)dxy, g->points, ng, ctx->d_flag);
+  fixed_table_build(ctx->st, c, g->points, ng, g->table, (JacRaw *)scratch);
+  GCK(hipGetLastError());
+  int bad = 0;
+  GCK(hipMemcpyAsync(&bad, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
+  GCK(hipStreamSynchronize(ctx->st));
+#undef GCK
+  hipFree(dxy); dxy = nullptr;
+  hipFree(scratch); scratch = nullptr;
+  if (bad) return fail(BPGPU_E_ARG);
+  *out = g;
+  return BPGPU_OK;
+}
+void bpgpu_gens_destroy(bpgpu_ctx *ctx, bpgpu_gens *g) {
+  if (!g) return;
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
+  hipFree(g->points);
+  hipFree(g->table);
+  delete g;
+}
+size_t bpgpu_gens_capacity(const bpgpu_gens *g) { return g ? g->cap : 0; }
+
+int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars, uint8_t *out) {
+  if (!ctx || !g || (nb && (!scalars || !out))) return BPGPU_E_ARG;
+  if (n > g->cap) return BPGPU_E_GENS;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t per = 2 + 2 * n, tot = nb * per;
+  void *dsc, *dres, *dout;
+  CK(ws_get(ctx, 0, tot * 32, &dsc));
+  CK(ws_get(ctx, 4, nb * sizeof(JacRaw), &dres));
+  CK(ws_get(ctx, 5, nb * 64, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dsc, scalars, tot * 32));
+  scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
+  CK(msm_gens_dev(ctx, g, nb, n, (uint32_t *)dsc, (JacRaw *)dres, ctx->st));
+  jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, nb * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- IPP */
+int bpgpu_fold_witness(bpgpu_ctx *ctx, size_t n, const uint8_t u[32], const uint8_t u_inv[32], const uint8_t *a,
+                       const uint8_t *b, const uint8_t *G, const uint8_t *H, uint8_t *a_out, uint8_t *b_out,
+                       uint8_t *G_out, uint8_t *H_out) {
+  if (!ctx || !u || !u_inv || (n && (!a || !b || !G || !H || !a_out || !b_out || !G_out || !H_out))) return BPGPU_E_ARG;
+  if (!n) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  // slot 0: scalars u, u_inv, a[2n], b[2n], a_out[n], b_out[n]
+  void *dsc, *dxy, *dpts, *dres, *dout;
+  size_t nsc = 2 + 4 * n + 2 * n;
+  CK(ws_get(ctx, 0, nsc * 32, &dsc));
+  CK(ws_get(ctx, 1, 4 * n * 64, &dxy));
+  CK(ws_get(ctx, 2, 4 * n * sizeof(AffDev), &dpts));
+  CK(ws_get(ctx, 3, 2 * n * sizeof(JacRaw), &dres));
+  CK(ws_get(ctx, 5, 2 * n * 64, &dout));
+  Words8 *w = (Words8 *)dsc;
+  Words8 *du = w, *dui = w + 1, *da = w + 2, *db = w + 2 + 2 * n, *dao = w + 2 + 4 * n, *dbo = w + 2 + 5 * n;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, du, u, 32));
+  CK(h2d(ctx, dui, u_inv, 32));
+  CK(h2d(ctx, da, a, 2 * n * 32));
+  CK(h2d(ctx, db, b, 2 * n * 32));
+  CK(h2d(ctx, dxy, G, 2 * n * 64));
+  CK(h2d(ctx, (uint8_t *)dxy + 2 * n * 64, H, 2 * n * 64));
+  scalars_check(ctx->st, w, 2 + 4 * n, ctx->d_flag);
+  points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, 4 * n, ctx->d_flag);
+  fold_scalars(ctx->st, n, du, dui, da, db, dao, dbo);
+  AffDev *dG = (AffDev *)dpts, *dH = dG + 2 * n;
+  StrausArgs sg{};   // G' = u^-1 G_L + u G_R
+  sg.pts[0] = dG; sg.pts[1] = dG + n; sg.pt_stride[0] = sg.pt_stride[1] = 1;
+  sg.sc[0] = (uint32_t *)dui; sg.sc[1] = (uint32_t *)du; sg.sc_stride[0] = sg.sc_stride[1] = 0;
+  straus(ctx->st, 2, sg, (JacRaw *)dres, n);
+  StrausArgs sh{};   // H' = u H_L + u^-1 H_R
+  sh.pts[0] = dH; sh.pts[1] = dH + n; sh.pt_stride[0] = sh.pt_stride[1] = 1;
+  sh.sc[0] = (uint32_t *)du; sh.sc[1] = (uint32_t *)dui; sh.sc_stride[0] = sh.sc_stride[1] = 0;
+  straus(ctx->st, 2, sh, (JacRaw *)dres + n, n);
+  jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, 2 * n);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, a_out, dao, n * 32));
+  CK(d2h(ctx, b_out, dbo, n * 32));
+  CK(d2h(ctx, G_out, dout, n * 64));
+  CK(d2h(ctx, H_out, (uint8_t *)dout + n * 64, n * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t k, size_t n, uint8_t *u_sq,
+                               uint8_t *u_inv_sq, uint8_t *s) {
+  if (!ctx || !s || (k && (!challenges || !u_sq || !u_inv_sq))) return BPGPU_E_ARG;
+  if (k >= 32 || n != ((size_t)1 << k)) return BPGPU_E_LEN;   // inner_product_proof.rs:259-267
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *d;
+  CK(ws_get(ctx, 0, (3 * k + n + 1) * 32, &d));
+  Words8 *w = (Words8 *)d;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, w, challenges, k * 32));
+  scalars_check(ctx->st, w, k, ctx->d_flag);
+  verification_scalars(ctx->st, w, k, n, w + k, w + 2 * k, w + 3 * k);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, u_sq, w + k, k * 32));
+  CK(d2h(ctx, u_inv_sq, w + 2 * k, k * 32));
+  CK(d2h(ctx, s, w + 3 * k, n * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- R1CS */
+int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
+                         const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
+  if (!ctx || !out || !row_ptr) return BPGPU_E_ARG;
+  *out = nullptr;
+  size_t nnz = row_ptr[q];
+  if (nnz && (!kind || !idx || !coeff)) return BPGPU_E_ARG;
+  // CSR (row-major, as the reference holds constraints) -> column-major by output variable
+  size_t nout = 3 * n_mul + m + 1;
+  std::vector<uint32_t> col_ptr(nout + 1, 0), rows(nnz ? nnz : 1);
+  std::vector<uint8_t> cf((nnz ? nnz : 1) * 32);
+  auto out_of = [&](size_t t, size_t &o) -> bool {
+    uint32_t kd = kind[t], ix = idx[t];
+    if (kd <= 2) { if (ix >= n_mul) return false; o = kd * n_mul + ix; }
+    else if (kd == 3) { if (ix >= m) return false; o = 3 * n_mul + ix; }
+    else if (kd == 4) o = 3 * n_mul + m;
+    else return false;
+    return true;
+  };
+  for (size_t r = 0; r < q; r++) {
+    if (row_ptr[r + 1] < row_ptr[r]) return BPGPU_E_ARG;
+    for (size_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
+      size_t o;
+      if (!out_of(t, o)) return BPGPU_E_ARG;
+      col_ptr[o + 1]++;
+    }
+  }
+  for (size_t o = 0; o < nout; o++) col_ptr[o + 1] += col_ptr[o];
+  std::vector<uint32_t> fillp(col_ptr.begin(), col_ptr.end() - 1);
+  for (size_t r = 0; r < q; r++)
+    for (size_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
+      size_t o;
+      out_of(t, o);
+      uint32_t pos = fillp[o]++;
+      rows[pos] = (uint32_t)r;
+      memcpy(&cf[(size_t)pos * 32], coeff + t * 32, 32);
+    }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  bpgpu_circuit *c = new (std::nothrow) bpgpu_circuit();
+  if (!c) return BPGPU_E_OOM;
+  c->q = q; c->n = n_mul; c->m = m; c->nnz = nnz;
+  auto fail = [&](int rc) { hipFree(c->col_ptr); hipFree(c->row); hipFree(c->coeff); delete c; return rc; };
+  if (hipMalloc((void **)&c->col_ptr, (nout + 1) * 4) != hipSuccess || hipMalloc((void **)&c->row, (nnz ? nnz : 1) * 4) != hipSuccess ||
+      hipMalloc((void **)&c->coeff, (nnz ? nnz : 1) * 32) != hipSuccess)
+    return fail(BPGPU_E_OOM);
+  if (hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->st) != hipSuccess ||
+      hipMemcpyAsync(c->col_ptr, col_ptr.data(), (nout + 1) * 4, hipMemcpyHostToDevice, ctx->st) != hipSuccess ||
+      hipMemcpyAsync(c->row, rows.data(), (nnz ? nnz : 1) * 4, hipMemcpyHostToDevice, ctx->st) != hipSuccess ||
+      hipMemcpyAsync(c->coeff, cf.data(), (nnz ? nnz : 1) * 32, hipMemcpyHostToDevice, ctx->st) != hipSuccess)
+    return fail(BPGPU_E_DEVICE);
+  if (nnz) hipLaunchKernelGGL(k_coeff_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, ctx->st, c->coeff, nnz, ctx->d_flag);
+  int bad = 0;
+  if (hipMemcpyAsync(&bad, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st) != hipSuccess ||
+      hipStreamSynchronize(ctx->st) != hipSuccess)
+    return fail(BPGPU_E_DEVICE);
+  if (bad) return fail(BPGPU_E_ARG);
+  *out = c;
+  return BPGPU_OK;
+}
+void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c) {
+  if (!c) return;
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
+  hipFree(c->col_ptr);
+  hipFree(c->row);
+  hipFree(c->coeff);
+  delete c;
+}
+static CircuitDev circuit_dev(const bpgpu_circuit *c) {
+  CircuitDev d;
+  d.col_ptr = c->col_ptr; d.row = c->row; d.coeff = c->coeff;
+  d.q = c->q; d.n = c->n; d.m = c->m; d.nnz = c->nnz;
+  return d;
+}
+int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z, uint8_t *wL,
+                              uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc) {
+  if (!ctx || !c || (nb && (!z || (c->n && (!wL || !wR || !wO)) || (c->m && !wV)))) return BPGPU_E_ARG;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t n = c->n, m = c->m;
+  void *dz, *dw, *dzp;
+  CK(ws_get(ctx, 0, nb * 32, &dz));
+  CK(ws_get(ctx, 1, nb * (3 * n + m + 1) * 32, &dw));
+  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  Words8 *w = (Words8 *)dw;
+  Words8 *dL = w, *dR = w + nb * n, *dO = w + 2 * nb * n, *dV = w + 3 * nb * n, *dC = w + 3 * nb * n + nb * m;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dz, z, nb * 32));
+  scalars_check(ctx->st, (Words8 *)dz, nb, ctx->d_flag);
+  flatten(ctx->st, circuit_dev(c), nb, (Words8 *)dz, 8, dL, dR, dO, dV, dC, (int32_t *)dzp);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, wL, dL, nb * n * 32));
+  CK(d2h(ctx, wR, dR, nb * n * 32));
+  CK(d2h(ctx, wO, dO, nb * n * 32));
+  CK(d2h(ctx, wV, dV, nb * m * 32));
+  if (wc) CK(d2h(ctx, wc, dC, nb * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                   size_t k, const void *points, const void *scalars, const void *challenges,
+                                   void *ok, void *mega, void *full_sc) {
+  if (k >= 32) return BPGPU_E_LEN;
+  size_t np = (size_t)1 << k, n = c->n, m = c->m;
+  if (n > np || n1 > n || (np > 1 && n <= np / 2 && n != 0)) return BPGPU_E_LEN;   // padded_n = next_pow2(n)
+  if (np > g->cap) return BPGPU_E_GENS;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t nvar = 11 + m + 2 * k, nfix = 2 + 2 * np;
+  void *dpts, *dfix, *dvar, *dzp, *dvres, *dfres;
+  CK(ws_get(ctx, 7, nb * nvar * sizeof(AffDev), &dpts));
+  CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
+  CK(ws_get(ctx, 9, nb * nvar * 32, &dvar));
+  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
+  CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
+  VerifyDims d{nb, n1, n, np, k, m};
+  CK(flag_reset(ctx));
+  // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
+  scalars_check(ctx->st, (const Words8 *)scalars, nb * 5, ctx->d_flag);
+  scalars_check(ctx->st, (const Words8 *)challenges, nb * (6 + k), ctx->d_flag);
+  verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
+                 (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag);
+  HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
+  HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
+  CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2));
+  HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
+  points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
+  StrausArgs a{};
+  a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
+  a.sc[0] = (uint32_t *)dvar; a.sc_stride[0] = 8;
+  straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar);
+  HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
+  verify_finalize(ctx->st, (JacRaw *)dvres, nvar, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
+  return launch_ok(ctx);
+}
+int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                size_t k, const void *points, const void *scalars, const void *challenges,
+                                void *ok, void *mega, void *full_sc) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, ok, mega, full_sc);
+}
+int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                            size_t k, const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges,
+                            int32_t *ok, uint8_t *mega, uint8_t *msm_scalars) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok))) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t np = (size_t)1 << k, m = c->m, nvar = 11 + m + 2 * k, nterms = 13 + m + 2 * np + 2 * k;
+  void *dP, *dS, *dC, *dok, *dmega, *dfull = nullptr;
+  CK(ws_get(ctx, 0, nb * nvar * 64, &dP));
+  CK(ws_get(ctx, 1, nb * 5 * 32, &dS));
+  CK(ws_get(ctx, 2, nb * (6 + k) * 32, &dC));
+  CK(ws_get(ctx, 3, nb * 4, &dok));
+  CK(ws_get(ctx, 4, nb * 64, &dmega));
+  if (msm_scalars) CK(ws_get(ctx, 5, nb * nterms * 32, &dfull));
+  CK(h2d(ctx, dP, points, nb * nvar * 64));
+  CK(h2d(ctx, dS, scalars, nb * 5 * 32));
+  CK(h2d(ctx, dC, challenges, nb * (6 + k) * 32));
+  CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, dP, dS, dC, dok, mega ? dmega : nullptr, dfull));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, ok, dok, nb * 4));
+  if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
+  if (msm_scalars) CK(d2h(ctx, msm_scalars, dfull, nb * nterms * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+#pragma GCC visibility pop
+}  // extern "C"
+

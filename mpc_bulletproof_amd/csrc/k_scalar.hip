@@ -1,0 +1,365 @@
+// k_scalar.hip -- scalar-field (F_n) kernels: canonical checks, batched inversion, inner products,
+// IPP scalar fold, verification scalars, constraint flattening, verifier scalar assembly.
+//
+// Hot-path rows: a2 (scalar half of fold_witness), a4 inner_product, a5
+// verification_scalars, a6 batch_inverse, a7 flattened_constraints, a9 verifier scalar assembly.
+#include "fe29.cuh"
+#include "kernels.h"
+
+using namespace bp;
+
+namespace bpk {
+
+__device__ __forceinline__ Fn load_plain(const Words8 *p) {   // plain canonical words -> Montgomery
+  uint32_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j] = p->w[j];
+  return to_mont(unpack<FN>(w));
+}
+__device__ __forceinline__ void store_plain(Words8 *p, const Fn &x) {   // Montgomery -> plain canonical words
+  uint32_t w[8];
+  pack(w, from_mont(x));
+#pragma unroll
+  for (int j = 0; j < 8; j++) p->w[j] = w[j];
+}
+__device__ __forceinline__ Fn fn_from_u32(uint32_t v) {
+  Fn t = fe_zero<FN>();
+  t.v[0] = (int32_t)(v & LMASK);
+  t.v[1] = (int32_t)(v >> LB);
+  return to_mont(t);
+}
+__device__ __forceinline__ Fn fn_pow_u32(Fn base, uint32_t e) {   // base^e, e >= 0
+  Fn acc = fe_one<FN>();
+  while (e) {
+    if (e & 1) acc = mul(acc, base);
+    e >>= 1;
+    if (e) base = sqr(base);
+  }
+  return acc;
+}
+// raw limb I/O for device scratch (zpow tables, partial sums)
+__device__ __forceinline__ void raw_put(int32_t *d, const Fn &x) {
+#pragma unroll
+  for (int j = 0; j < NL; j++) d[j] = x.v[j];
+}
+__device__ __forceinline__ Fn raw_get(const int32_t *s) {
+  Fn x;
+#pragma unroll
+  for (int j = 0; j < NL; j++) x.v[j] = s[j];
+  return x;
+}
+// wave-level sum of one Fn per lane (shuffle tree); result in every lane
+__device__ __forceinline__ Fn wave_sum(Fn x) {
+#pragma unroll 1
+  for (int off = 32; off > 0; off >>= 1) {
+    Fn o;
+#pragma unroll
+    for (int j = 0; j < NL; j++) o.v[j] = __shfl_xor(x.v[j], off, 64);
+    x = add(x, o);
+  }
+  return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_scalars_check(const Words8 *in, size_t n, int *bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j] = in[i].w[j];
+  if (!words_lt_mod<FN>(w)) atomicOr(bad, 1);
+}
+void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scalars_check, dim3((n + 255) / 256), dim3(256), 0, st, in, n, bad);
+}
+
+// Scalar::batch_inverse: Montgomery's trick, RUN elements per lane, one Fermat inversion per lane
+template <int RUN>
+__global__ void __launch_bounds__(64) k_batch_inverse(Words8 *io, size_t n, int *bad_zero) {
+  size_t base = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * RUN;
+  if (base >= n) return;
+  Fn pref[RUN], val[RUN];
+  Fn acc = fe_one<FN>();
+#pragma unroll
+  for (int i = 0; i < RUN; i++) {
+    pref[i] = acc;
+    if (base + i < n) {
+      val[i] = load_plain(&io[base + i]);
+      if (is_zero_exact(val[i])) { atomicOr(bad_zero, 1); val[i] = fe_one<FN>(); }
+      acc = mul(acc, val[i]);
+    }
+  }
+  Fn ai = inv(acc);
+#pragma unroll
+  for (int i = RUN - 1; i >= 0; i--) {
+    if (base + i < n) {
+      store_plain(&io[base + i], mul(ai, pref[i]));
+      ai = mul(ai, val[i]);
+    }
+  }
+}
+void batch_inverse(hipStream_t st, Words8 *io, size_t n, int *bad_zero) {
+  if (!n) return;
+  size_t lanes = (n + 3) / 4;
+  hipLaunchKernelGGL(k_batch_inverse<4>, dim3((lanes + 63) / 64), dim3(64), 0, st, io, n, bad_zero);
+}
+
+// inner_product: grid-stride partial sums, one raw partial per block, then a single-block finish
+constexpr int IP_TPB = 256;
+__global__ void __launch_bounds__(IP_TPB) k_inner_product_partial(const Words8 *a, const Words8 *b, size_t n, int32_t *partials) {
+  __shared__ int32_t sm[NL * (IP_TPB / 64)];
+  Fn acc = fe_zero<FN>();
+  for (size_t i = (size_t)blockIdx.x * IP_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * IP_TPB)
+    acc = add(acc, mul(load_plain(&a[i]), load_plain(&b[i])));
+  acc = wave_sum(acc);
+  int wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) raw_put(sm + wv * NL, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fn t = raw_get(sm);
+    for (int w = 1; w < IP_TPB / 64; w++) t = add(t, raw_get(sm + w * NL));
+    raw_put(partials + (size_t)blockIdx.x * NL, t);
+  }
+}
+__global__ void __launch_bounds__(64) k_inner_product_finish(const int32_t *partials, int nparts, Words8 *out) {
+  Fn acc = fe_zero<FN>();
+  for (int i = threadIdx.x; i < nparts; i += 64) acc = add(acc, raw_get(partials + (size_t)i * NL));
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) store_plain(out, acc);
+}
+static int ip_blocks(size_t n) {
+  size_t b = (n + IP_TPB - 1) / IP_TPB;
+  return (int)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+size_t inner_product_scratch_bytes(size_t n) { return (size_t)ip_blocks(n) * NL * 4; }
+void inner_product(hipStream_t st, const Words8 *a, const Words8 *b, size_t n, Words8 *out, void *scratch) {
+  int nb = ip_blocks(n);
+  hipLaunchKernelGGL(k_inner_product_partial, dim3(nb), dim3(IP_TPB), 0, st, a, b, n, (int32_t *)scratch);
+  hipLaunchKernelGGL(k_inner_product_finish, dim3(1), dim3(64), 0, st, (const int32_t *)scratch, nb, out);
+}
+
+// inner_product_proof.rs:224-225,239-240: a' = a_L u + u^-1 a_R ; b' = b_L u^-1 + u b_R
+__global__ void __launch_bounds__(256) k_fold_scalars(size_t n, const Words8 *u, const Words8 *u_inv, const Words8 *a,
+                                                      const Words8 *b, Words8 *a_out, Words8 *b_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Fn uu = load_plain(u), ui = load_plain(u_inv);
+  Fn aL = load_plain(&a[i]), aR = load_plain(&a[n + i]), bL = load_plain(&b[i]), bR = load_plain(&b[n + i]);
+  store_plain(&a_out[i], add(mul(aL, uu), mul(ui, aR)));
+  store_plain(&b_out[i], add(mul(bL, ui), mul(uu, bR)));
+}
+void fold_scalars(hipStream_t st, size_t n, const Words8 *u, const Words8 *u_inv, const Words8 *a,
+                  const Words8 *b, Words8 *a_out, Words8 *b_out) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_fold_scalars, dim3((n + 255) / 256), dim3(256), 0, st, n, u, u_inv, a, b, a_out, b_out);
+}
+
+// inner_product_proof.rs:280-309.  One block; lane 0 inverts (Montgomery trick over the k challenges);
+// s_i = allinv * prod_{b : bit b of i} u_sq[(k-1)-b]  (closed form of the reference's induction :298-307)
+__global__ void __launch_bounds__(256) k_verification_scalars(const Words8 *ch, int k, size_t n, Words8 *u_sq,
+                                                             Words8 *u_inv_sq, Words8 *s) {
+  __shared__ int32_t sm[(32 + 1) * NL];   // u_sq[k] (k < 32), allinv
+  if (threadIdx.x == 0) {
+    Fn pref[32], val[32];
+    Fn acc = fe_one<FN>();
+    for (int i = 0; i < k; i++) { pref[i] = acc; val[i] = load_plain(&ch[i]); acc = mul(acc, val[i]); }
+    Fn ai = inv(acc);
+    Fn allinv = ai;   // 1 / (u_1 ... u_k)
+    for (int i = k - 1; i >= 0; i--) {
+      Fn ui = mul(ai, pref[i]);
+      ai = mul(ai, val[i]);
+      Fn us = sqr(val[i]);
+      store_plain(&u_sq[i], us);
+      store_plain(&u_inv_sq[i], sqr(ui));
+      raw_put(sm + i * NL, us);
+    }
+    raw_put(sm + 32 * NL, allinv);
+  }
+  __syncthreads();
+  Fn allinv = raw_get(sm + 32 * NL);
+  for (size_t i = threadIdx.x; i < n; i += blockDim.x) {
+    Fn v = allinv;
+    for (int b = 0; b < k; b++)
+      if ((i >> b) & 1) v = mul(v, raw_get(sm + (k - 1 - b) * NL));
+    store_plain(&s[i], v);
+  }
+}
+void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, size_t n, Words8 *u_sq,
+                          Words8 *u_inv_sq, Words8 *s) {
+  hipLaunchKernelGGL(k_verification_scalars, dim3(1), dim3(256), 0, st, challenges, (int)k, n, u_sq, u_inv_sq, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// flattened_constraints: zpow[b][r] = z_b^(r+1); output o = sum over its column of coeff * zpow[row]
+// (w_V and w_c carry the reference's minus sign: prover.rs:367-369, verifier.rs:349-354)
+__global__ void __launch_bounds__(256) k_zpow(const Words8 *z, size_t z_stride, size_t q, int32_t *zpow) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t b = blockIdx.y;
+  if (r >= q) return;
+  Fn zz = load_plain((const Words8 *)((const uint32_t *)z + b * z_stride));
+  raw_put(zpow + (b * q + r) * NL, fn_pow_u32(zz, (uint32_t)r + 1));
+}
+__device__ __forceinline__ Fn flatten_column(const CircuitDev &c, size_t o, const int32_t *zp) {
+  Fn acc = fe_zero<FN>();
+  for (uint32_t t = c.col_ptr[o]; t < c.col_ptr[o + 1]; t++) {
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = c.coeff[t].w[j];
+    acc = add(acc, mul(unpack<FN>(w), raw_get(zp + (size_t)c.row[t] * NL)));
+  }
+  if (o >= 3 * c.n) acc = neg(acc);
+  return acc;
+}
+__global__ void __launch_bounds__(256) k_flatten(CircuitDev c, const int32_t *zpow, Words8 *wL, Words8 *wR, Words8 *wO,
+                                                 Words8 *wV, Words8 *wc) {
+  size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t b = blockIdx.y;
+  size_t nout = 3 * c.n + c.m + 1;
+  if (o >= nout) return;
+  Fn v = flatten_column(c, o, zpow + b * c.q * NL);
+  if (o < c.n) store_plain(&wL[b * c.n + o], v);
+  else if (o < 2 * c.n) store_plain(&wR[b * c.n + o - c.n], v);
+  else if (o < 3 * c.n) store_plain(&wO[b * c.n + o - 2 * c.n], v);
+  else if (o < 3 * c.n + c.m) store_plain(&wV[b * c.m + o - 3 * c.n], v);
+  else if (wc) store_plain(&wc[b], v);
+}
+void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
+             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow) {
+  if (!nb) return;
+  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, c.q, zpow);
+  size_t nout = 3 * c.n + c.m + 1;
+  hipLaunchKernelGGL(k_flatten, dim3((nout + 255) / 256, nb), dim3(256), 0, st, c, zpow, wL, wR, wO, wV, wc);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Verifier scalar assembly, one block per proof (r1cs/verifier.rs:457-532).
+// Wave 1 / lane 0 performs the (1 + k) inversions with one Fermat exponentiation while wave 0.. fill
+// the z-power table; then every lane produces g_i, h_i for its indices.
+constexpr int VS_TPB = 128;
+__global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
+                                                           const Words8 *proof_scalars, Words8 *fixed_sc,
+                                                           Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all) {
+  __shared__ int32_t sm[(40 + 2 * 32) * NL + NL * (VS_TPB / 64)];
+  // sm slots (NL ints each): 0 y_inv, 1 allinv, 2 delta, 3 wc, 8.. u_sq[k], 40.. u_inv_sq[k], tail: wave partials
+  int32_t *s_usq = sm + 8 * NL, *s_uinvsq = sm + 40 * NL, *s_part = sm + (40 + 64) * NL;
+  const size_t p = blockIdx.x;
+  const int tid = threadIdx.x;
+  const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m, n1 = d.n1;
+  const Words8 *ch = challenges + p * (6 + k);
+  const Words8 *ps = proof_scalars + p * 5;
+  int32_t *zpow = zpow_all + p * c.q * NL;
+  Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
+
+  if (tid == 64) {   // inversions: y^-1 and u_j^-1 (verifier.rs:468, inner_product_proof.rs:283)
+    Fn pref[33], val[33];
+    Fn acc = fe_one<FN>();
+    val[0] = y;
+    for (size_t i = 0; i < k; i++) val[1 + i] = load_plain(&ch[6 + i]);
+    for (size_t i = 0; i <= k; i++) { pref[i] = acc; acc = mul(acc, val[i]); }
+    Fn ai = inv(acc);
+    Fn allinv = fe_one<FN>();
+    for (int i = (int)k; i >= 0; i--) {
+      Fn vi = mul(ai, pref[i]);
+      ai = mul(ai, val[i]);
+      if (i == 0) raw_put(sm + 0 * NL, vi);
+      else {
+        allinv = mul(allinv, vi);
+        raw_put(s_usq + (i - 1) * NL, sqr(val[i]));
+        raw_put(s_uinvsq + (i - 1) * NL, sqr(vi));
+      }
+    }
+    raw_put(sm + 1 * NL, allinv);
+  } else if (tid < 64) {   // z^(r+1) table (verifier.rs:336,358)
+    for (size_t r = tid; r < c.q; r += 64) raw_put(zpow + r * NL, fn_pow_u32(z, (uint32_t)r + 1));
+  }
+  __syncthreads();
+  Fn y_inv = raw_get(sm + 0 * NL), allinv = raw_get(sm + 1 * NL);
+  Fn a = load_plain(&ps[3]), b = load_plain(&ps[4]);
+  const size_t nterms = 13 + m + 2 * np + 2 * k;
+  Words8 *fx = fixed_sc + p * (2 + 2 * np);
+  Words8 *full = full_sc ? full_sc + p * nterms : nullptr;
+  const size_t off_g = 13 + m, off_h = 13 + m + np;   // positions in verifier.rs:517-532 order
+
+  Fn dpart = fe_zero<FN>();
+  for (size_t i = tid; i < np; i += VS_TPB) {
+    Fn yi = fn_pow_u32(y_inv, (uint32_t)i);                  // y^-i (verifier.rs:469-471)
+    // s_i and s_{np-1-i} (inner_product_proof.rs:298-307, closed form)
+    Fn si = allinv, sr = allinv;
+    size_t ir = np - 1 - i;
+    for (size_t bb = 0; bb < k; bb++) {
+      Fn us = raw_get(s_usq + (k - 1 - bb) * NL);
+      if ((i >> bb) & 1) si = mul(si, us);
+      if ((ir >> bb) & 1) sr = mul(sr, us);
+    }
+    Fn wLi = fe_zero<FN>(), wRi = fe_zero<FN>(), wOi = fe_zero<FN>();
+    if (i < n) {
+      wLi = flatten_column(c, i, zpow);
+      wRi = flatten_column(c, n + i, zpow);
+      wOi = flatten_column(c, 2 * n + i, zpow);
+    }
+    Fn yneg_wR = mul(wRi, yi);                                // verifier.rs:472-477
+    dpart = add(dpart, mul(yneg_wR, wLi));                    // delta, verifier.rs:479
+    Fn g = sub(mul(x, yneg_wR), mul(a, si));                  // verifier.rs:487-491
+    Fn h = sub(mul(yi, sub(add(mul(x, wLi), wOi), mul(b, sr))), fe_one<FN>());   // verifier.rs:493-501
+    if (i >= n1) { g = mul(u, g); h = mul(u, h); }
+    store_plain(&fx[2 + i], g);
+    store_plain(&fx[2 + np + i], h);
+    if (full) { store_plain(&full[off_g + i], g); store_plain(&full[off_h + i], h); }
+  }
+  dpart = wave_sum(dpart);
+  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, dpart);
+  __syncthreads();
+  if (tid == 0) {
+    Fn delta = raw_get(s_part);
+    for (int w = 1; w < VS_TPB / 64; w++) delta = add(delta, raw_get(s_part + w * NL));
+    Fn wc = flatten_column(c, 3 * n + m, zpow);
+    Fn w_ch = load_plain(&ch[4]), r = load_plain(&ch[5]);
+    Fn t_x = load_plain(&ps[0]), t_xb = load_plain(&ps[1]), e_b = load_plain(&ps[2]);
+    Fn xx = sqr(x), rxx = mul(r, xx), xxx = mul(x, xx);
+    Words8 *vs = var_sc + p * (11 + m + 2 * k);
+    auto put = [&](size_t vpos, size_t fpos, const Fn &v) {
+      store_plain(&vs[vpos], v);
+      if (full) store_plain(&full[fpos], v);
+    };
+    put(0, 0, x); put(1, 1, xx); put(2, 2, xxx);                              // A_I1 A_O1 S1
+    put(3, 3, mul(u, x)); put(4, 4, mul(u, xx)); put(5, 5, mul(u, xxx));      // A_I2 A_O2 S2
+    Fn rx = mul(r, x);
+    put(6 + m, 6 + m, rx);                                                    // T_1: r x
+    put(7 + m, 7 + m, mul(rxx, x));                                           // T_3: r x^3
+    put(8 + m, 8 + m, mul(rxx, xx));                                          // T_4
+    put(9 + m, 9 + m, mul(rxx, xxx));                                         // T_5
+    put(10 + m, 10 + m, mul(mul(rxx, xx), xx));                               // T_6
+    // B: w (t_x - a b) + r (xx (wc + delta) - t_x) ; B_blinding: -e_blinding - r t_x_blinding
+    Fn sB = add(mul(w_ch, sub(t_x, mul(a, b))), mul(r, sub(mul(xx, add(wc, delta)), t_x)));
+    Fn sBb = neg(add(e_b, mul(r, t_xb)));
+    store_plain(&fx[0], sB);
+    store_plain(&fx[1], sBb);
+    if (full) { store_plain(&full[11 + m], sB); store_plain(&full[12 + m], sBb); }
+    for (size_t j = 0; j < k; j++) {
+      put(11 + m + j, 13 + m + 2 * np + j, raw_get(s_usq + j * NL));          // L_j: u_j^2
+      put(11 + m + k + j, 13 + m + 2 * np + k + j, raw_get(s_uinvsq + j * NL)); // R_j: u_j^-2
+    }
+    raw_put(sm + 2 * NL, rxx);
+  }
+  __syncthreads();
+  {   // V_j: wV_j * r x^2 (verifier.rs:523)
+    Fn rxx = raw_get(sm + 2 * NL);
+    Words8 *vs = var_sc + p * (11 + m + 2 * k);
+    for (size_t j = tid; j < m; j += VS_TPB) {
+      Fn v = mul(flatten_column(c, 3 * n + j, zpow), rxx);
+      store_plain(&vs[6 + j], v);
+      if (full) store_plain(&full[6 + j], v);
+    }
+  }
+}
+void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
+                    const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
+                    int32_t *zpow_scratch, int *bad) {
+  (void)bad;
+  if (!d.nb) return;
+  hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
+                     fixed_sc, var_sc, full_sc, zpow_scratch);
+}
+
+}  // namespace bpk

@@ -1,0 +1,81 @@
+// kernels.h -- host-callable launchers of the HIP kernels (k_ec.hip, k_scalar.hip).
+// All pointers are device pointers; every launcher enqueues on `st` and returns immediately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace bpk {
+
+struct JacRaw { int32_t v[27]; };   // unpacked Jacobian limbs (X[9] Y[9] Z[9]), device scratch format
+struct AffDev { uint32_t w[16]; };  // packed Montgomery affine (x[8] y[8]); zeros = identity
+struct Words8 { uint32_t w[8]; };   // one 256-bit field element (plain canonical at the boundary)
+
+// ---- points ------------------------------------------------------------------------------------
+// boundary bytes -> device affine; sets *bad (int) to 1 on a non-canonical / off-curve point
+void points_from_boundary(hipStream_t st, const Words8 *xy /*2 per point*/, AffDev *out, size_t n, int *bad);
+// JacRaw -> boundary bytes (one inversion per point)
+void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy_out, size_t n);
+// JacRaw[n] -> device affine, Montgomery's trick in runs of `run` points per lane
+void batch_normalize(hipStream_t st, const JacRaw *in, AffDev *out, size_t n, int run);
+
+// out[i] = sum_{j<np} scalar_j(i) * point_j(i);  scalar_j(i) = sc[j] + i*sc_stride[j] words
+// (stride 0 = broadcast), point_j(i) = pts[j] + i*pt_stride[j].  np in {1, 2}.
+struct StrausArgs {
+  const AffDev *pts[2];
+  size_t pt_stride[2];
+  const uint32_t *sc[2];
+  size_t sc_stride[2];
+};
+void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n);
+
+// out[b] = sum_{i<n} in[b*n + i]
+void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, size_t n);
+
+// ---- fixed-base tables -------------------------------------------------------------------------
+// table[(g*W + w) * 2^(c-1) + (d-1)] = d * 2^(c*w) * P_g,  W = 252/c + 1
+size_t fixed_table_entries(int c, size_t ngens);
+void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, AffDev *table,
+                       JacRaw *scratch /* >= ngens*W + entries */);
+// out[b] = sum_g scalars[b*sc_stride + g*8 ..] * P_g  via table lookups (plain canonical scalars)
+void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t ngens_used, const uint32_t *scalars,
+               size_t sc_stride_words, JacRaw *out, size_t nb);
+
+// ---- verification tail -------------------------------------------------------------------------
+// per proof: sum of nvar variable-base results + the fixed-base partial; ok = is_identity;
+// mega (optional) = boundary affine of the sum
+void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRaw *fixed, size_t nb,
+                     int32_t *ok, Words8 *mega_xy);
+
+// ---- scalar field (k_scalar.hip) ---------------------------------------------------------------
+void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad);   // canonical (< n)?
+void batch_inverse(hipStream_t st, Words8 *io, size_t n, int *bad_zero);
+void inner_product(hipStream_t st, const Words8 *a, const Words8 *b, size_t n, Words8 *out, void *scratch);
+size_t inner_product_scratch_bytes(size_t n);
+void fold_scalars(hipStream_t st, size_t n, const Words8 *u, const Words8 *u_inv, const Words8 *a,
+                  const Words8 *b, Words8 *a_out, Words8 *b_out);
+void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, size_t n, Words8 *u_sq,
+                          Words8 *u_inv_sq, Words8 *s);
+
+// column-major constraint weights: for output o in [0, 3n + m + 1): terms col_ptr[o]..col_ptr[o+1]
+// outputs ordered wL[0..n) wR[0..n) wO[0..n) wV[0..m) wc
+struct CircuitDev {
+  const uint32_t *col_ptr;   // 3n + m + 2
+  const uint32_t *row;       // nnz: constraint row of the term
+  const Words8 *coeff;       // nnz: Montgomery form
+  size_t q, n, m, nnz;
+};
+// zpow scratch: nb * q field elements (9 int32 each)
+void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
+             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow_scratch);
+
+struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
+// Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes
+//   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]
+//   (A_I1 A_O1 S1 A_I2 A_O2 S2 V.. T_1 T_3 T_4 T_5 T_6 L.. R..), plain canonical words;
+//   full_sc (optional): nb x (13 + m + 2 padded_n + 2k) in verifier.rs:517-532 order.
+void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
+                    const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
+                    int32_t *zpow_scratch, int *bad);
+
+}  // namespace bpk

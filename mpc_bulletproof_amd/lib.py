@@ -1,0 +1,217 @@
+"""ctypes binding of libbpgpu.so (include/bpgpu.h).  Byte-level, no torch types."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libbpgpu.so")
+
+SYMBOLS = [
+    "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
+    "bpgpu_stream", "bpgpu_input_flag", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
+    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_gens_create",
+    "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
+    "bpgpu_verification_scalars", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
+    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev",
+]
+
+
+class BpGpuError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__(f"bpgpu error {code}: {what}")
+
+
+def load():
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} is missing: the HIP extension has not been built "
+            "(run __graft_entry__.build()).  There is no CPU fallback.")
+    lib = C.CDLL(SO_PATH)
+    lib.bpgpu_strerror.restype = C.c_char_p
+    lib.bpgpu_last_error.restype = C.c_char_p
+    lib.bpgpu_stream.restype = C.c_void_p
+    lib.bpgpu_gens_capacity.restype = C.c_size_t
+    return lib
+
+
+_lib = load()
+E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
+
+
+def _buf(b):
+    b = bytes(b)
+    return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0")
+
+
+def _out(n):
+    return (C.c_uint8 * max(n, 1))()
+
+
+def device_count():
+    return _lib.bpgpu_device_count()
+
+
+class BpGpu:
+    """One context on one device.  All byte encodings as in include/bpgpu.h."""
+
+    def __init__(self, device=0):
+        self.ctx = C.c_void_p()
+        rc = _lib.bpgpu_create(device, C.byref(self.ctx))
+        if rc:
+            raise BpGpuError(rc, _lib.bpgpu_strerror(rc).decode())
+
+    def close(self):
+        if self.ctx:
+            _lib.bpgpu_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise BpGpuError(rc, _lib.bpgpu_strerror(rc).decode() + " | " + _lib.bpgpu_last_error(self.ctx).decode())
+
+    # ---- plumbing
+    def sync(self):
+        self._ck(_lib.bpgpu_sync(self.ctx))
+
+    def stream(self):
+        return _lib.bpgpu_stream(self.ctx)
+
+    def malloc(self, nbytes):
+        p = C.c_void_p()
+        self._ck(_lib.bpgpu_malloc(self.ctx, C.c_size_t(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        self._ck(_lib.bpgpu_free(self.ctx, p))
+
+    def upload(self, dptr, data):
+        self._ck(_lib.bpgpu_upload(self.ctx, dptr, _buf(data), C.c_size_t(len(data))))
+
+    def to_device(self, data):
+        p = self.malloc(len(data))
+        self.upload(p, data)
+        return p
+
+    def download(self, dptr, nbytes):
+        o = _out(nbytes)
+        self._ck(_lib.bpgpu_download(self.ctx, o, dptr, C.c_size_t(nbytes)))
+        return bytes(o)[:nbytes]
+
+    def input_flag(self):
+        v = C.c_int(0)
+        self._ck(_lib.bpgpu_input_flag(self.ctx, C.byref(v)))
+        return v.value
+
+    # ---- scalar field
+    def batch_inverse(self, scalars):
+        n = len(scalars) // 32
+        b = _buf(scalars)
+        self._ck(_lib.bpgpu_batch_inverse(self.ctx, b, C.c_size_t(n)))
+        return bytes(b)[:32 * n]
+
+    def inner_product(self, a, b):
+        if len(a) != len(b):
+            raise BpGpuError(E_LEN, "inner_product(a,b): lengths of vectors do not match")
+        o = _out(32)
+        self._ck(_lib.bpgpu_inner_product(self.ctx, _buf(a), _buf(b), C.c_size_t(len(a) // 32), o))
+        return bytes(o)
+
+    # ---- MSM
+    def msm(self, scalars, points):
+        n = len(scalars) // 32
+        if len(points) != 64 * n:
+            raise BpGpuError(E_LEN, "msm: length mismatch")
+        o = _out(64)
+        self._ck(_lib.bpgpu_msm(self.ctx, _buf(scalars), _buf(points), C.c_size_t(n), o))
+        return bytes(o)
+
+    def msm_batch(self, nb, n, scalars, points):
+        if len(scalars) != 32 * nb * n or len(points) != 64 * nb * n:
+            raise BpGpuError(E_LEN, "msm_batch: length mismatch")
+        o = _out(64 * nb)
+        self._ck(_lib.bpgpu_msm_batch(self.ctx, C.c_size_t(nb), C.c_size_t(n), _buf(scalars), _buf(points), o))
+        return bytes(o)[:64 * nb]
+
+    # ---- generators
+    def gens_create(self, G, H, B, B_blinding, window_bits=8):
+        cap = len(G) // 64
+        h = C.c_void_p()
+        self._ck(_lib.bpgpu_gens_create(self.ctx, _buf(G), _buf(H), C.c_size_t(cap), _buf(B), _buf(B_blinding),
+                                        window_bits, C.byref(h)))
+        return h
+
+    def gens_destroy(self, h):
+        _lib.bpgpu_gens_destroy(self.ctx, h)
+
+    def msm_gens(self, gens, nb, n, scalars):
+        o = _out(64 * nb)
+        self._ck(_lib.bpgpu_msm_gens(self.ctx, gens, C.c_size_t(nb), C.c_size_t(n), _buf(scalars), o))
+        return bytes(o)[:64 * nb]
+
+    # ---- IPP
+    def fold_witness(self, n, u, u_inv, a, b, G, H):
+        if not (len(a) == len(b) == 64 * n and len(G) == len(H) == 128 * n):
+            raise BpGpuError(E_LEN, "fold_witness: length mismatch")
+        ao, bo, Go, Ho = _out(32 * n), _out(32 * n), _out(64 * n), _out(64 * n)
+        self._ck(_lib.bpgpu_fold_witness(self.ctx, C.c_size_t(n), _buf(u), _buf(u_inv), _buf(a), _buf(b), _buf(G),
+                                         _buf(H), ao, bo, Go, Ho))
+        return bytes(ao)[:32 * n], bytes(bo)[:32 * n], bytes(Go)[:64 * n], bytes(Ho)[:64 * n]
+
+    def verification_scalars(self, challenges, n):
+        k = len(challenges) // 32
+        a, b, s = _out(32 * k), _out(32 * k), _out(32 * n)
+        self._ck(_lib.bpgpu_verification_scalars(self.ctx, _buf(challenges), C.c_size_t(k), C.c_size_t(n), a, b, s))
+        return bytes(a)[:32 * k], bytes(b)[:32 * k], bytes(s)[:32 * n]
+
+    # ---- R1CS
+    def circuit_create(self, row_ptr, kind, idx, coeff, n_mul, m):
+        q = len(row_ptr) - 1
+        nnz = len(kind)
+        h = C.c_void_p()
+        rp = (C.c_uint32 * (q + 1))(*row_ptr)
+        kd = (C.c_uint32 * max(nnz, 1))(*kind)
+        ix = (C.c_uint32 * max(nnz, 1))(*idx)
+        self._ck(_lib.bpgpu_circuit_create(self.ctx, C.c_size_t(q), rp, kd, ix, _buf(coeff), C.c_size_t(n_mul),
+                                           C.c_size_t(m), C.byref(h)))
+        return h
+
+    def circuit_destroy(self, h):
+        _lib.bpgpu_circuit_destroy(self.ctx, h)
+
+    def flatten_constraints(self, circuit, n_mul, m, z, want_wc=True):
+        nb = len(z) // 32
+        wL, wR, wO = _out(32 * nb * n_mul), _out(32 * nb * n_mul), _out(32 * nb * n_mul)
+        wV, wc = _out(32 * nb * m), _out(32 * nb)
+        self._ck(_lib.bpgpu_flatten_constraints(self.ctx, circuit, C.c_size_t(nb), _buf(z), wL, wR, wO, wV,
+                                                wc if want_wc else None))
+
+        def cut(b, k):
+            return bytes(b)[:32 * nb * k]
+
+        return cut(wL, n_mul), cut(wR, n_mul), cut(wO, n_mul), cut(wV, m), bytes(wc)[:32 * nb]
+
+    def r1cs_verify_batch(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, want_mega=True,
+                          want_scalars=False):
+        np_ = 1 << k
+        nvar, nterms = 11 + m + 2 * k, 13 + m + 2 * np_ + 2 * k
+        if len(points) != 64 * nb * nvar or len(scalars) != 160 * nb or len(challenges) != 32 * nb * (6 + k):
+            raise BpGpuError(E_LEN, "r1cs_verify_batch: length mismatch")
+        ok = (C.c_int32 * max(nb, 1))()
+        mega = _out(64 * nb) if want_mega else None
+        full = _out(32 * nb * nterms) if want_scalars else None
+        self._ck(_lib.bpgpu_r1cs_verify_batch(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                              _buf(points), _buf(scalars), _buf(challenges), ok, mega, full))
+        return (list(ok)[:nb], bytes(mega)[:64 * nb] if want_mega else None,
+                bytes(full)[:32 * nb * nterms] if want_scalars else None)
+
+    def r1cs_verify_batch_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_ok, d_mega=None,
+                              d_full=None):
+        self._ck(_lib.bpgpu_r1cs_verify_batch_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1),
+                                                  C.c_size_t(k), d_points, d_scalars, d_challenges, d_ok, d_mega,
+                                                  d_full))

@@ -1,0 +1,220 @@
+"""GPU parity tests: every exported function of libbpgpu.so (called through the C ABI) against the
+CPU oracle and the committed golden vectors, bit for bit.  Run with `-m gpu` on an MI355X."""
+import pytest
+
+import bp_helpers as bh
+import oracle_lib as o
+
+pytestmark = pytest.mark.gpu
+H = bytes.fromhex
+N = o.N
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import mpc_bulletproof_amd as m
+    g = m.BpGpu(0)
+    yield g
+    g.close()
+
+
+def J(c, k):
+    return b"".join(map(H, c[k]))
+
+
+# ------------------------------------------------------------------ scalar field
+def test_batch_inverse(gpu, golden_primitives):
+    bi = golden_primitives["batch_inverse"]
+    assert gpu.batch_inverse(J(bi, "in")) == J(bi, "out")
+    for n in (1, 2, 5, 64, 1000):
+        s = o.random_scalars(n, n)
+        assert gpu.batch_inverse(s) == o.batch_inverse(s)
+    assert gpu.batch_inverse(b"") == b""
+
+
+def test_batch_inverse_rejects(gpu):
+    import mpc_bulletproof_amd as m
+    with pytest.raises(m.BpGpuError) as e:
+        gpu.batch_inverse(o.s2b(5) + bytes(32))          # zero element
+    assert e.value.code == m.lib.E_ARG
+    with pytest.raises(m.BpGpuError):
+        gpu.batch_inverse(N.to_bytes(32, "little"))      # non-canonical
+
+
+def test_inner_product(gpu):
+    assert gpu.inner_product(o.scalars([1, 2, 3, 4]), o.scalars([2, 3, 4, 5])) == o.s2b(40)   # inner_product_proof.rs:620-635
+    assert gpu.inner_product(b"", b"") == bytes(32)
+    for n in (1, 63, 64, 65, 1000, 70000):
+        a, b = o.random_scalars(3 * n, n), o.random_scalars(3 * n + 1, n)
+        assert gpu.inner_product(a, b) == o.inner_product(a, b)
+    import mpc_bulletproof_amd as m
+    with pytest.raises(m.BpGpuError):
+        gpu.inner_product(o.scalars([1, 2]), o.scalars([1]))
+
+
+# ------------------------------------------------------------------ MSM
+def test_msm_golden(gpu, golden_msm):
+    for c in golden_msm:
+        assert gpu.msm(J(c, "scalars"), J(c, "points")) == H(c["out"]), c["name"]
+
+
+def test_msm_random_and_dlog_identity(gpu):
+    for n in (7, 64, 154, 1000):
+        Gp, Gd = o.gens("G", n, dlogs=True)
+        sc = o.random_scalars(100 + n, n)
+        got = gpu.msm(sc, Gp)
+        assert got == o.msm(sc, Gp)
+        assert got == o.point_mul(o.inner_product(sc, Gd), o.generator())   # needs no oracle MSM
+
+
+def test_msm_batch(gpu):
+    nb, n = 5, 33
+    Gp = o.gens("G", n)
+    sc = o.random_scalars(9, nb * n)
+    pts = Gp * nb
+    assert gpu.msm_batch(nb, n, sc, pts) == o.msm_batch(sc, pts, nb, n)
+
+
+def test_msm_rejects_bad_input(gpu):
+    import mpc_bulletproof_amd as m
+    G = o.generator()
+    bad = bytearray(G)
+    bad[0] ^= 1
+    with pytest.raises(m.BpGpuError) as e:
+        gpu.msm(o.s2b(3), bytes(bad))
+    assert e.value.code == m.lib.E_ARG
+    with pytest.raises(m.BpGpuError):
+        gpu.msm(N.to_bytes(32, "little"), G)
+
+
+@pytest.mark.parametrize("c", [4, 8])
+def test_msm_gens(gpu, c):
+    cap = 16
+    Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
+    g = gpu.gens_create(Gp, Hp, B, B, c)
+    try:
+        for n in (16, 8, 1, 0):
+            nb = 3
+            sc = o.random_scalars(50 + n, nb * (2 + 2 * n))
+            pts = B + B + Gp[:64 * n] + Hp[:64 * n]
+            want = o.msm_batch(sc, pts * nb, nb, 2 + 2 * n)
+            assert gpu.msm_gens(g, nb, n, sc) == want
+        # edge scalars: 0, 1, n-1 and equal scalars on B == B_blinding (duplicate points)
+        sc = o.scalars([5, 5] + [0, 1, N - 1, 2] * 8)
+        assert gpu.msm_gens(g, 1, 16, sc) == o.msm(sc, B + B + Gp + Hp)
+        sc = o.scalars([7, N - 7] + [0] * 32)
+        assert gpu.msm_gens(g, 1, 16, sc) == bytes(64)
+    finally:
+        gpu.gens_destroy(g)
+
+
+# ------------------------------------------------------------------ IPP
+def test_fold_witness(gpu, golden_ipp):
+    for c in golden_ipp["fold"]:
+        got = gpu.fold_witness(c["n"], H(c["u"]), H(c["u_inv"]), J(c, "a"), J(c, "b"), J(c, "G"), J(c, "H"))
+        assert got == (J(c, "a_out"), J(c, "b_out"), J(c, "G_out"), J(c, "H_out"))
+    n = 40
+    u = o.random_scalars(1, 1)
+    ui = o.sc_inv(u)
+    a, b = o.random_scalars(2, 2 * n), o.random_scalars(3, 2 * n)
+    G, Hh = o.gens("G", 2 * n), o.gens("H", 2 * n)
+    assert gpu.fold_witness(n, u, ui, a, b, G, Hh) == o.fold_witness(n, u, ui, a, b, G, Hh)
+
+
+def test_verification_scalars(gpu, golden_ipp):
+    for c in golden_ipp["verification_scalars"]:
+        k = len(c["challenges"])
+        assert gpu.verification_scalars(J(c, "challenges"), 1 << k) == (J(c, "u_sq"), J(c, "u_inv_sq"), J(c, "s"))
+    ch = o.random_scalars(4, 10)
+    assert gpu.verification_scalars(ch, 1024) == o.verification_scalars(ch, 1024)
+    import mpc_bulletproof_amd as m
+    with pytest.raises(m.BpGpuError) as e:
+        gpu.verification_scalars(ch, 512)     # n != 2^k -> VerificationError (inner_product_proof.rs:265-267)
+    assert e.value.code == m.lib.E_LEN
+
+
+# ------------------------------------------------------------------ R1CS
+def _session(kind, param, rec, values_verify, cap=16):
+    label = H(rec["label"])
+    com = b"".join(map(H, rec["commitments"]))
+    return o.VerifySession(kind, param, label, values_verify, com, H(rec["proof"]), cap), com
+
+
+def _gens(gpu, cap, c=8):
+    return gpu.gens_create(o.gens("G", cap), o.gens("H", cap), o.generator(), o.generator(), c)
+
+
+def _check_record(gpu, g, kind, param, rec, values_verify):
+    s, com = _session(kind, param, rec, values_verify)
+    rp, kind_, idx, coeff = s.csr()
+    circ = gpu.circuit_create(rp, kind_, idx, coeff, s.n1 + s.n2, s.m)
+    try:
+        z = H(rec["challenges"][1])
+        assert gpu.flatten_constraints(circ, s.n1 + s.n2, s.m, z) == \
+            (J(rec, "wL"), J(rec, "wR"), J(rec, "wO"), J(rec, "wV"), H(rec["wc"]))
+        k, points, scalars = bh.verify_inputs(H(rec["proof"]), com)
+        ok, mega, full = gpu.r1cs_verify_batch(g, circ, 1, s.n1, k, s.m, points, scalars, s.challenges(),
+                                               want_mega=True, want_scalars=True)
+        assert mega == H(rec["mega_check"])
+        assert ok == [1 if rec["ok"] else 0]
+        assert full == s.msm_terms()[0]
+    finally:
+        gpu.circuit_destroy(circ)
+
+
+def test_r1cs_golden_records(gpu, golden_r1cs):
+    g = _gens(gpu, 16)
+    try:
+        for rec in golden_r1cs["range"]:
+            _check_record(gpu, g, o.K_RANGE, rec["n_bits"], rec, [])
+        for rec in golden_r1cs["shuffle"]:
+            _check_record(gpu, g, o.K_SHUFFLE, rec["k"], rec, [])
+        for rec in golden_r1cs["example"]:
+            _check_record(gpu, g, o.K_EXAMPLE, 0, rec, [rec["values"][5]])
+    finally:
+        gpu.gens_destroy(g)
+
+
+@pytest.mark.parametrize("n_bits,nb,c", [(8, 12, 8), (64, 6, 8), (32, 4, 4)])
+def test_range_verify_batch(gpu, n_bits, nb, c):
+    """Batched verification of the n-bit range gadget (config 2 shape at small batch): accept bits,
+    mega_check points (also for tampered proofs) and all MSM scalars equal the oracle's."""
+    tamper = {1, nb - 1}
+    recs, cap = bh.make_range_batch(n_bits, nb, tamper=tamper)
+    sessions = [o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+    s0 = sessions[0]
+    rp, kind, idx, coeff = s0.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, c)
+    try:
+        pts = sc = ch = b""
+        for (proof, com), s in zip(recs, sessions):
+            k, p, q = bh.verify_inputs(proof, com)
+            pts += p
+            sc += q
+            ch += s.challenges()
+        ok, mega, full = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, True, True)
+        for i, s in enumerate(sessions):
+            assert ok[i] == (1 if s.rc == 0 else 0) == (0 if i in tamper else 1)
+            assert mega[64 * i:64 * i + 64] == s.mega_check()
+            assert full[32 * s.nterms * i:32 * s.nterms * (i + 1)] == s.msm_terms()[0]
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+
+
+def test_verify_batch_generators_too_short(gpu):
+    import mpc_bulletproof_amd as m
+    recs, cap = bh.make_range_batch(8, 1)
+    s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
+    rp, kind, idx, coeff = s.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, 8, 1)
+    g = _gens(gpu, 4)
+    try:
+        k, p, q = bh.verify_inputs(*recs[0])
+        with pytest.raises(m.BpGpuError) as e:
+            gpu.r1cs_verify_batch(g, circ, 1, 8, k, 1, p, q, s.challenges())
+        assert e.value.code == m.lib.E_GENS      # R1CSError::InvalidGeneratorsLength (verifier.rs:421-423)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
