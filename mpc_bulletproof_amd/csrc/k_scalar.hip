@@ -37,6 +37,10 @@ __device__ __forceinline__ Fn fn_pow_u32(Fn base, uint32_t e) {   // base^e, e >
   }
   return acc;
 }
+// Lazy sums keep limbs small but let the VALUE grow (top limb has ~11 spare bits over a 252-bit
+// modulus): fold the value back into (-eps, (1+eps) n) with one Montgomery multiplication by R mod n.
+// Rule used below: never add more than ~64 reduced values (x 64 lanes of a wave sum) without it.
+__device__ __forceinline__ Fn fn_reduce(const Fn &x) { return mul(x, fe_one<FN>()); }
 // raw limb I/O for device scratch (zpow tables, partial sums)
 __device__ __forceinline__ void raw_put(int32_t *d, const Fn &x) {
 #pragma unroll
@@ -110,22 +114,25 @@ constexpr int IP_TPB = 256;
 __global__ void __launch_bounds__(IP_TPB) k_inner_product_partial(const Words8 *a, const Words8 *b, size_t n, int32_t *partials) {
   __shared__ int32_t sm[NL * (IP_TPB / 64)];
   Fn acc = fe_zero<FN>();
-  for (size_t i = (size_t)blockIdx.x * IP_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * IP_TPB)
+  int cnt = 0;
+  for (size_t i = (size_t)blockIdx.x * IP_TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * IP_TPB) {
     acc = add(acc, mul(load_plain(&a[i]), load_plain(&b[i])));
-  acc = wave_sum(acc);
+    if ((++cnt & 15) == 0) acc = fn_reduce(acc);
+  }
+  acc = wave_sum(fn_reduce(acc));
   int wv = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) raw_put(sm + wv * NL, acc);
   __syncthreads();
   if (threadIdx.x == 0) {
     Fn t = raw_get(sm);
     for (int w = 1; w < IP_TPB / 64; w++) t = add(t, raw_get(sm + w * NL));
-    raw_put(partials + (size_t)blockIdx.x * NL, t);
+    raw_put(partials + (size_t)blockIdx.x * NL, fn_reduce(t));
   }
 }
 __global__ void __launch_bounds__(64) k_inner_product_finish(const int32_t *partials, int nparts, Words8 *out) {
   Fn acc = fe_zero<FN>();
-  for (int i = threadIdx.x; i < nparts; i += 64) acc = add(acc, raw_get(partials + (size_t)i * NL));
-  acc = wave_sum(acc);
+  for (int i = threadIdx.x; i < nparts; i += 64) acc = add(acc, raw_get(partials + (size_t)i * NL));   // <= 16 reduced terms
+  acc = wave_sum(fn_reduce(acc));
   if (threadIdx.x == 0) store_plain(out, acc);
 }
 static int ip_blocks(size_t n) {
@@ -202,11 +209,13 @@ __global__ void __launch_bounds__(256) k_zpow(const Words8 *z, size_t z_stride, 
 }
 __device__ __forceinline__ Fn flatten_column(const CircuitDev &c, size_t o, const int32_t *zp) {
   Fn acc = fe_zero<FN>();
+  uint32_t cnt = 0;
   for (uint32_t t = c.col_ptr[o]; t < c.col_ptr[o + 1]; t++) {
     uint32_t w[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) w[j] = c.coeff[t].w[j];
     acc = add(acc, mul(unpack<FN>(w), raw_get(zp + (size_t)c.row[t] * NL)));
+    if ((++cnt & 15) == 0) acc = fn_reduce(acc);
   }
   if (o >= 3 * c.n) acc = neg(acc);
   return acc;
@@ -282,7 +291,9 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   const size_t off_g = 13 + m, off_h = 13 + m + np;   // positions in verifier.rs:517-532 order
 
   Fn dpart = fe_zero<FN>();
+  int dcnt = 0;
   for (size_t i = tid; i < np; i += VS_TPB) {
+    if ((++dcnt & 15) == 0) dpart = fn_reduce(dpart);
     Fn yi = fn_pow_u32(y_inv, (uint32_t)i);                  // y^-i (verifier.rs:469-471)
     // s_i and s_{np-1-i} (inner_product_proof.rs:298-307, closed form)
     Fn si = allinv, sr = allinv;
@@ -307,8 +318,8 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
     store_plain(&fx[2 + np + i], h);
     if (full) { store_plain(&full[off_g + i], g); store_plain(&full[off_h + i], h); }
   }
-  dpart = wave_sum(dpart);
-  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, dpart);
+  dpart = wave_sum(fn_reduce(dpart));
+  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, fn_reduce(dpart));
   __syncthreads();
   if (tid == 0) {
     Fn delta = raw_get(s_part);
