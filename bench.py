@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- range-proof verifications/s on MI355X (BASELINE.json configs[1]).
+
+One step = one pass of the verification hot path (reference src/r1cs/verifier.rs:457-553: constraint
+flattening, inversions, verifier scalar assembly, the 154-term mega_check MSM, identity test) over a
+batch of 1024 proofs of the 64-bit range gadget (tests/r1cs.rs:620-652, m = 1), inputs resident in
+HBM (proof points/scalars + host-transcript challenges, boundary byte encodings of include/bpgpu.h).
+Multi-GPU: one process per GPU, each rank verifies its own 1024 proofs (independent units, no
+data-path collective) -> weak scaling; value = all ranks' proofs / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+N_BITS = 64
+LABEL = b"RangeProofTest"
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
+
+
+def _gen_one(args):
+    """worker (CPU oracle): prove one instance, replay the verifier transcript for the challenges."""
+    import oracle_lib as o
+    import bp_helpers as bh
+    i, seed0 = args
+    v = (0x9E3779B97F4A7C15 * (i + 1) + seed0) & ((1 << N_BITS) - 1)
+    rc, proof, com = o.r1cs_prove(o.K_RANGE, N_BITS, LABEL, [v], seed0 + i, N_BITS)
+    assert rc == 0
+    s = o.VerifySession(o.K_RANGE, N_BITS, LABEL, [], com, proof, N_BITS)
+    assert s.rc == 0
+    k, pts, sc = bh.verify_inputs(proof, com)
+    out = (proof, com, pts, sc, s.challenges(), (s.n1, s.n2, s.k, s.m), s.csr() if i == 0 else None)
+    s.close()
+    return out
+
+
+def _cpu_verify_chunk(args):
+    import oracle_lib as o
+    proofs, coms, plen = args
+    nb = len(proofs) // plen
+    t0 = time.perf_counter()
+    ok = o.r1cs_verify_many(o.K_RANGE, N_BITS, LABEL, [], coms, 1, proofs, plen, nb, N_BITS)
+    return sum(ok), time.perf_counter() - t0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "8")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload-cache", default=None,
+                    help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    nb = a.batch
+
+    # ---- synthetic workload from the CPU oracle (setup, untimed; forked before any GPU init)
+    ncpu = max(1, min(os.cpu_count() or 1, 16) // max(1, min(world, 8)))
+    seed0 = 0xB0117E7 + 100003 * rank
+    import pickle
+    cache = f"{a.workload_cache}.{rank}.{nb}" if a.workload_cache else None
+    cpu = None
+    if cache and os.path.exists(cache):
+        with open(cache, "rb") as f:
+            recs = pickle.load(f)
+    else:
+      with mp.get_context("fork").Pool(ncpu) as pool:
+          recs = pool.map(_gen_one, [(i, seed0) for i in range(nb)], chunksize=max(1, nb // (4 * ncpu)))
+          if rank == 0 and world == 1 and not a.no_cpu_baseline:
+              # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
+              plen = len(recs[0][0])
+              per = (nb + ncpu - 1) // ncpu
+              chunks = []
+              for c in range(ncpu):
+                  sub = recs[c * per:(c + 1) * per]
+                  if sub:
+                      chunks.append((b"".join(r[0] for r in sub), b"".join(r[1] for r in sub), plen))
+              t0 = time.perf_counter()
+              res = pool.map(_cpu_verify_chunk, chunks)
+              wall = time.perf_counter() - t0
+              assert sum(r[0] for r in res) == nb
+              cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
+                     "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
+                               f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
+      if cache:
+        with open(cache, "wb") as f:
+          pickle.dump(recs, f)
+    n1, n2, k, m = recs[0][5]
+    rp, kind, idx, coeff = recs[0][6]
+    pts = b"".join(r[2] for r in recs)
+    sc = b"".join(r[3] for r in recs)
+    ch = b"".join(r[4] for r in recs)
+
+    # ---- GPU
+    import torch
+    import torch.distributed as dist
+    import mpc_bulletproof_amd as mb
+    import oracle_lib as o
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    gpu = mb.BpGpu(local_rank)
+    circ = gpu.circuit_create(rp, kind, idx, coeff, n1 + n2, m)
+    gens = gpu.gens_create(o.gens("G", N_BITS), o.gens("H", N_BITS), o.generator(), o.generator(), a.window_bits)
+    d_pts, d_sc, d_ch = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch)
+    d_ok = gpu.malloc(4 * nb)
+
+    def step():
+        gpu.r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_ok)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    gpu.sync()
+    ok = gpu.download(d_ok, 4 * nb)
+    assert ok == (1).to_bytes(4, "little") * nb and gpu.input_flag() == 0, "GPU verification disagrees"
+    gpu.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    gpu.sync()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = gpu.profile_read()
+    gpu.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ok = gpu.download(d_ok, 4 * nb)
+    assert ok == (1).to_bytes(4, "little") * nb
+
+    if rank == 0:
+        nvar = 11 + m + 2 * k
+        nterms = 13 + m + 2 * (1 << k) + 2 * k
+        # dominant kernel = variable-base Straus over nb * nvar (scalar, point) pairs, 96 B per term
+        dom = max(("straus", "fixed_msm", "verify_scalars"), key=lambda n_: prof[n_][0])
+        ms, cnt = prof[dom]
+        avg_s = ms / max(cnt, 1) / 1e3
+        terms = {"straus": nvar, "fixed_msm": nterms - nvar, "verify_scalars": 0}[dom]
+        alg_bytes = nb * (terms * 96 if dom != "verify_scalars" else (6 + k + 5) * 32 + nterms * 32)
+        achieved = alg_bytes / avg_s / 1e9
+        # integer roofline of the same kernel: algorithmic F_p multiplications x 94 MADs each
+        fpmul = {"straus": nb * nvar * (252 * 9 + 63 * 16 + 7 * 11), "fixed_msm": nb * (nterms - nvar) * (252 // a.window_bits + 1) * 11,
+                 "verify_scalars": 0}[dom]
+        out = {
+            "metric": "range-proof verifications/sec (64-bit, m=1)",
+            "value": world * nb * a.steps / dt, "unit": "verifications/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 252-bit prime fields)", "data": "synthetic",
+            "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
+                                   f"mega_check MSM per proof, per-proof accept bits) per GPU",
+                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb},
+            "roofline": {"bound": "hbm", "kernel": {"straus": "k_straus<1,128>", "fixed_msm": "k_fixed_msm", "verify_scalars": "k_verify_scalars"}[dom],
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+            "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "achieved": fpmul * 94 / avg_s / 1e12 if avg_s else None,
+                             "peak": MAD_PEAK_TOPS, "unit": "Tmad/s", "frac": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
+            "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    gpu.gens_destroy(gens)
+    gpu.circuit_destroy(circ)
+    gpu.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,12 @@ void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for e
 /* after a `_dev` call: synchronise and report whether any input of it was malformed (1) */
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
+/* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
+ * bench.py's `roofline` uses).  kinds: 0 verify_scalars, 1 fixed-base MSM, 2 point import,
+ * 3 variable-base Straus, 4 verify tail.  read() synchronises, returns sums since the last read. */
+int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
+int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]);
+
 /* device memory plumbing */
 int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);
 int bpgpu_free(bpgpu_ctx *ctx, void *dptr);

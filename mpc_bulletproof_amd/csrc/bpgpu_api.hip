@@ -28,6 +28,18 @@ struct bpgpu_ctx {
   std::string err;
   int *d_flag = nullptr;          // device int: bad-input flag
   Slot ws[16];                    // grow-only workspace slots
+  // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev[8];
+};
+struct ProfScope {   // records start/stop events on `st` around a launch when profiling is on
+  bpgpu_ctx *c; int kind; hipStream_t st;
+  ProfScope(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) {
+    if (c->prof) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_ev[kind].push_back(e); } }
+  }
+  ~ProfScope() {
+    if (c->prof) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_ev[kind].push_back(e); } }
+  }
 };
 struct bpgpu_gens {
   size_t cap = 0;
@@ -181,6 +193,30 @@ int bpgpu_sync(bpgpu_ctx *ctx) {
   return BPGPU_OK;
 }
 void *bpgpu_stream(bpgpu_ctx *ctx) { return ctx ? (void *)ctx->st : nullptr; }
+int bpgpu_profile_enable(bpgpu_ctx *ctx, int on) {
+  if (!ctx) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->prof = on != 0;
+  return BPGPU_OK;
+}
+int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]) {
+  if (!ctx || !ms_sum || !launches) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  for (int k = 0; k < 8; k++) {
+    ms_sum[k] = 0;
+    launches[k] = 0;
+    auto &v = ctx->prof_ev[k];
+    for (size_t i = 0; i + 1 < v.size(); i += 2) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) { ms_sum[k] += ms; launches[k]++; }
+    }
+    for (auto e : v) (void)hipEventDestroy(e);
+    v.clear();
+  }
+  return BPGPU_OK;
+}
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad) {
   if (!ctx || !bad) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -588,19 +624,34 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
   scalars_check(ctx->st, (const Words8 *)scalars, nb * 5, ctx->d_flag);
   scalars_check(ctx->st, (const Words8 *)challenges, nb * (6 + k), ctx->d_flag);
-  verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
-                 (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag);
+  {
+    ProfScope ps(ctx, 0, ctx->st);
+    verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
+                   (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag);
+  }
   HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
   HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
-  CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2));
+  {
+    ProfScope ps(ctx, 1, ctx->st2);
+    CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2));
+  }
   HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
-  points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
+  {
+    ProfScope ps(ctx, 2, ctx->st);
+    points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
+  }
   StrausArgs a{};
   a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
   a.sc[0] = (uint32_t *)dvar; a.sc_stride[0] = 8;
-  straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar);
+  {
+    ProfScope ps(ctx, 3, ctx->st);
+    straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar);
+  }
   HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
-  verify_finalize(ctx->st, (JacRaw *)dvres, nvar, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
+  {
+    ProfScope ps(ctx, 4, ctx->st);
+    verify_finalize(ctx->st, (JacRaw *)dvres, nvar, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
+  }
   return launch_ok(ctx);
 }
 int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,

@@ -7,7 +7,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_input_flag", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
+    "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
@@ -107,6 +107,16 @@ class BpGpu:
         v = C.c_int(0)
         self._ck(_lib.bpgpu_input_flag(self.ctx, C.byref(v)))
         return v.value
+
+    def profile_enable(self, on=True):
+        self._ck(_lib.bpgpu_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_double * 8)()
+        cnt = (C.c_uint64 * 8)()
+        self._ck(_lib.bpgpu_profile_read(self.ctx, ms, cnt))
+        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize"]
+        return {n: (ms[i], int(cnt[i])) for i, n in enumerate(names)}
 
     # ---- scalar field
     def batch_inverse(self, scalars):

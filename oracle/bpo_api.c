@@ -444,3 +444,42 @@ API int bpo_r1cs_verify(int kind, size_t param, const uint8_t *label, size_t lab
   bpo_verify_close(h);
   return rc;
 }
+
+/* Verifier::verify over nb proofs of one gadget with the generators built once (what a host that
+ * keeps BulletproofGens around does; benches/r1cs.rs:69).  proofs: nb x proof_len, commitments:
+ * nb x m x 64.  ok[i] = 1 accept / 0 reject.  Used as the timed CPU baseline ("port"). */
+API int bpo_r1cs_verify_many(int kind, size_t param, const uint8_t *label, size_t label_len,
+                             const uint64_t *values, size_t nvalues, const uint8_t *commitments, size_t m,
+                             const uint8_t *proofs, size_t proof_len, size_t nb, size_t gens_capacity,
+                             int32_t *ok) {
+  size_t cap = gens_capacity;
+  aff *G = (aff *)malloc((cap ? cap : 1) * sizeof(aff)), *H = (aff *)malloc((cap ? cap : 1) * sizeof(aff));
+  gens_chain(G, NULL, 'G', 0, cap);
+  gens_chain(H, NULL, 'H', 0, cap);
+  aff *V = (aff *)malloc((m ? m : 1) * sizeof(aff));
+  var_t *vars = (var_t *)malloc((m ? m : 1) * sizeof(var_t));
+  int rc_all = 0;
+  for (size_t i = 0; i < nb; i++) {
+    ok[i] = 0;
+    transcript t;
+    start_transcript(&t, kind, param, label, label_len);
+    cs_t cs;
+    cs_init(&cs, 0, &t);
+    r1cs_proof p;
+    memset(&p, 0, sizeof p);
+    if (load_points(V, commitments + i * m * 64, m) == 0 && proof_from_flat(&p, proofs + i * proof_len, proof_len) == 0) {
+      for (size_t j = 0; j < m; j++) vars[j] = cs_commit_verifier(&cs, &V[j]);
+      int good = 1;
+      if (kind == K_RANGE && m == 1) gadget_range_proof(&cs, vars[0], 0, 0, param);
+      else if (kind == K_SHUFFLE && m == 2 * param) gadget_shuffle(&cs, vars, vars + param, param);
+      else if (kind == K_EXAMPLE && m == 5 && nvalues == 1) gadget_example(&cs, vars, values[0]);
+      else good = 0;
+      if (good) ok[i] = cs_verify(&cs, &p, G, H, cap, NULL) == BPO_OK;
+      else rc_all = -3;
+    } else rc_all = -3;
+    r1cs_proof_free(&p);
+    cs_free(&cs);
+  }
+  free(G); free(H); free(V); free(vars);
+  return rc_all;
+}

@@ -242,3 +242,13 @@ def r1cs_verify(kind, param, label, values, commitments, proof, gens_capacity):
     rc = s.rc
     s.close()
     return rc
+
+
+def r1cs_verify_many(kind, param, label, values, commitments, m, proofs, proof_len, nb, gens_capacity):
+    vals = (C.c_uint64 * max(len(values), 1))(*values)
+    ok = (C.c_int32 * max(nb, 1))()
+    rc = lib.bpo_r1cs_verify_many(kind, C.c_size_t(param), _buf(label), C.c_size_t(len(label)), vals,
+                                  C.c_size_t(len(values)), _buf(commitments), C.c_size_t(m), _buf(proofs),
+                                  C.c_size_t(proof_len), C.c_size_t(nb), C.c_size_t(gens_capacity), ok)
+    assert rc == 0, rc
+    return list(ok)[:nb]
