@@ -110,6 +110,26 @@ int bpgpu_fold_witness(bpgpu_ctx *ctx, size_t n, const uint8_t u[32], const uint
 int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t k, size_t n,
                                uint8_t *u_sq, uint8_t *u_inv_sq, uint8_t *s);
 
+/* InnerProductProof::create -- src/inner_product_proof.rs:49-193 -- split at the Fiat-Shamir transcript
+ * (which stays on the host) for nb independent proofs advancing in lock-step; all state stays in HBM
+ * between rounds.  n must be a power of two (reference asserts, :70).  G/H: n points shared by all
+ * proofs (shared_gens = 1) or nb x n.  Protocol per round while bpgpu_ipp_len() > 1:
+ *   bpgpu_ipp_round -> L[nb], R[nb]   (c_L, c_R :87-88,156-157 and the two MSMs :90-114,159-172;
+ *                                       the first round folds G_factors/H_factors into the scalars)
+ *   host: append L, R; u = challenge; u_inv = u.inverse()              (:119-123,177-181)
+ *   bpgpu_ipp_fold(u[nb], u_inv[nb])  (first round also scales the generators, :125-134; then
+ *                                       fold_witness :135-146,183-184)
+ * then bpgpu_ipp_finish -> a[nb], b[nb] (:187-192). */
+typedef struct bpgpu_ipp bpgpu_ipp;
+int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
+                    const uint8_t *H_factors, const uint8_t *G, const uint8_t *H, int shared_gens,
+                    const uint8_t *a, const uint8_t *b, bpgpu_ipp **out);
+void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s);
+size_t bpgpu_ipp_len(const bpgpu_ipp *s);
+int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R);
+int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t *u_inv);
+int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_out);
+
 /* ---- R1CS ------------------------------------------------------------------------------------
  * Constraint rows as the reference holds them (Vec<LinearCombination>, r1cs/prover.rs:31,
  * r1cs/verifier.rs:38): CSR with row_ptr[q+1]; per term kind (0 MultiplierLeft, 1 MultiplierRight,

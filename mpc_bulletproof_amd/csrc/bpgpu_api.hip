@@ -47,6 +47,20 @@ struct bpgpu_gens {
   AffDev *points = nullptr;       // [B, B_blinding, G_0..G_{cap-1}, H_0..H_{cap-1}]
   AffDev *table = nullptr;        // (2 + 2 cap) * W * 2^(c-1)
 };
+// lock-step InnerProductProof::create state for nb proofs (device resident between rounds)
+struct bpgpu_ipp {
+  size_t nb = 0, n0 = 0, n = 0;
+  bool first = true, shared_gens = false;
+  Words8 *a[2] = {nullptr, nullptr}, *b[2] = {nullptr, nullptr};   // ping-pong, nb x n
+  AffDev *G[2] = {nullptr, nullptr}, *H[2] = {nullptr, nullptr};   // [0]: input (n0 or nb x n0), [1]/[0] folded
+  AffDev *Q = nullptr;
+  Words8 *Gf = nullptr, *Hf = nullptr;                             // nb x n0 (first round only)
+  Words8 *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr;   // nb x n0/2 temporaries
+  Words8 *cLR = nullptr, *uu = nullptr;                            // nb x 2 each (uu: u | u_inv as 2 arrays of nb)
+  JacRaw *res = nullptr, *sums = nullptr;                          // nb x 2 x (n0 + 1), nb x 2
+  Words8 *out_xy = nullptr;                                        // nb x 2 points
+  int cur = 0;                                                     // index of the live a/b/G/H buffers
+};
 struct bpgpu_circuit {
   size_t q = 0, n = 0, m = 0, nnz = 0;
   uint32_t *col_ptr = nullptr, *row = nullptr;
@@ -687,6 +701,173 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   CK(d2h(ctx, ok, dok, nb * 4));
   if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
   if (msm_scalars) CK(d2h(ctx, msm_scalars, dfull, nb * nterms * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+
+/* ---------------------------------------------------------------- IPP prover session */
+static void ipp_free_all(bpgpu_ipp *s) {
+  for (int i = 0; i < 2; i++) { hipFree(s->a[i]); hipFree(s->b[i]); hipFree(s->G[i]); hipFree(s->H[i]); }
+  hipFree(s->Q); hipFree(s->Gf); hipFree(s->Hf); hipFree(s->t1); hipFree(s->t2); hipFree(s->t3); hipFree(s->t4);
+  hipFree(s->cLR); hipFree(s->uu); hipFree(s->res); hipFree(s->sums); hipFree(s->out_xy);
+  delete s;
+}
+int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
+                    const uint8_t *H_factors, const uint8_t *G, const uint8_t *H, int shared_gens, const uint8_t *a,
+                    const uint8_t *b, bpgpu_ipp **out) {
+  if (!ctx || !out || !nb || !Q || !G_factors || !H_factors || !G || !H || !a || !b) return BPGPU_E_ARG;
+  if (!n || (n & (n - 1))) return BPGPU_E_LEN;   // assert!(n.is_power_of_two()), inner_product_proof.rs:70
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
+  if (!s) return BPGPU_E_OOM;
+  s->nb = nb; s->n0 = s->n = n; s->shared_gens = shared_gens != 0;
+  size_t tot = nb * n, gtot = shared_gens ? n : tot, half = nb * (n > 1 ? n / 2 : 1);
+  void *stage = nullptr;
+  bool okk = true;
+  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
+  M((void **)&s->G[0], (gtot > half ? gtot : half) * sizeof(AffDev)); M((void **)&s->H[0], (gtot > half ? gtot : half) * sizeof(AffDev));
+  M((void **)&s->G[1], half * sizeof(AffDev)); M((void **)&s->H[1], half * sizeof(AffDev));
+  M((void **)&s->Q, nb * sizeof(AffDev)); M((void **)&s->Gf, tot * 32); M((void **)&s->Hf, tot * 32);
+  M((void **)&s->t1, half * 32); M((void **)&s->t2, half * 32); M((void **)&s->t3, half * 32); M((void **)&s->t4, half * 32);
+  M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
+  M((void **)&s->res, nb * 2 * (n + 1) * sizeof(JacRaw)); M((void **)&s->sums, nb * 2 * sizeof(JacRaw));
+  M((void **)&s->out_xy, nb * 2 * 64);
+  M(&stage, (2 * gtot + nb) * 64);
+  if (!okk) { hipFree(stage); ipp_free_all(s); return BPGPU_E_OOM; }
+  int rc = BPGPU_OK;
+  do {
+    if ((rc = flag_reset(ctx))) break;
+    if ((rc = h2d(ctx, s->a[0], a, tot * 32)) || (rc = h2d(ctx, s->b[0], b, tot * 32)) ||
+        (rc = h2d(ctx, s->Gf, G_factors, tot * 32)) || (rc = h2d(ctx, s->Hf, H_factors, tot * 32))) break;
+    uint8_t *st8 = (uint8_t *)stage;
+    if ((rc = h2d(ctx, st8, G, gtot * 64)) || (rc = h2d(ctx, st8 + gtot * 64, H, gtot * 64)) ||
+        (rc = h2d(ctx, st8 + 2 * gtot * 64, Q, nb * 64))) break;
+    scalars_check(ctx->st, s->a[0], tot, ctx->d_flag);
+    scalars_check(ctx->st, s->b[0], tot, ctx->d_flag);
+    scalars_check(ctx->st, s->Gf, tot, ctx->d_flag);
+    scalars_check(ctx->st, s->Hf, tot, ctx->d_flag);
+    points_from_boundary(ctx->st, (Words8 *)st8, s->G[0], gtot, ctx->d_flag);
+    points_from_boundary(ctx->st, (Words8 *)(st8 + gtot * 64), s->H[0], gtot, ctx->d_flag);
+    points_from_boundary(ctx->st, (Words8 *)(st8 + 2 * gtot * 64), s->Q, nb, ctx->d_flag);
+    if ((rc = launch_ok(ctx))) break;
+    int bad = 0;
+    if ((rc = flag_read(ctx, &bad))) break;
+    if (bad) rc = BPGPU_E_ARG;
+  } while (0);
+  hipFree(stage);
+  if (rc) { ipp_free_all(s); return rc; }
+  *out = s;
+  return BPGPU_OK;
+}
+void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s) {
+  if (!s) return;
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
+  ipp_free_all(s);
+}
+size_t bpgpu_ipp_len(const bpgpu_ipp *s) { return s ? s->n : 0; }
+
+/* c_L, c_R and the two MSMs of one round -- inner_product_proof.rs:87-114 (first) / :156-172 */
+int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
+  if (!ctx || !s || !L || !R) return BPGPU_E_ARG;
+  if (s->n < 2) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->st;
+  const size_t nb = s->nb, n = s->n, h = n / 2, seg = 2 * h + 1;
+  Words8 *a = s->a[s->cur], *b = s->b[s->cur];
+  const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
+  const bool shared = s->first && s->shared_gens;
+  const size_t gouter = shared ? 0 : n;
+  sc_dot_batched(st, nb, h, a, n, b + h, n, s->cLR, 2);        // c_L = <a_L, b_R>
+  sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
+  const Words8 *sLa = a, *sLb = b + h, *sRa = a + h, *sRb = b;
+  size_t so = n;   // outer stride (Words8) of the scalar sources
+  if (s->first) {  // fold the factors into the scalars, :90-114
+    sc_mul_strided(st, nb, h, a, n, 1, s->Gf + h, s->n0, 1, s->t1);       // a_L * G_factors[n..2n]
+    sc_mul_strided(st, nb, h, b + h, n, 1, s->Hf, s->n0, 1, s->t2);       // b_R * H_factors[0..n]
+    sc_mul_strided(st, nb, h, a + h, n, 1, s->Gf, s->n0, 1, s->t3);       // a_R * G_factors[0..n]
+    sc_mul_strided(st, nb, h, b, n, 1, s->Hf + h, s->n0, 1, s->t4);       // b_L * H_factors[n..2n]
+    sLa = s->t1; sLb = s->t2; sRa = s->t3; sRb = s->t4; so = h;
+  }
+  auto run = [&](const Words8 *sc, size_t sc_outer, const AffDev *pts, size_t pt_outer, size_t cnt, size_t off) {
+    StrausArgs x{};
+    x.pts[0] = pts; x.pt_stride[0] = 1; x.pt_outer[0] = pt_outer;
+    x.sc[0] = (const uint32_t *)sc; x.sc_stride[0] = 8; x.sc_outer[0] = sc_outer * 8;
+    x.inner = cnt; x.out_outer = 2 * seg;
+    straus(st, 1, x, s->res + off, nb * cnt);
+  };
+  run(sLa, so, G + h, gouter, h, 0);              // L: a_L (.) G_R
+  run(sLb, so, H, gouter, h, h);                  //    b_R (.) H_L
+  run(s->cLR, 2, s->Q, 1, 1, 2 * h);              //    c_L Q
+  run(sRa, so, G, gouter, h, seg);                // R: a_R (.) G_L
+  run(sRb, so, H + h, gouter, h, seg + h);        //    b_L (.) H_R
+  run(s->cLR + 1, 2, s->Q, 1, 1, seg + 2 * h);    //    c_R Q
+  segmented_sum(st, s->res, s->sums, nb * 2, seg);
+  jac_to_boundary(st, s->sums, s->out_xy, nb * 2);
+  CK(launch_ok(ctx));
+  std::vector<uint8_t> tmp(nb * 128);
+  CK(d2h(ctx, tmp.data(), s->out_xy, nb * 128));
+  HIPCK(ctx, hipStreamSynchronize(st));
+  for (size_t p = 0; p < nb; p++) { memcpy(L + 64 * p, &tmp[128 * p], 64); memcpy(R + 64 * p, &tmp[128 * p + 64], 64); }
+  return BPGPU_OK;
+}
+/* fold_witness with the round's challenges -- inner_product_proof.rs:125-146 (first) / :183-184 */
+int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t *u_inv) {
+  if (!ctx || !s || !u || !u_inv) return BPGPU_E_ARG;
+  if (s->n < 2) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->st;
+  const size_t nb = s->nb, n = s->n, h = n / 2;
+  const int cur = s->cur, nxt = cur ^ 1;
+  Words8 *du = s->uu, *dui = s->uu + nb;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, du, u, nb * 32));
+  CK(h2d(ctx, dui, u_inv, nb * 32));
+  scalars_check(st, s->uu, 2 * nb, ctx->d_flag);
+  const AffDev *G = s->G[cur], *H = s->H[cur];
+  const bool shared = s->first && s->shared_gens;
+  const size_t gouter = shared ? 0 : n;
+  JacRaw *fres = s->res;   // reuse: nb x h (G) then nb x h (H)
+  StrausArgs g{}, hh{};
+  g.pts[0] = G; g.pts[1] = G + h; hh.pts[0] = H; hh.pts[1] = H + h;
+  for (int j = 0; j < 2; j++) { g.pt_stride[j] = hh.pt_stride[j] = 1; g.pt_outer[j] = hh.pt_outer[j] = gouter; }
+  g.inner = hh.inner = h;
+  if (s->first) {   // G_i <- G_factors_i * G_i folded into the fold scalars, :125-134
+    sc_mul_strided(st, nb, h, s->Gf, s->n0, 1, dui, 1, 0, s->t1);       // u^-1 * gf_i
+    sc_mul_strided(st, nb, h, s->Gf + h, s->n0, 1, du, 1, 0, s->t2);    // u    * gf_{h+i}
+    sc_mul_strided(st, nb, h, s->Hf, s->n0, 1, du, 1, 0, s->t3);        // u    * hf_i
+    sc_mul_strided(st, nb, h, s->Hf + h, s->n0, 1, dui, 1, 0, s->t4);   // u^-1 * hf_{h+i}
+    g.sc[0] = (uint32_t *)s->t1; g.sc[1] = (uint32_t *)s->t2; hh.sc[0] = (uint32_t *)s->t3; hh.sc[1] = (uint32_t *)s->t4;
+    for (int j = 0; j < 2; j++) { g.sc_stride[j] = hh.sc_stride[j] = 8; g.sc_outer[j] = hh.sc_outer[j] = h * 8; }
+  } else {
+    g.sc[0] = (uint32_t *)dui; g.sc[1] = (uint32_t *)du; hh.sc[0] = (uint32_t *)du; hh.sc[1] = (uint32_t *)dui;
+    for (int j = 0; j < 2; j++) { g.sc_stride[j] = hh.sc_stride[j] = 0; g.sc_outer[j] = hh.sc_outer[j] = 8; }
+  }
+  straus(st, 2, g, fres, nb * h);
+  straus(st, 2, hh, fres + nb * h, nb * h);
+  // when the input generators are shared the folded ones become per-proof: write them to buffer nxt
+  batch_normalize(st, fres, s->G[nxt], nb * h, 8);
+  batch_normalize(st, fres + nb * h, s->H[nxt], nb * h, 8);
+  fold_scalars_batched(st, nb, h, du, dui, s->a[cur], s->b[cur], s->a[nxt], s->b[nxt]);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  s->cur = nxt; s->n = h; s->first = false;
+  return BPGPU_OK;
+}
+/* final a, b -- inner_product_proof.rs:187-192 */
+int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_out) {
+  if (!ctx || !s || !a_out || !b_out) return BPGPU_E_ARG;
+  if (s->n != 1) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CK(d2h(ctx, a_out, s->a[s->cur], s->nb * 32));
+  CK(d2h(ctx, b_out, s->b[s->cur], s->nb * 32));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
 }

@@ -134,11 +134,12 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     uint32_t s[8];
-    const uint32_t *src = a.sc[j] + i * a.sc_stride[j];
+    const size_t pp = a.inner ? i / a.inner : 0, rr = a.inner ? i - pp * a.inner : i;
+    const uint32_t *src = a.sc[j] + pp * a.sc_outer[j] + rr * a.sc_stride[j];
 #pragma unroll
     for (int t = 0; t < 8; t++) s[t] = src[t];
     recode_add_k<SW>(sp[j], s);
-    Aff P = aff_load(a.pts[j] + i * a.pt_stride[j]);
+    Aff P = aff_load(a.pts[j] + pp * a.pt_outer[j] + rr * a.pt_stride[j]);
     Jac m = jac_from_aff(P);
 #pragma unroll 1
     for (int e = 0; e < SE; e++) {
@@ -170,7 +171,11 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
       }
     }
   }
-  if (live) raw_store(&out[i], acc);
+  if (live) {
+    size_t o = i;
+    if (a.inner && a.out_outer) { size_t pp = i / a.inner; o = pp * a.out_outer + (i - pp * a.inner); }
+    raw_store(&out[o], acc);
+  }
 }
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n) {
   if (!n) return;

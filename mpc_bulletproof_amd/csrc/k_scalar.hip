@@ -162,6 +162,58 @@ void fold_scalars(hipStream_t st, size_t n, const Words8 *u, const Words8 *u_inv
   hipLaunchKernelGGL(k_fold_scalars, dim3((n + 255) / 256), dim3(256), 0, st, n, u, u_inv, a, b, a_out, b_out);
 }
 
+// ---- batched (proof-major) IPP scalar kernels ---------------------------------------------------
+__global__ void __launch_bounds__(256) k_sc_mul_strided(size_t cnt, const Words8 *x, size_t x_outer, size_t x_stride,
+                                                        const Words8 *y, size_t y_outer, size_t y_stride, Words8 *out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= cnt) return;
+  store_plain(&out[p * cnt + i], mul(load_plain(&x[p * x_outer + i * x_stride]), load_plain(&y[p * y_outer + i * y_stride])));
+}
+void sc_mul_strided(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size_t x_outer, size_t x_stride,
+                    const Words8 *y, size_t y_outer, size_t y_stride, Words8 *out) {
+  if (!nb || !cnt) return;
+  hipLaunchKernelGGL(k_sc_mul_strided, dim3((cnt + 255) / 256, nb), dim3(256), 0, st, cnt, x, x_outer, x_stride, y,
+                     y_outer, y_stride, out);
+}
+__global__ void __launch_bounds__(256) k_sc_dot_batched(size_t cnt, const Words8 *x, size_t x_outer, const Words8 *y,
+                                                        size_t y_outer, Words8 *out, size_t out_stride) {
+  __shared__ int32_t sm[NL * 4];
+  size_t p = blockIdx.x;
+  Fn acc = fe_zero<FN>();
+  int c = 0;
+  for (size_t i = threadIdx.x; i < cnt; i += 256) {
+    acc = add(acc, mul(load_plain(&x[p * x_outer + i]), load_plain(&y[p * y_outer + i])));
+    if ((++c & 15) == 0) acc = fn_reduce(acc);
+  }
+  acc = wave_sum(fn_reduce(acc));
+  if ((threadIdx.x & 63) == 0) raw_put(sm + (threadIdx.x >> 6) * NL, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fn t = raw_get(sm);
+    for (int w = 1; w < 4; w++) t = add(t, raw_get(sm + w * NL));
+    store_plain(&out[p * out_stride], t);
+  }
+}
+void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size_t x_outer, const Words8 *y,
+                    size_t y_outer, Words8 *out, size_t out_stride) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_sc_dot_batched, dim3(nb), dim3(256), 0, st, cnt, x, x_outer, y, y_outer, out, out_stride);
+}
+__global__ void __launch_bounds__(256) k_fold_scalars_batched(size_t h, const Words8 *u, const Words8 *u_inv,
+                                                              const Words8 *a, const Words8 *b, Words8 *a_out, Words8 *b_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= h) return;
+  Fn uu = load_plain(&u[p]), ui = load_plain(&u_inv[p]);
+  const Words8 *ap = a + p * 2 * h, *bp = b + p * 2 * h;
+  store_plain(&a_out[p * h + i], add(mul(load_plain(&ap[i]), uu), mul(ui, load_plain(&ap[h + i]))));
+  store_plain(&b_out[p * h + i], add(mul(load_plain(&bp[i]), ui), mul(uu, load_plain(&bp[h + i]))));
+}
+void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, const Words8 *u_inv, const Words8 *a,
+                          const Words8 *b, Words8 *a_out, Words8 *b_out) {
+  if (!nb || !h) return;
+  hipLaunchKernelGGL(k_fold_scalars_batched, dim3((h + 255) / 256, nb), dim3(256), 0, st, h, u, u_inv, a, b, a_out, b_out);
+}
+
 // inner_product_proof.rs:280-309.  One block; lane 0 inverts (Montgomery trick over the k challenges);
 // s_i = allinv * prod_{b : bit b of i} u_sq[(k-1)-b]  (closed form of the reference's induction :298-307)
 __global__ void __launch_bounds__(256) k_verification_scalars(const Words8 *ch, int k, size_t n, Words8 *u_sq,

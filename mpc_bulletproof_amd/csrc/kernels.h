@@ -19,13 +19,20 @@ void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy_out, size_t n)
 // JacRaw[n] -> device affine, Montgomery's trick in runs of `run` points per lane
 void batch_normalize(hipStream_t st, const JacRaw *in, AffDev *out, size_t n, int run);
 
-// out[i] = sum_{j<np} scalar_j(i) * point_j(i);  scalar_j(i) = sc[j] + i*sc_stride[j] words
-// (stride 0 = broadcast), point_j(i) = pts[j] + i*pt_stride[j].  np in {1, 2}.
+// out[i] = sum_{j<np} scalar_j(i) * point_j(i), np in {1, 2}.  Two-level indexing for batched
+// (proof-major) arrays: i = p * inner + r;
+//   point_j(i)  = pts[j] + p * pt_outer[j] + r * pt_stride[j]          (AffDev units)
+//   scalar_j(i) = sc[j]  + p * sc_outer[j] + r * sc_stride[j]          (u32 words; stride 0 = broadcast)
+// inner == 0 means a flat array (p = 0, r = i).
 struct StrausArgs {
   const AffDev *pts[2];
   size_t pt_stride[2];
   const uint32_t *sc[2];
   size_t sc_stride[2];
+  size_t inner;
+  size_t pt_outer[2];
+  size_t sc_outer[2];
+  size_t out_outer;   // with inner != 0: out[p * out_outer + r]; 0 = dense (out[i])
 };
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n);
 
@@ -56,6 +63,16 @@ void fold_scalars(hipStream_t st, size_t n, const Words8 *u, const Words8 *u_inv
                   const Words8 *b, Words8 *a_out, Words8 *b_out);
 void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, size_t n, Words8 *u_sq,
                           Words8 *u_inv_sq, Words8 *s);
+// batched IPP scalar kernels (proof-major arrays of nb x n)
+// out[p][i] = x[p*x_outer + i*x_stride] * y[p*y_outer + i*y_stride]  for i < cnt (strides in Words8 units)
+void sc_mul_strided(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size_t x_outer, size_t x_stride,
+                    const Words8 *y, size_t y_outer, size_t y_stride, Words8 *out);
+// out[p] = <x[p*x_outer .. +cnt), y[p*y_outer .. +cnt)>
+void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size_t x_outer, const Words8 *y,
+                    size_t y_outer, Words8 *out, size_t out_stride);
+// a'[p][i] = a[p][i] u_p + u_p^-1 a[p][h+i] ; b'[p][i] = b[p][i] u_p^-1 + u_p b[p][h+i]   (in: nb x 2h, out: nb x h)
+void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, const Words8 *u_inv, const Words8 *a,
+                          const Words8 *b, Words8 *a_out, Words8 *b_out);
 
 // column-major constraint weights: for output o in [0, 3n + m + 1): terms col_ptr[o]..col_ptr[o+1]
 // outputs ordered wL[0..n) wR[0..n) wO[0..n) wV[0..m) wc

@@ -10,7 +10,8 @@ SYMBOLS = [
     "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
-    "bpgpu_verification_scalars", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
+    "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev",
 ]
 
@@ -31,6 +32,7 @@ def load():
     lib.bpgpu_last_error.restype = C.c_char_p
     lib.bpgpu_stream.restype = C.c_void_p
     lib.bpgpu_gens_capacity.restype = C.c_size_t
+    lib.bpgpu_ipp_len.restype = C.c_size_t
     return lib
 
 
@@ -178,6 +180,32 @@ class BpGpu:
         a, b, s = _out(32 * k), _out(32 * k), _out(32 * n)
         self._ck(_lib.bpgpu_verification_scalars(self.ctx, _buf(challenges), C.c_size_t(k), C.c_size_t(n), a, b, s))
         return bytes(a)[:32 * k], bytes(b)[:32 * k], bytes(s)[:32 * n]
+
+    # lock-step InnerProductProof::create (transcript on the host)
+    def ipp_begin(self, nb, n, Q, Gf, Hf, G, H, shared_gens, a, b):
+        h = C.c_void_p()
+        self._ck(_lib.bpgpu_ipp_begin(self.ctx, C.c_size_t(nb), C.c_size_t(n), _buf(Q), _buf(Gf), _buf(Hf), _buf(G),
+                                      _buf(H), 1 if shared_gens else 0, _buf(a), _buf(b), C.byref(h)))
+        return h
+
+    def ipp_len(self, s):
+        return _lib.bpgpu_ipp_len(s)
+
+    def ipp_round(self, s, nb):
+        L, R = _out(64 * nb), _out(64 * nb)
+        self._ck(_lib.bpgpu_ipp_round(self.ctx, s, L, R))
+        return bytes(L)[:64 * nb], bytes(R)[:64 * nb]
+
+    def ipp_fold(self, s, u, u_inv):
+        self._ck(_lib.bpgpu_ipp_fold(self.ctx, s, _buf(u), _buf(u_inv)))
+
+    def ipp_finish(self, s, nb):
+        a, b = _out(32 * nb), _out(32 * nb)
+        self._ck(_lib.bpgpu_ipp_finish(self.ctx, s, a, b))
+        return bytes(a)[:32 * nb], bytes(b)[:32 * nb]
+
+    def ipp_destroy(self, s):
+        _lib.bpgpu_ipp_destroy(self.ctx, s)
 
     # ---- R1CS
     def circuit_create(self, row_ptr, kind, idx, coeff, n_mul, m):

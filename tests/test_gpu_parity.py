@@ -218,3 +218,72 @@ def test_verify_batch_generators_too_short(gpu):
     finally:
         gpu.gens_destroy(g)
         gpu.circuit_destroy(circ)
+
+
+# ------------------------------------------------------------------ IPP prover (lock-step session)
+def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b):
+    """Drive InnerProductProof::create (inner_product_proof.rs:49-193) with the transcript on the host
+    (the oracle's Python model of it) and all arithmetic on the GPU."""
+    import pymodel as pm
+    trs = [pm.Transcript(label) for _ in range(nb)]
+    for t in trs:
+        t.innerproduct_domain_sep(n)
+    s = gpu.ipp_begin(nb, n, Q, Gf, Hf, G, H, shared, a, b)
+    Ls, Rs, chs = [b""] * nb, [b""] * nb, [b""] * nb
+    try:
+        while gpu.ipp_len(s) > 1:
+            L, R = gpu.ipp_round(s, nb)
+            u = b""
+            for p, t in enumerate(trs):
+                t.append_message(b"L", L[64 * p:64 * p + 64])
+                t.append_message(b"R", R[64 * p:64 * p + 64])
+                up = pm.s2b(t.challenge_scalar(b"u"))
+                u += up
+                Ls[p] += L[64 * p:64 * p + 64]
+                Rs[p] += R[64 * p:64 * p + 64]
+                chs[p] += up
+            gpu.ipp_fold(s, u, gpu.batch_inverse(u))
+        aa, bb = gpu.ipp_finish(s, nb)
+    finally:
+        gpu.ipp_destroy(s)
+    return Ls, Rs, aa, bb, chs
+
+
+def test_ipp_create_golden(gpu, golden_ipp):
+    sys_path_oracle()
+    for c in golden_ipp["create"]:
+        n = c["n"]
+        Gp, Hp = o.gens("G", n), o.gens("H", n)
+        Ls, Rs, aa, bb, chs = _ipp_create_gpu(gpu, H(c["label"]), 1, n, H(c["Q"]), J(c, "G_factors"), J(c, "H_factors"),
+                                              Gp, Hp, True, J(c, "a"), J(c, "b"))
+        assert (Ls[0], Rs[0], aa, bb, chs[0]) == (J(c, "L"), J(c, "R"), H(c["a_out"]), H(c["b_out"]), J(c, "challenges"))
+
+
+@pytest.mark.parametrize("shared", [True, False])
+def test_ipp_create_batched(gpu, shared):
+    sys_path_oracle()
+    nb, n = 3, 16
+    Gp, Hp = o.gens("G", n), o.gens("H", n)
+    a, b = o.random_scalars(21, nb * n), o.random_scalars(22, nb * n)
+    Gf, Hf = o.random_scalars(23, nb * n), o.random_scalars(24, nb * n)
+    Q = b"".join(o.point_mul(o.random_scalars(30 + p, 1), o.generator()) for p in range(nb))
+    if shared:
+        G, Hh = Gp, Hp
+    else:   # per-proof generator sets (rotations of the chain)
+        G = b"".join(Gp[64 * p:] + Gp[:64 * p] for p in range(nb))
+        Hh = b"".join(Hp[64 * p:] + Hp[:64 * p] for p in range(nb))
+    Ls, Rs, aa, bb, _ = _ipp_create_gpu(gpu, b"innerproducttest", nb, n, Q, Gf, Hf, G, Hh, shared, a, b)
+    for p in range(nb):
+        sl = slice(32 * n * p, 32 * n * (p + 1))
+        Gq = Gp if shared else G[64 * n * p:64 * n * (p + 1)]
+        Hq = Hp if shared else Hh[64 * n * p:64 * n * (p + 1)]
+        L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q[64 * p:64 * p + 64], Gf[sl], Hf[sl], Gq, Hq, a[sl], b[sl])
+        assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo)
+
+
+def sys_path_oracle():
+    import os
+    import sys
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    if d not in sys.path:
+        sys.path.insert(0, d)
