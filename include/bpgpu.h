@@ -143,6 +143,25 @@ void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c);
 int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z,
                               uint8_t *wL, uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc);
 
+/* Prover::prove arithmetic between the y,z and the u,x challenges -- r1cs/prover.rs:587-619:
+ * flattened_constraints(z), exp_y / exp_y_inv, the l(x)/r(x) coefficient vectors and
+ * t_1..t_6 = VecPoly3::special_inner_product (util.rs:152-170), for nb provers of ONE circuit.
+ * Inputs proof-major: y, y_inv, z (nb); a_L, a_R, a_O, s_L, s_R (nb x n, n = multipliers).
+ * Outputs: t_coeffs nb x 6 (t1 t2 t3 t4 t5 t6), wV nb x m (for t_2_blinding, prover.rs:644-648).
+ * The coefficient vectors stay in HBM in *out for bpgpu_r1cs_prover_eval -- prover.rs:659-672:
+ * l_vec, r_vec (nb x padded_n) = l(x), r(x) with the zero / -y^i padding. */
+typedef struct bpgpu_prover bpgpu_prover;
+int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y,
+                            const uint8_t *y_inv, const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R,
+                            const uint8_t *a_O, const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs,
+                            uint8_t *wV, bpgpu_prover **out);
+int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, const uint8_t *x,
+                           uint8_t *l_vec, uint8_t *r_vec);
+void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s);
+/* out[i] = scalars[i] * (curve generator) -- GeneratorsChain::next (generators.rs:112-124),
+ * Q = w * B (prover.rs:687), PedersenGens::commit with B = B_blinding (generators.rs:41-43,61-70) */
+int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out);
+
 /* Batched Verifier::verify arithmetic -- r1cs/verifier.rs:457-553 for nb proofs of ONE circuit.
  * Per proof p (all arrays proof-major):
  *   points     : (11 + m + 2k) x 64 B : A_I1 A_O1 S1 A_I2 A_O2 S2 | V_0..V_{m-1} | T_1 T_3 T_4 T_5 T_6 | L_0..L_{k-1} | R_0..R_{k-1}

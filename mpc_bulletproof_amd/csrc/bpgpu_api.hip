@@ -872,6 +872,123 @@ int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_ou
   return BPGPU_OK;
 }
 
+/* ---------------------------------------------------------------- R1CS prover polynomials */
+/* One call = prover.rs:587-619: flattened_constraints(z), exp_y / exp_y_inv, the l/r coefficient
+ * vectors and t_1..t_6 (util.rs:152-170) for nb provers of one circuit; then prover.rs:659-672
+ * (l(x), r(x), padding) once the host transcript has produced x. */
+struct bpgpu_prover {
+  size_t nb = 0, n = 0, m = 0;
+  int32_t *polys = nullptr;   // [6][nb][n][9]
+  Words8 *y = nullptr;        // nb
+};
+int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
+                            const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
+                            const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
+                            bpgpu_prover **out) {
+  if (!ctx || !c || !out || !nb || !y || !y_inv || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
+  size_t n = c->n, m = c->m;
+  if (n && (!a_L || !a_R || !a_O || !s_L || !s_R)) return BPGPU_E_ARG;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  bpgpu_prover *s = new (std::nothrow) bpgpu_prover();
+  if (!s) return BPGPU_E_OOM;
+  s->nb = nb; s->n = n; s->m = m;
+  auto fail = [&](int rc) { hipFree(s->polys); hipFree(s->y); delete s; return rc; };
+  if (hipMalloc((void **)&s->polys, (6 * nb * (n ? n : 1) * 9) * 4) != hipSuccess || hipMalloc((void **)&s->y, nb * 32) != hipSuccess)
+    return fail(BPGPU_E_OOM);
+  void *din, *dzp, *dout;
+  size_t tot = nb * n;
+  int rc;
+  if ((rc = ws_get(ctx, 0, (3 * nb + 5 * tot) * 32, &din)) || (rc = ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp)) ||
+      (rc = ws_get(ctx, 1, (nb * 6 + nb * m) * 32, &dout)))
+    return fail(rc);
+  Words8 *w = (Words8 *)din;
+  Words8 *dy = w, *dyi = w + nb, *dz = w + 2 * nb, *dL = w + 3 * nb, *dR = dL + tot, *dO = dR + tot, *dsL = dO + tot, *dsR = dsL + tot;
+  Words8 *dt = (Words8 *)dout, *dwV = dt + nb * 6;
+  if ((rc = flag_reset(ctx)) || (rc = h2d(ctx, dy, y, nb * 32)) || (rc = h2d(ctx, dyi, y_inv, nb * 32)) ||
+      (rc = h2d(ctx, dz, z, nb * 32)) || (rc = h2d(ctx, dL, a_L, tot * 32)) || (rc = h2d(ctx, dR, a_R, tot * 32)) ||
+      (rc = h2d(ctx, dO, a_O, tot * 32)) || (rc = h2d(ctx, dsL, s_L, tot * 32)) || (rc = h2d(ctx, dsR, s_R, tot * 32)))
+    return fail(rc);
+  scalars_check(ctx->st, w, 3 * nb + 5 * tot, ctx->d_flag);
+  if (hipMemcpyAsync(s->y, dy, nb * 32, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
+  CircuitDev cd = circuit_dev(c);
+  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);
+  prover_polys(ctx->st, cd, nb, dy, dyi, dL, dR, dO, dsL, dsR, (const int32_t *)dzp, s->polys, dwV);
+  prover_tcoeffs(ctx->st, nb, n, s->polys, dt);
+  if ((rc = launch_ok(ctx))) return fail(rc);
+  int bad = 0;
+  if ((rc = flag_read(ctx, &bad))) return fail(rc);
+  if (bad) return fail(BPGPU_E_ARG);
+  if ((rc = d2h(ctx, t_coeffs, dt, nb * 6 * 32)) || (m && (rc = d2h(ctx, wV, dwV, nb * m * 32)))) return fail(rc);
+  if (hipStreamSynchronize(ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
+  *out = s;
+  return BPGPU_OK;
+}
+int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, const uint8_t *x, uint8_t *l_vec,
+                           uint8_t *r_vec) {
+  if (!ctx || !s || !x || !l_vec || !r_vec) return BPGPU_E_ARG;
+  if (padded_n < s->n || (padded_n & (padded_n - 1))) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *dx, *dout;
+  size_t nb = s->nb;
+  CK(ws_get(ctx, 0, nb * 32, &dx));
+  CK(ws_get(ctx, 1, 2 * nb * padded_n * 32, &dout));
+  Words8 *dl = (Words8 *)dout, *dr = dl + nb * padded_n;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dx, x, nb * 32));
+  scalars_check(ctx->st, (Words8 *)dx, nb, ctx->d_flag);
+  prover_eval(ctx->st, nb, s->n, padded_n, (Words8 *)dx, s->y, s->polys, dl, dr);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, l_vec, dl, nb * padded_n * 32));
+  CK(d2h(ctx, r_vec, dr, nb * padded_n * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s) {
+  if (!s) return;
+  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); }
+  hipFree(s->polys);
+  hipFree(s->y);
+  delete s;
+}
+/* scalars[i] * (curve generator): GeneratorsChain::next (generators.rs:112-124), Q = w * B (prover.rs:687) */
+int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out) {
+  if (!ctx || (n && (!scalars || !out))) return BPGPU_E_ARG;
+  if (!n) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  static const uint8_t GEN[64] = {0xca,0xcf,0x43,0xc9,0x8b,0x3d,0x72,0x3d,0xe0,0x19,0x18,0x0d,0x9b,0xfd,0xac,0xde,0xc7,0xf0,0x40,0x5a,0x41,0xed,0xec,0x7b,0x1b,0x97,0x99,0x85,0xc1,0x15,0xef,0x01,
+                                  0x1f,0xdc,0xe8,0x36,0x0c,0x00,0x73,0x28,0xa3,0x43,0xbe,0x1a,0xd1,0xec,0x53,0xde,0x62,0xec,0x46,0xdf,0x01,0x48,0xbe,0xb7,0x30,0x97,0xa4,0x0a,0x06,0x68,0x56,0x00};
+  void *dsc, *dg, *dgp, *dres, *dout;
+  CK(ws_get(ctx, 0, n * 32, &dsc));
+  CK(ws_get(ctx, 1, 64, &dg));
+  CK(ws_get(ctx, 2, sizeof(AffDev), &dgp));
+  CK(ws_get(ctx, 3, n * sizeof(JacRaw), &dres));
+  CK(ws_get(ctx, 5, n * 64, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dsc, scalars, n * 32));
+  CK(h2d(ctx, dg, GEN, 64));
+  scalars_check(ctx->st, (Words8 *)dsc, n, ctx->d_flag);
+  points_from_boundary(ctx->st, (Words8 *)dg, (AffDev *)dgp, 1, ctx->d_flag);
+  StrausArgs a{};
+  a.pts[0] = (AffDev *)dgp; a.pt_stride[0] = 0;
+  a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
+  straus(ctx->st, 1, a, (JacRaw *)dres, n);
+  jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, n);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, n * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
 #pragma GCC visibility pop
 }  // extern "C"
 

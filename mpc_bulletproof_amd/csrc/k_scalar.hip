@@ -293,6 +293,95 @@ void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, si
   hipLaunchKernelGGL(k_flatten, dim3((nout + 255) / 256, nb), dim3(256), 0, st, c, zpow, wL, wR, wO, wV, wc);
 }
 
+void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow) {
+  if (nb && q) hipLaunchKernelGGL(k_zpow, dim3((q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, q, zpow);
+}
+
+// ------------------------------------------------------------------------------------------------
+// R1CS prover: l(x), r(x) coefficient vectors (prover.rs:596-617)
+//   l1 = a_L + y^-i wR ; l2 = a_O ; l3 = s_L ; r0 = wO - y^i ; r1 = y^i a_R + wL ; r3 = y^i s_R
+__global__ void __launch_bounds__(128) k_prover_polys(CircuitDev c, size_t nb, const Words8 *y, const Words8 *y_inv,
+                                                      const Words8 *a_L, const Words8 *a_R, const Words8 *a_O,
+                                                      const Words8 *s_L, const Words8 *s_R, const int32_t *zpow_all,
+                                                      int32_t *polys, Words8 *wV_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  const size_t n = c.n;
+  const int32_t *zp = zpow_all + p * c.q * NL;
+  if (i < c.m && wV_out) store_plain(&wV_out[p * c.m + i], flatten_column(c, 3 * n + i, zp));
+  if (i >= n) return;
+  Fn yi = fn_pow_u32(load_plain(&y[p]), (uint32_t)i), yni = fn_pow_u32(load_plain(&y_inv[p]), (uint32_t)i);
+  Fn wL = flatten_column(c, i, zp), wR = flatten_column(c, n + i, zp), wO = flatten_column(c, 2 * n + i, zp);
+  size_t e = p * n + i, plane = nb * n * NL;
+  int32_t *dst = polys + e * NL;
+  raw_put(dst + 0 * plane, add(load_plain(&a_L[e]), mul(yni, wR)));
+  raw_put(dst + 1 * plane, load_plain(&a_O[e]));
+  raw_put(dst + 2 * plane, load_plain(&s_L[e]));
+  raw_put(dst + 3 * plane, sub(wO, yi));
+  raw_put(dst + 4 * plane, add(mul(yi, load_plain(&a_R[e])), wL));
+  raw_put(dst + 5 * plane, mul(yi, load_plain(&s_R[e])));
+}
+void prover_polys(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *y, const Words8 *y_inv,
+                  const Words8 *a_L, const Words8 *a_R, const Words8 *a_O, const Words8 *s_L, const Words8 *s_R,
+                  const int32_t *zpow, int32_t *polys, Words8 *wV_out) {
+  size_t span = c.n > c.m ? c.n : c.m;
+  if (!nb || !span) return;
+  hipLaunchKernelGGL(k_prover_polys, dim3((span + 127) / 128, nb), dim3(128), 0, st, c, nb, y, y_inv, a_L, a_R, a_O,
+                     s_L, s_R, zpow, polys, wV_out);
+}
+// one block per (proof, coefficient): t1 = <l1,r0>; t2 = <l1,r1> + <l2,r0>; t3 = <l2,r1> + <l3,r0>;
+// t4 = <l1,r3> + <l3,r1>; t5 = <l2,r3>; t6 = <l3,r3>     (planes: 0 l1, 1 l2, 2 l3, 3 r0, 4 r1, 5 r3)
+__global__ void __launch_bounds__(256) k_prover_tcoeffs(size_t nb, size_t n, const int32_t *polys, Words8 *t_out) {
+  __shared__ int32_t sm[NL * 4];
+  const size_t p = blockIdx.x, plane = nb * n * NL;
+  const int which = blockIdx.y;
+  const int A1[6] = {0, 0, 1, 0, 1, 2}, B1[6] = {3, 4, 4, 5, 5, 5}, A2[6] = {-1, 1, 2, 2, -1, -1}, B2[6] = {-1, 3, 3, 4, -1, -1};
+  const int a1 = A1[which], b1 = B1[which], a2 = A2[which], b2 = B2[which];
+  Fn acc = fe_zero<FN>();
+  int c = 0;
+  for (size_t i = threadIdx.x; i < n; i += 256) {
+    const int32_t *e = polys + (p * n + i) * NL;
+    acc = add(acc, mul(raw_get(e + a1 * plane), raw_get(e + b1 * plane)));
+    if (a2 >= 0) acc = add(acc, mul(raw_get(e + a2 * plane), raw_get(e + b2 * plane)));
+    if ((++c & 7) == 0) acc = fn_reduce(acc);
+  }
+  acc = wave_sum(fn_reduce(acc));
+  if ((threadIdx.x & 63) == 0) raw_put(sm + (threadIdx.x >> 6) * NL, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fn t = raw_get(sm);
+    for (int w = 1; w < 4; w++) t = add(t, raw_get(sm + w * NL));
+    store_plain(&t_out[p * 6 + which], t);
+  }
+}
+void prover_tcoeffs(hipStream_t st, size_t nb, size_t n, const int32_t *polys, Words8 *t_out) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_prover_tcoeffs, dim3(nb, 6), dim3(256), 0, st, nb, n, polys, t_out);
+}
+// util.rs:172-181 VecPoly3::eval (l0 = 0, r2 = 0) and the padding of prover.rs:661-672
+__global__ void __launch_bounds__(128) k_prover_eval(size_t nb, size_t n, size_t np, const Words8 *x, const Words8 *y,
+                                                     const int32_t *polys, Words8 *l_vec, Words8 *r_vec) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= np) return;
+  if (i < n) {
+    Fn xx = load_plain(&x[p]);
+    const size_t plane = nb * n * NL;
+    const int32_t *e = polys + (p * n + i) * NL;
+    Fn l = mul(xx, add(raw_get(e), mul(xx, add(raw_get(e + plane), mul(xx, raw_get(e + 2 * plane))))));
+    Fn r = add(raw_get(e + 3 * plane), mul(xx, add(raw_get(e + 4 * plane), mul(xx, mul(xx, raw_get(e + 5 * plane))))));
+    store_plain(&l_vec[p * np + i], l);
+    store_plain(&r_vec[p * np + i], r);
+  } else {
+    store_plain(&l_vec[p * np + i], fe_zero<FN>());
+    store_plain(&r_vec[p * np + i], neg(fn_pow_u32(load_plain(&y[p]), (uint32_t)i)));
+  }
+}
+void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Words8 *x, const Words8 *y,
+                 const int32_t *polys, Words8 *l_vec, Words8 *r_vec) {
+  if (!nb || !padded_n) return;
+  hipLaunchKernelGGL(k_prover_eval, dim3((padded_n + 127) / 128, nb), dim3(128), 0, st, nb, n, padded_n, x, y, polys,
+                     l_vec, r_vec);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Verifier scalar assembly, one block per proof (r1cs/verifier.rs:457-532).
 // Wave 1 / lane 0 performs the (1 + k) inversions with one Fermat exponentiation while wave 0.. fill

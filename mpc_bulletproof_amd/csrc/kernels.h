@@ -86,6 +86,18 @@ struct CircuitDev {
 void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
              Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow_scratch);
 
+// ---- R1CS prover polynomials (r1cs/prover.rs:587-619, 659-672) -----------------------------------
+// polys: raw Montgomery limbs, layout [6][nb][n][9]: l1 l2 l3 r0 r1 r3
+void prover_polys(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *y, const Words8 *y_inv,
+                  const Words8 *a_L, const Words8 *a_R, const Words8 *a_O, const Words8 *s_L, const Words8 *s_R,
+                  const int32_t *zpow, int32_t *polys, Words8 *wV_out);
+// t[nb][6] = t1..t6 (util.rs:152-170 special_inner_product)
+void prover_tcoeffs(hipStream_t st, size_t nb, size_t n, const int32_t *polys, Words8 *t_out);
+// l_vec, r_vec[nb][padded_n] = l(x), r(x) with the padding of prover.rs:661-672
+void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Words8 *x, const Words8 *y,
+                 const int32_t *polys, Words8 *l_vec, Words8 *r_vec);
+void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow);
+
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 // Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]

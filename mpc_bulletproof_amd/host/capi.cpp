@@ -1,0 +1,167 @@
+// capi.cpp -- flat entry points of the host mirror (libbphost.so) with the same shape as the CPU
+// oracle's flat API, so tests compare proof bytes / accept results one to one.
+// Return codes: 0 Ok, -1 VerificationError, -2 InvalidGeneratorsLength, -3 malformed/FormatError,
+// -4 MissingAssignment, -10 device failure (no CPU fallback).
+#include <cstring>
+
+#include "gadgets.hpp"
+
+using namespace mpc_bulletproof;
+using namespace mpc_bulletproof::r1cs;
+
+enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3 };
+
+static int map_error(const R1CSException &e) {
+  switch (e.e) {
+    case R1CSError::VerificationError: return -1;
+    case R1CSError::InvalidGeneratorsLength: return -2;
+    case R1CSError::FormatError: return -3;
+    case R1CSError::MissingAssignment: return -4;
+    default: return -5;
+  }
+}
+static Transcript start_transcript(int kind, size_t param, const uint8_t *label, size_t len) {
+  Transcript t(std::string((const char *)label, len));
+  if (kind == K_SHUFFLE) {   // tests/r1cs.rs:80-81
+    t.append_message("dom-sep", (const uint8_t *)"ShuffleProof", 12);
+    t.append_u64("k", param);
+  }
+  return t;
+}
+#define GUARD(...)                                    \
+  try { __VA_ARGS__ } catch (const R1CSException &e) { return map_error(e); } \
+  catch (const ProofException &) { return -1; }       \
+  catch (const DeviceException &) { return -10; }     \
+  catch (const std::exception &) { return -3; }
+
+extern "C" {
+#pragma GCC visibility push(default)
+
+int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_len, const uint64_t *values,
+                   size_t nvalues, uint64_t seed, size_t gens_capacity, uint8_t *proof_out, size_t *proof_len,
+                   uint8_t *commitments_out, size_t *m_out) {
+  GUARD({
+    PedersenGens pc_gens;
+    BulletproofGens bp_gens(gens_capacity, 1);
+    Transcript transcript = start_transcript(kind, param, label, label_len);
+    Prover prover(pc_gens, transcript);
+    Rng rng(seed);
+    std::vector<StarkPoint> commitments;
+    std::vector<Variable> vars;
+    auto commit = [&](uint64_t v) {
+      auto cv = prover.commit(Scalar::from(v), rng.scalar());
+      commitments.push_back(cv.first);
+      vars.push_back(cv.second);
+    };
+    if (kind == K_RANGE) {
+      if (nvalues != 1) return -3;
+      commit(values[0]);
+      gadgets::range_proof(prover, LinearCombination(vars[0]), &values[0], param);
+    } else if (kind == K_SHUFFLE) {
+      if (nvalues != 2 * param) return -3;
+      for (size_t i = 0; i < 2 * param; i++) commit(values[i]);
+      gadgets::shuffle_gadget(prover, std::vector<Variable>(vars.begin(), vars.begin() + param),
+                              std::vector<Variable>(vars.begin() + param, vars.end()));
+    } else if (kind == K_EXAMPLE) {
+      if (nvalues != 6) return -3;
+      for (int i = 0; i < 5; i++) commit(values[i]);
+      gadgets::example_gadget(prover, vars[0], vars[1], vars[2], vars[3], vars[4], LinearCombination(Scalar::from(values[5])));
+    } else if (kind == K_DUMMY) {
+      Scalar val = rng.scalar();
+      auto cv = prover.commit(val, Scalar::one());   // commit_public, prover.rs:171-173
+      commitments.push_back(cv.first);
+      gadgets::dummy_circuit(prover, cv.second, param);
+    } else return -3;
+    R1CSProof proof = prover.prove(bp_gens, rng);
+    auto bytes = proof.to_flat_bytes();
+    memcpy(proof_out, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    for (size_t i = 0; i < commitments.size(); i++) memcpy(commitments_out + 64 * i, commitments[i].xy.data(), 64);
+    *m_out = commitments.size();
+    return 0;
+  })
+}
+
+int bph_r1cs_verify(int kind, size_t param, const uint8_t *label, size_t label_len, const uint64_t *values,
+                    size_t nvalues, const uint8_t *commitments, size_t m, const uint8_t *proof, size_t proof_len,
+                    size_t gens_capacity, uint8_t mega_out[64]) {
+  GUARD({
+    PedersenGens pc_gens;
+    BulletproofGens bp_gens(gens_capacity, 1);
+    Transcript transcript = start_transcript(kind, param, label, label_len);
+    Verifier verifier(pc_gens, transcript);
+    std::vector<Variable> vars;
+    for (size_t i = 0; i < m; i++) {
+      StarkPoint V;
+      memcpy(V.xy.data(), commitments + 64 * i, 64);
+      vars.push_back(verifier.commit(V));
+    }
+    if (kind == K_RANGE && m == 1) gadgets::range_proof(verifier, LinearCombination(vars[0]), nullptr, param);
+    else if (kind == K_SHUFFLE && m == 2 * param)
+      gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + param),
+                              std::vector<Variable>(vars.begin() + param, vars.end()));
+    else if (kind == K_EXAMPLE && m == 5 && nvalues == 1)
+      gadgets::example_gadget(verifier, vars[0], vars[1], vars[2], vars[3], vars[4], LinearCombination(Scalar::from(values[0])));
+    else if (kind == K_DUMMY && m == 1) gadgets::dummy_circuit(verifier, vars[0], param);
+    else return -3;
+    R1CSProof pr = R1CSProof::from_flat_bytes(std::vector<uint8_t>(proof, proof + proof_len));
+    if (mega_out) memset(mega_out, 0xff, 64);
+    try {
+      verifier.verify(pr, bp_gens);
+    } catch (const R1CSException &e) {
+      if (mega_out) memcpy(mega_out, verifier.last_mega_check().xy.data(), 64);
+      return map_error(e);
+    }
+    if (mega_out) memcpy(mega_out, verifier.last_mega_check().xy.data(), 64);
+    return 0;
+  })
+}
+
+int bph_gens(int which, uint32_t party, size_t n, uint8_t *out) {
+  GUARD({
+    BulletproofGens g(n, party + 1);
+    auto pts = which == 'G' ? g.share(party).G(n) : g.share(party).H(n);
+    for (size_t i = 0; i < n; i++) memcpy(out + 64 * i, pts[i].xy.data(), 64);
+    return 0;
+  })
+}
+
+int bph_ipp_create(const uint8_t *label, size_t label_len, size_t n, const uint8_t Q[64], const uint8_t *Gf,
+                   const uint8_t *Hf, const uint8_t *G, const uint8_t *H, const uint8_t *a, const uint8_t *b,
+                   uint8_t *L_out, uint8_t *R_out, uint8_t a_out[32], uint8_t b_out[32]) {
+  GUARD({
+    auto sv = [&](const uint8_t *p) { std::vector<Scalar> v(n); for (size_t i = 0; i < n; i++) v[i] = Scalar::from_bytes_le(p + 32 * i); return v; };
+    auto pv = [&](const uint8_t *p) { std::vector<StarkPoint> v(n); for (size_t i = 0; i < n; i++) memcpy(v[i].xy.data(), p + 64 * i, 64); return v; };
+    Transcript t(std::string((const char *)label, label_len));
+    StarkPoint q;
+    memcpy(q.xy.data(), Q, 64);
+    InnerProductProof p = InnerProductProof::create(t, q, sv(Gf), sv(Hf), pv(G), pv(H), sv(a), sv(b));
+    for (size_t i = 0; i < p.L_vec.size(); i++) { memcpy(L_out + 64 * i, p.L_vec[i].xy.data(), 64); memcpy(R_out + 64 * i, p.R_vec[i].xy.data(), 64); }
+    p.a.to_bytes_le(a_out);
+    p.b.to_bytes_le(b_out);
+    return 0;
+  })
+}
+
+int bph_ipp_verify(const uint8_t *label, size_t label_len, size_t n, const uint8_t *Gf, const uint8_t *Hf,
+                   const uint8_t P[64], const uint8_t Q[64], const uint8_t *G, const uint8_t *H, const uint8_t *L,
+                   const uint8_t *R, size_t k, const uint8_t a[32], const uint8_t b[32]) {
+  GUARD({
+    auto sv = [&](const uint8_t *p, size_t c) { std::vector<Scalar> v(c); for (size_t i = 0; i < c; i++) v[i] = Scalar::from_bytes_le(p + 32 * i); return v; };
+    auto pv = [&](const uint8_t *p, size_t c) { std::vector<StarkPoint> v(c); for (size_t i = 0; i < c; i++) memcpy(v[i].xy.data(), p + 64 * i, 64); return v; };
+    InnerProductProof pr;
+    pr.L_vec = pv(L, k);
+    pr.R_vec = pv(R, k);
+    pr.a = Scalar::from_bytes_le(a);
+    pr.b = Scalar::from_bytes_le(b);
+    Transcript t(std::string((const char *)label, label_len));
+    StarkPoint pp, qq;
+    memcpy(pp.xy.data(), P, 64);
+    memcpy(qq.xy.data(), Q, 64);
+    pr.verify(n, t, sv(Gf, n), sv(Hf, n), pp, qq, pv(G, n), pv(H, n));
+    return 0;
+  })
+}
+
+#pragma GCC visibility pop
+}

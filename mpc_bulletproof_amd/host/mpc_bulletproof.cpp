@@ -1,0 +1,814 @@
+// mpc_bulletproof.cpp -- host-side orchestration of the reference's API over the bpgpu C ABI.
+// Citations are to renegade-fi/mpc-bulletproof (paths relative to its root).
+#include "mpc_bulletproof.hpp"
+
+#include <cstring>
+
+namespace mpc_bulletproof {
+
+typedef unsigned __int128 u128;
+
+// ================================================================ Scalar (host glue, F_n) =========
+namespace {
+const uint64_t NMOD[4] = {0x1e66a241adc64d2fULL, 0xb781126dcae7b232ULL, 0xffffffffffffffffULL, 0x0800000000000010ULL};
+const uint64_t N0INV = 0xbb6b3c4ce8bde631ULL;   // -n^-1 mod 2^64
+const uint64_t R2[4] = {0x6021b3f1ea1c688dULL, 0x509cf64d14ce60b9ULL, 0xbaf0ab4cf78bbabbULL, 0x07d9e57c2333766eULL};
+const uint64_t RONE[4] = {0x51925a0bf4fca74fULL, 0xc75ec4b46df16beeULL, 0x0000000000000008ULL, 0x07fffffffffffdf1ULL};
+
+bool geq_n(const uint64_t a[4]) {
+  for (int i = 3; i >= 0; i--) {
+    if (a[i] != NMOD[i]) return a[i] > NMOD[i];
+  }
+  return true;
+}
+void sub_n(uint64_t a[4]) {
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) {
+    u128 d = (u128)a[i] - NMOD[i] - (uint64_t)br;
+    a[i] = (uint64_t)d;
+    br = (d >> 64) & 1;
+  }
+}
+void mont_mul(uint64_t r[4], const uint64_t a[4], const uint64_t b[4]) {
+  uint64_t t[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 4; i++) {
+    u128 c = 0;
+    for (int j = 0; j < 4; j++) { c += (u128)a[j] * b[i] + t[j]; t[j] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[4] = (uint64_t)c; t[5] = (uint64_t)(c >> 64);
+    uint64_t m = t[0] * N0INV;
+    c = ((u128)m * NMOD[0] + t[0]) >> 64;
+    for (int j = 1; j < 4; j++) { c += (u128)m * NMOD[j] + t[j]; t[j - 1] = (uint64_t)c; c >>= 64; }
+    c += t[4]; t[3] = (uint64_t)c; t[4] = t[5] + (uint64_t)(c >> 64);
+  }
+  if (t[4] || geq_n(t)) sub_n(t);
+  memcpy(r, t, 32);
+}
+}  // namespace
+
+Scalar Scalar::one() { Scalar s; memcpy(s.v_, RONE, 32); return s; }
+Scalar Scalar::from(uint64_t x) { Scalar s; uint64_t t[4] = {x, 0, 0, 0}; mont_mul(s.v_, t, R2); return s; }
+Scalar Scalar::from_bytes_le(const uint8_t b[32]) {
+  uint64_t t[4];
+  for (int i = 0; i < 4; i++) { t[i] = 0; for (int j = 7; j >= 0; j--) t[i] = (t[i] << 8) | b[8 * i + j]; }
+  if (geq_n(t)) throw ProofException(ProofError::FormatError);
+  Scalar s;
+  mont_mul(s.v_, t, R2);
+  return s;
+}
+Scalar Scalar::from_le_bytes_mod_order_wide(const uint8_t b[64]) {
+  uint64_t lo[4], hi[4];
+  for (int h = 0; h < 2; h++)
+    for (int i = 0; i < 4; i++) {
+      uint64_t w = 0;
+      for (int j = 7; j >= 0; j--) w = (w << 8) | b[32 * h + 8 * i + j];
+      (h ? hi : lo)[i] = w;
+    }
+  while (geq_n(lo)) sub_n(lo);
+  while (geq_n(hi)) sub_n(hi);
+  Scalar l, h;
+  mont_mul(l.v_, lo, R2);
+  mont_mul(h.v_, hi, R2);
+  mont_mul(h.v_, h.v_, R2);   // hi * 2^256
+  return l + h;
+}
+void Scalar::to_bytes_le(uint8_t out[32]) const {
+  uint64_t one[4] = {1, 0, 0, 0}, t[4];
+  mont_mul(t, v_, one);
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(t[i] >> (8 * j));
+}
+Scalar Scalar::operator+(const Scalar &o) const {
+  Scalar r;
+  u128 c = 0;
+  for (int i = 0; i < 4; i++) { c += (u128)v_[i] + o.v_[i]; r.v_[i] = (uint64_t)c; c >>= 64; }
+  if (geq_n(r.v_)) sub_n(r.v_);
+  return r;
+}
+Scalar Scalar::operator-() const {
+  Scalar r;
+  if (*this == Scalar()) return r;
+  u128 br = 0;
+  for (int i = 0; i < 4; i++) { u128 d = (u128)NMOD[i] - v_[i] - (uint64_t)br; r.v_[i] = (uint64_t)d; br = (d >> 64) & 1; }
+  return r;
+}
+Scalar Scalar::operator-(const Scalar &o) const { return *this + (-o); }
+Scalar Scalar::operator*(const Scalar &o) const { Scalar r; mont_mul(r.v_, v_, o.v_); return r; }
+Scalar Scalar::inverse() const {
+  uint64_t e[4] = {NMOD[0] - 2, NMOD[1], NMOD[2], NMOD[3]};
+  Scalar acc = Scalar::one(), base = *this;
+  for (int i = 0; i < 256; i++) {
+    if ((e[i / 64] >> (i % 64)) & 1) acc = acc * base;
+    base = base * base;
+  }
+  return acc;
+}
+
+uint64_t Rng::next_u64() {
+  s_ += 0x9E3779B97F4A7C15ULL;
+  uint64_t z = s_;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  return z ^ (z >> 31);
+}
+Scalar Rng::scalar() {
+  uint8_t b[64] = {0};
+  for (int i = 0; i < 4; i++) { uint64_t w = next_u64(); for (int j = 0; j < 8; j++) b[8 * i + j] = (uint8_t)(w >> (8 * j)); }
+  return Scalar::from_le_bytes_mod_order_wide(b);
+}
+
+StarkPoint StarkPoint::generator() {
+  static const uint8_t GEN[64] = {0xca,0xcf,0x43,0xc9,0x8b,0x3d,0x72,0x3d,0xe0,0x19,0x18,0x0d,0x9b,0xfd,0xac,0xde,0xc7,0xf0,0x40,0x5a,0x41,0xed,0xec,0x7b,0x1b,0x97,0x99,0x85,0xc1,0x15,0xef,0x01,
+                                  0x1f,0xdc,0xe8,0x36,0x0c,0x00,0x73,0x28,0xa3,0x43,0xbe,0x1a,0xd1,0xec,0x53,0xde,0x62,0xec,0x46,0xdf,0x01,0x48,0xbe,0xb7,0x30,0x97,0xa4,0x0a,0x06,0x68,0x56,0x00};
+  StarkPoint p;
+  memcpy(p.xy.data(), GEN, 64);
+  return p;
+}
+
+// ================================================================ byte packing helpers ============
+namespace {
+std::vector<uint8_t> pack_scalars(const std::vector<Scalar> &v) {
+  std::vector<uint8_t> o(v.size() * 32);
+  for (size_t i = 0; i < v.size(); i++) v[i].to_bytes_le(&o[32 * i]);
+  return o;
+}
+std::vector<Scalar> unpack_scalars(const uint8_t *b, size_t n) {
+  std::vector<Scalar> o(n);
+  for (size_t i = 0; i < n; i++) o[i] = Scalar::from_bytes_le(b + 32 * i);
+  return o;
+}
+std::vector<uint8_t> pack_points(const std::vector<StarkPoint> &v) {
+  std::vector<uint8_t> o(v.size() * 64);
+  for (size_t i = 0; i < v.size(); i++) memcpy(&o[64 * i], v[i].xy.data(), 64);
+  return o;
+}
+std::vector<StarkPoint> unpack_points(const uint8_t *b, size_t n) {
+  std::vector<StarkPoint> o(n);
+  for (size_t i = 0; i < n; i++) memcpy(o[i].xy.data(), b + 64 * i, 64);
+  return o;
+}
+}  // namespace
+
+// ================================================================ Device ==========================
+Device::Device(int index) {
+  int rc = bpgpu_create(index, &ctx_);
+  if (rc) throw DeviceException(rc, std::string("bpgpu_create: ") + bpgpu_strerror(rc));
+}
+Device::~Device() { bpgpu_destroy(ctx_); }
+Device &Device::default_device() { static Device d(0); return d; }
+void Device::check(int rc, const char *what) const {
+  if (rc) throw DeviceException(rc, std::string(what) + ": " + bpgpu_strerror(rc) + " | " + bpgpu_last_error(ctx_));
+}
+StarkPoint Device::msm(const std::vector<Scalar> &scalars, const std::vector<StarkPoint> &points) const {
+  if (scalars.size() != points.size()) throw std::invalid_argument("msm: length mismatch");
+  StarkPoint out;
+  auto s = pack_scalars(scalars);
+  auto p = pack_points(points);
+  check(bpgpu_msm(ctx_, s.data(), p.data(), scalars.size(), out.xy.data()), "bpgpu_msm");
+  return out;
+}
+
+// ================================================================ keccak / transcript =============
+namespace {
+const uint64_t KRC[24] = {
+    0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+    0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+    0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+    0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+    0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+inline uint64_t rotl(uint64_t x, int n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+void permute(uint64_t A[5][5]) {   // A[x][y]
+  static const int ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};
+  for (int r = 0; r < 24; r++) {
+    uint64_t C[5], D[5], B[5][5];
+    for (int x = 0; x < 5; x++) C[x] = A[x][0] ^ A[x][1] ^ A[x][2] ^ A[x][3] ^ A[x][4];
+    for (int x = 0; x < 5; x++) D[x] = C[(x + 4) % 5] ^ rotl(C[(x + 1) % 5], 1);
+    for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) A[x][y] ^= D[x];
+    for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) B[y][(2 * x + 3 * y) % 5] = rotl(A[x][y], ROT[x][y]);
+    for (int x = 0; x < 5; x++) for (int y = 0; y < 5; y++) A[x][y] = B[x][y] ^ (~B[(x + 1) % 5][y] & B[(x + 2) % 5][y]);
+    A[0][0] ^= KRC[r];
+  }
+}
+std::vector<uint8_t> pad_label(const std::string &l) {   // merlin fork pad_label: source absent; see DESIGN.md
+  size_t k = (l.size() + 31) / 32 * 32;
+  if (k < 32) k = 32;
+  std::vector<uint8_t> o(k, 0);
+  memcpy(o.data(), l.data(), l.size());
+  return o;
+}
+}  // namespace
+void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {   // original Keccak padding 0x01
+  const size_t rate = 136;
+  std::vector<uint8_t> m(in, in + len);
+  m.push_back(0x01);
+  while (m.size() % rate) m.push_back(0);
+  m.back() |= 0x80;
+  uint64_t A[5][5];
+  memset(A, 0, sizeof A);
+  for (size_t off = 0; off < m.size(); off += rate) {
+    for (size_t i = 0; i < rate / 8; i++) {
+      uint64_t w = 0;
+      for (int j = 7; j >= 0; j--) w = (w << 8) | m[off + 8 * i + j];
+      A[i % 5][i / 5] ^= w;
+    }
+    permute(A);
+  }
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(A[i % 5][i / 5] >> (8 * j));
+}
+Scalar hash_to_scalar(const uint8_t low[32]) {
+  uint8_t buf[64];
+  memcpy(buf, low, 32);
+  keccak256(low, 32, buf + 32);
+  return Scalar::from_le_bytes_mod_order_wide(buf);
+}
+Transcript::Transcript(const std::string &label) {
+  auto a = pad_label("bp-hashchain-v0"), b = pad_label(label);
+  a.insert(a.end(), b.begin(), b.end());
+  keccak256(a.data(), a.size(), state_);
+}
+void Transcript::append_message(const std::string &label, const uint8_t *msg, size_t len) {
+  std::vector<uint8_t> buf(state_, state_ + 32);
+  buf.push_back(0x00);
+  auto l = pad_label(label);
+  buf.insert(buf.end(), l.begin(), l.end());
+  for (int j = 0; j < 8; j++) buf.push_back((uint8_t)((uint64_t)len >> (8 * j)));
+  buf.insert(buf.end(), msg, msg + len);
+  keccak256(buf.data(), buf.size(), state_);
+}
+void Transcript::append_u64(const std::string &label, uint64_t x) {
+  uint8_t b[8];
+  for (int j = 0; j < 8; j++) b[j] = (uint8_t)(x >> (8 * j));
+  append_message(label, b, 8);
+}
+void Transcript::challenge_bytes(const std::string &label, uint8_t out[32]) {
+  std::vector<uint8_t> buf(state_, state_ + 32);
+  buf.push_back(0x01);
+  auto l = pad_label(label);
+  buf.insert(buf.end(), l.begin(), l.end());
+  keccak256(buf.data(), buf.size(), state_);
+  memcpy(out, state_, 32);
+}
+static void dom_sep(Transcript &t, const std::string &s) { auto p = pad_label(s); t.append_message("dom-sep", p.data(), p.size()); }
+void Transcript::innerproduct_domain_sep(uint64_t n) { dom_sep(*this, "ipp v1"); append_u64("n", n); }   // transcript.rs:70-73
+void Transcript::r1cs_domain_sep() { dom_sep(*this, "r1cs v1"); }
+void Transcript::r1cs_1phase_domain_sep() { dom_sep(*this, "r1cs-1phase"); }
+void Transcript::r1cs_2phase_domain_sep() { dom_sep(*this, "r1cs-2phase"); }
+void Transcript::append_scalar(const std::string &label, const Scalar &s) { auto b = s.to_bytes(); append_message(label, b.data(), 32); }
+void Transcript::append_point(const std::string &label, const StarkPoint &p) { append_message(label, p.xy.data(), 64); }
+void Transcript::validate_and_append_point(const std::string &label, const StarkPoint &p) {
+  if (p.is_identity()) throw ProofException(ProofError::VerificationError);   // transcript.rs:101-113
+  append_point(label, p);
+}
+Scalar Transcript::challenge_scalar(const std::string &label) {
+  uint8_t b[32];
+  challenge_bytes(label, b);
+  return hash_to_scalar(b);
+}
+
+// ================================================================ generators ======================
+PedersenGens::PedersenGens() : B(StarkPoint::generator()), B_blinding(StarkPoint::generator()) {}
+StarkPoint PedersenGens::commit(const Scalar &value, const Scalar &blinding) const {
+  return Device::default_device().msm({value, blinding}, {B, B_blinding});
+}
+static std::vector<StarkPoint> generators_chain(char which, uint32_t party, size_t skip, size_t count) {
+  // GeneratorsChain::new + fast_forward + next, generators.rs:82-124
+  std::string lab = "GeneratorsChain";
+  lab.push_back(which);
+  for (int j = 0; j < 4; j++) lab.push_back((char)(party >> (8 * j)));
+  auto padded = pad_label(lab);
+  uint8_t state[32], nx[32];
+  keccak256(padded.data(), padded.size(), state);
+  for (size_t i = 0; i < skip; i++) { keccak256(state, 32, nx); memcpy(state, nx, 32); }
+  std::vector<uint8_t> sc(count * 32), out(count * 64);
+  for (size_t i = 0; i < count; i++) {
+    keccak256(state, 32, nx);
+    memcpy(state, nx, 32);
+    hash_to_scalar(state).to_bytes_le(&sc[32 * i]);
+  }
+  Device &d = Device::default_device();
+  d.check(bpgpu_generator_mul(d.ctx(), sc.data(), count, out.data()), "bpgpu_generator_mul");
+  return unpack_points(out.data(), count);
+}
+BulletproofGens::BulletproofGens(size_t cap, size_t parties) : party_capacity(parties), G_vec_(parties), H_vec_(parties) {
+  increase_capacity(cap);
+}
+BulletproofGens::~BulletproofGens() {
+  if (tables_) bpgpu_gens_destroy(Device::default_device().ctx(), tables_);
+}
+void BulletproofGens::increase_capacity(size_t new_capacity) {
+  if (gens_capacity >= new_capacity) return;
+  for (size_t i = 0; i < party_capacity; i++) {
+    auto g = generators_chain('G', (uint32_t)i, gens_capacity, new_capacity - gens_capacity);
+    auto h = generators_chain('H', (uint32_t)i, gens_capacity, new_capacity - gens_capacity);
+    G_vec_[i].insert(G_vec_[i].end(), g.begin(), g.end());
+    H_vec_[i].insert(H_vec_[i].end(), h.begin(), h.end());
+  }
+  gens_capacity = new_capacity;
+}
+std::vector<StarkPoint> BulletproofGens::Share::G(size_t n) const {
+  const auto &v = gens->G_vec_[share];
+  return std::vector<StarkPoint>(v.begin(), v.begin() + std::min(n, v.size()));
+}
+std::vector<StarkPoint> BulletproofGens::Share::H(size_t n) const {
+  const auto &v = gens->H_vec_[share];
+  return std::vector<StarkPoint>(v.begin(), v.begin() + std::min(n, v.size()));
+}
+bpgpu_gens *BulletproofGens::device_tables(const PedersenGens &pc, int window_bits) const {
+  std::array<uint8_t, 128> key;
+  memcpy(key.data(), pc.B.xy.data(), 64);
+  memcpy(key.data() + 64, pc.B_blinding.xy.data(), 64);
+  Device &d = Device::default_device();
+  if (tables_ && tables_cap_ == gens_capacity && tables_pc_ == key) return tables_;
+  if (tables_) { bpgpu_gens_destroy(d.ctx(), tables_); tables_ = nullptr; }
+  auto g = pack_points(G_vec_[0]), h = pack_points(H_vec_[0]);
+  d.check(bpgpu_gens_create(d.ctx(), g.data(), h.data(), gens_capacity, pc.B.xy.data(), pc.B_blinding.xy.data(), window_bits, &tables_),
+          "bpgpu_gens_create");
+  tables_cap_ = gens_capacity;
+  tables_pc_ = key;
+  return tables_;
+}
+
+// ================================================================ util / inner product =============
+namespace util {
+std::vector<Scalar> exp_iter(const Scalar &x, size_t n) {
+  std::vector<Scalar> o(n);
+  Scalar cur = Scalar::one();
+  for (size_t i = 0; i < n; i++) { o[i] = cur; cur *= x; }
+  return o;
+}
+Scalar sum_of_powers_slow(const Scalar &x, size_t n) {
+  Scalar acc, cur = Scalar::one();
+  for (size_t i = 0; i < n; i++) { acc += cur; cur *= x; }
+  return acc;
+}
+Scalar sum_of_powers(const Scalar &x, size_t n) {
+  if (n & (n - 1)) return sum_of_powers_slow(x, n);
+  if (n == 0 || n == 1) return Scalar::from(n);
+  size_t m = n;
+  Scalar result = Scalar::one() + x, factor = x;
+  while (m > 2) { factor = factor * factor; result = result + factor * result; m /= 2; }
+  return result;
+}
+}  // namespace util
+
+Scalar inner_product(const std::vector<Scalar> &a, const std::vector<Scalar> &b) {
+  if (a.size() != b.size()) throw std::invalid_argument("inner_product(a,b): lengths of vectors do not match");
+  Device &d = Device::default_device();
+  auto pa = pack_scalars(a), pb = pack_scalars(b);
+  uint8_t out[32];
+  d.check(bpgpu_inner_product(d.ctx(), pa.data(), pb.data(), a.size(), out), "bpgpu_inner_product");
+  return Scalar::from_bytes_le(out);
+}
+
+InnerProductProof InnerProductProof::create(Transcript &transcript, const StarkPoint &Q, const std::vector<Scalar> &G_factors,
+                                            const std::vector<Scalar> &H_factors, std::vector<StarkPoint> G_vec,
+                                            std::vector<StarkPoint> H_vec, std::vector<Scalar> a_vec, std::vector<Scalar> b_vec) {
+  size_t n = G_vec.size();
+  if (H_vec.size() != n || a_vec.size() != n || b_vec.size() != n || G_factors.size() != n || H_factors.size() != n)
+    throw std::invalid_argument("InnerProductProof::create: length mismatch");          // asserts :62-67
+  if (!n || (n & (n - 1))) throw std::invalid_argument("InnerProductProof::create: n must be a power of two");   // :70
+  transcript.innerproduct_domain_sep(n);                                                  // :72
+  Device &d = Device::default_device();
+  InnerProductProof proof;
+  bpgpu_ipp *s = nullptr;
+  auto pG = pack_points(G_vec), pH = pack_points(H_vec);
+  auto pa = pack_scalars(a_vec), pb = pack_scalars(b_vec), pgf = pack_scalars(G_factors), phf = pack_scalars(H_factors);
+  d.check(bpgpu_ipp_begin(d.ctx(), 1, n, Q.xy.data(), pgf.data(), phf.data(), pG.data(), pH.data(), 1, pa.data(), pb.data(), &s),
+          "bpgpu_ipp_begin");
+  try {
+    while (bpgpu_ipp_len(s) > 1) {
+      StarkPoint L, R;
+      d.check(bpgpu_ipp_round(d.ctx(), s, L.xy.data(), R.xy.data()), "bpgpu_ipp_round");
+      proof.L_vec.push_back(L);
+      proof.R_vec.push_back(R);
+      transcript.append_point("L", L);                                                    // :119-123 / :177-181
+      transcript.append_point("R", R);
+      Scalar u = transcript.challenge_scalar("u"), u_inv = u.inverse();
+      auto bu = u.to_bytes(), bi = u_inv.to_bytes();
+      d.check(bpgpu_ipp_fold(d.ctx(), s, bu.data(), bi.data()), "bpgpu_ipp_fold");
+    }
+    uint8_t a[32], b[32];
+    d.check(bpgpu_ipp_finish(d.ctx(), s, a, b), "bpgpu_ipp_finish");
+    proof.a = Scalar::from_bytes_le(a);
+    proof.b = Scalar::from_bytes_le(b);
+  } catch (...) {
+    bpgpu_ipp_destroy(d.ctx(), s);
+    throw;
+  }
+  bpgpu_ipp_destroy(d.ctx(), s);
+  return proof;
+}
+
+InnerProductProof::VerificationScalars InnerProductProof::verification_scalars(size_t n, Transcript &transcript,
+                                                                               std::vector<Scalar> *challenges_out) const {
+  size_t lg_n = L_vec.size();
+  if (lg_n >= 32) throw ProofException(ProofError::VerificationError);                    // :259-264
+  if (n != ((size_t)1 << lg_n)) throw ProofException(ProofError::VerificationError);      // :265-267
+  transcript.innerproduct_domain_sep(n);
+  std::vector<Scalar> ch;
+  for (size_t i = 0; i < lg_n; i++) {                                                     // :273-278
+    transcript.validate_and_append_point("L", L_vec[i]);
+    transcript.validate_and_append_point("R", R_vec.at(i));
+    ch.push_back(transcript.challenge_scalar("u"));
+  }
+  if (challenges_out) *challenges_out = ch;
+  Device &d = Device::default_device();
+  auto pc = pack_scalars(ch);
+  std::vector<uint8_t> us(lg_n * 32 + 1), uis(lg_n * 32 + 1), s(n * 32);
+  d.check(bpgpu_verification_scalars(d.ctx(), pc.data(), lg_n, n, us.data(), uis.data(), s.data()), "bpgpu_verification_scalars");
+  VerificationScalars v;
+  v.u_sq = unpack_scalars(us.data(), lg_n);
+  v.u_inv_sq = unpack_scalars(uis.data(), lg_n);
+  v.s = unpack_scalars(s.data(), n);
+  return v;
+}
+
+void InnerProductProof::verify(size_t n, Transcript &transcript, const std::vector<Scalar> &G_factors,
+                               const std::vector<Scalar> &H_factors, const StarkPoint &P, const StarkPoint &Q,
+                               const std::vector<StarkPoint> &G, const std::vector<StarkPoint> &H) const {
+  auto v = verification_scalars(n, transcript);
+  std::vector<Scalar> sc;
+  std::vector<StarkPoint> pts;
+  sc.push_back(a * b);
+  pts.push_back(Q);
+  for (size_t i = 0; i < n && i < G.size(); i++) { sc.push_back((a * v.s[i]) * G_factors.at(i)); pts.push_back(G[i]); }   // :336-340
+  for (size_t i = 0; i < n && i < H.size(); i++) { sc.push_back((b * v.s[n - 1 - i]) * H_factors.at(i)); pts.push_back(H[i]); }   // :343-348
+  for (size_t i = 0; i < L_vec.size(); i++) { sc.push_back(-v.u_sq[i]); pts.push_back(L_vec[i]); }
+  for (size_t i = 0; i < R_vec.size(); i++) { sc.push_back(-v.u_inv_sq[i]); pts.push_back(R_vec[i]); }
+  StarkPoint expect_P = Device::default_device().msm(sc, pts);
+  if (expect_P != P) throw ProofException(ProofError::VerificationError);
+}
+
+// ================================================================ r1cs ============================
+namespace r1cs {
+
+void LinearCombination::add_term(const Variable &v, const Scalar &c) {
+  auto it = terms.find(v);
+  if (it == terms.end()) terms[v] = c; else it->second = it->second + c;
+}
+LinearCombination LinearCombination::operator+(const LinearCombination &o) const {
+  LinearCombination r = *this;
+  for (auto &kv : o.terms) r.add_term(kv.first, kv.second);
+  return r;
+}
+LinearCombination LinearCombination::operator-() const {
+  LinearCombination r;
+  for (auto &kv : terms) r.terms[kv.first] = -kv.second;
+  return r;
+}
+LinearCombination LinearCombination::operator-(const LinearCombination &o) const { return *this + (-o); }
+LinearCombination LinearCombination::operator*(const Scalar &s) const {
+  LinearCombination r;
+  for (auto &kv : terms) r.terms[kv.first] = kv.second * s;
+  return r;
+}
+
+std::vector<uint8_t> R1CSProof::to_flat_bytes() const {
+  size_t k = ipp_proof.L_vec.size();
+  std::vector<uint8_t> o(8 + 11 * 64 + 96 + 128 * k + 64, 0);
+  for (int j = 0; j < 4; j++) o[j] = (uint8_t)(k >> (8 * j));
+  uint8_t *p = o.data() + 8;
+  const StarkPoint *pts[11] = {&A_I1, &A_O1, &S1, &A_I2, &A_O2, &S2, &T_1, &T_3, &T_4, &T_5, &T_6};
+  for (auto *q : pts) { memcpy(p, q->xy.data(), 64); p += 64; }
+  t_x.to_bytes_le(p); t_x_blinding.to_bytes_le(p + 32); e_blinding.to_bytes_le(p + 64); p += 96;
+  for (auto &q : ipp_proof.L_vec) { memcpy(p, q.xy.data(), 64); p += 64; }
+  for (auto &q : ipp_proof.R_vec) { memcpy(p, q.xy.data(), 64); p += 64; }
+  ipp_proof.a.to_bytes_le(p); ipp_proof.b.to_bytes_le(p + 32);
+  return o;
+}
+R1CSProof R1CSProof::from_flat_bytes(const std::vector<uint8_t> &b) {
+  if (b.size() < 8) throw R1CSException(R1CSError::FormatError);
+  size_t k = b[0] | (b[1] << 8) | (b[2] << 16) | ((size_t)b[3] << 24);
+  if (k >= 32 || b.size() != 8 + 11 * 64 + 96 + 128 * k + 64) throw R1CSException(R1CSError::FormatError);
+  R1CSProof pr;
+  const uint8_t *p = b.data() + 8;
+  StarkPoint *pts[11] = {&pr.A_I1, &pr.A_O1, &pr.S1, &pr.A_I2, &pr.A_O2, &pr.S2, &pr.T_1, &pr.T_3, &pr.T_4, &pr.T_5, &pr.T_6};
+  for (auto *q : pts) { memcpy(q->xy.data(), p, 64); p += 64; }
+  try {
+    pr.t_x = Scalar::from_bytes_le(p); pr.t_x_blinding = Scalar::from_bytes_le(p + 32); pr.e_blinding = Scalar::from_bytes_le(p + 64);
+    p += 96;
+    pr.ipp_proof.L_vec = unpack_points(p, k); p += 64 * k;
+    pr.ipp_proof.R_vec = unpack_points(p, k); p += 64 * k;
+    pr.ipp_proof.a = Scalar::from_bytes_le(p); pr.ipp_proof.b = Scalar::from_bytes_le(p + 32);
+  } catch (const ProofException &) { throw R1CSException(R1CSError::FormatError); }
+  return pr;
+}
+
+// ---- shared constraint-system core ---------------------------------------------------------------
+class CsCore {
+ public:
+  CsCore(bool prover, const PedersenGens &pc, Transcript &t, RandomizedConstraintSystem *self)
+      : is_prover(prover), pc_gens(pc), tr(t), self_(self) { tr.r1cs_domain_sep(); }
+  bool is_prover;
+  PedersenGens pc_gens;
+  Transcript &tr;
+  RandomizedConstraintSystem *self_;
+  std::vector<LinearCombination> constraints;
+  std::vector<Scalar> a_L, a_R, a_O, v, v_blinding;    // prover
+  std::vector<StarkPoint> V;                            // both (prover keeps them for convenience)
+  size_t num_vars = 0;                                  // verifier
+  std::vector<ConstraintSystem::Callback> deferred;
+  long pending_multiplier = -1;
+  StarkPoint mega;
+
+  size_t multipliers() const { return is_prover ? a_L.size() : num_vars; }
+  Scalar eval(const LinearCombination &lc) const {      // prover.rs:179-194 / verifier.rs:168-174
+    Scalar acc;
+    if (!is_prover) return acc;
+    for (auto &kv : lc.terms) {
+      Scalar val;
+      switch (kv.first.kind) {
+        case Variable::MultiplierLeft: val = a_L.at(kv.first.index); break;
+        case Variable::MultiplierRight: val = a_R.at(kv.first.index); break;
+        case Variable::MultiplierOutput: val = a_O.at(kv.first.index); break;
+        case Variable::Committed: val = v.at(kv.first.index); break;
+        case Variable::One: val = Scalar::one(); break;
+        default: break;
+      }
+      acc += kv.second * val;
+    }
+    return acc;
+  }
+  std::array<Variable, 3> new_multiplier(const Scalar &l, const Scalar &r) {
+    size_t i;
+    if (is_prover) { i = a_L.size(); a_L.push_back(l); a_R.push_back(r); a_O.push_back(l * r); }
+    else i = num_vars++;
+    return {Variable{Variable::MultiplierLeft, i}, Variable{Variable::MultiplierRight, i}, Variable{Variable::MultiplierOutput, i}};
+  }
+  std::array<Variable, 3> multiply(LinearCombination left, LinearCombination right) {   // prover.rs:99-125 / verifier.rs:99-120
+    auto vars = new_multiplier(eval(left), eval(right));
+    left.add_term(vars[0], -Scalar::one());
+    right.add_term(vars[1], -Scalar::one());
+    constraints.push_back(std::move(left));
+    constraints.push_back(std::move(right));
+    return vars;
+  }
+  Variable allocate(const Scalar *assignment) {                                         // prover.rs:127-146 / verifier.rs:122-135
+    if (is_prover && !assignment) throw R1CSException(R1CSError::MissingAssignment);
+    if (pending_multiplier < 0) {
+      size_t i = multipliers();
+      pending_multiplier = (long)i;
+      if (is_prover) { a_L.push_back(*assignment); a_R.push_back(Scalar()); a_O.push_back(Scalar()); }
+      else num_vars++;
+      return Variable{Variable::MultiplierLeft, i};
+    }
+    size_t i = (size_t)pending_multiplier;
+    pending_multiplier = -1;
+    if (is_prover) { a_R[i] = *assignment; a_O[i] = a_L[i] * a_R[i]; }
+    return Variable{Variable::MultiplierRight, i};
+  }
+  void create_randomized_constraints() {                                                // prover.rs:383-402 / verifier.rs:366-385
+    pending_multiplier = -1;
+    if (deferred.empty()) { tr.r1cs_1phase_domain_sep(); return; }
+    tr.r1cs_2phase_domain_sep();
+    auto cbs = std::move(deferred);
+    deferred.clear();
+    for (auto &cb : cbs) cb(*self_);
+  }
+  // constraint rows -> CSR arrays of the C ABI (the reference's Vec<LinearCombination>)
+  bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
+    std::vector<uint32_t> rp{0}, kind, idx;
+    std::vector<uint8_t> coeff;
+    for (auto &lc : constraints) {
+      for (auto &kv : lc.terms) {
+        if (kv.first.kind == Variable::Zero) continue;
+        kind.push_back(kv.first.kind);
+        idx.push_back((uint32_t)kv.first.index);
+        auto b = kv.second.to_bytes();
+        coeff.insert(coeff.end(), b.begin(), b.end());
+      }
+      rp.push_back((uint32_t)kind.size());
+    }
+    Device &d = Device::default_device();
+    bpgpu_circuit *c = nullptr;
+    uint32_t z32 = 0; uint8_t z8 = 0;
+    d.check(bpgpu_circuit_create(d.ctx(), constraints.size(), rp.data(), kind.empty() ? &z32 : kind.data(),
+                                 idx.empty() ? &z32 : idx.data(), coeff.empty() ? &z8 : coeff.data(), n_mul, m, &c),
+            "bpgpu_circuit_create");
+    return c;
+  }
+};
+
+static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
+
+// ---- Prover ----------------------------------------------------------------------------------------
+Prover::Prover(const PedersenGens &pc, Transcript &t) : c_(new CsCore(true, pc, t, this)) {}
+Prover::~Prover() {}
+Transcript &Prover::transcript() { return c_->tr; }
+size_t Prover::num_constraints() const { return c_->constraints.size(); }
+size_t Prover::num_multipliers() const { return c_->a_O.size(); }
+std::array<Variable, 3> Prover::multiply(LinearCombination l, LinearCombination r) { return c_->multiply(std::move(l), std::move(r)); }
+Variable Prover::allocate(const Scalar *a) { return c_->allocate(a); }
+std::array<Variable, 3> Prover::allocate_multiplier(const std::pair<Scalar, Scalar> *in) {
+  if (!in) throw R1CSException(R1CSError::MissingAssignment);                           // prover.rs:152
+  return c_->new_multiplier(in->first, in->second);
+}
+Variable Prover::commit_public(const Scalar &v) { return commit(v, Scalar::one()).second; }   // prover.rs:171-173
+void Prover::constrain(LinearCombination lc) { c_->constraints.push_back(std::move(lc)); }
+Scalar Prover::eval(const LinearCombination &lc) const { return c_->eval(lc); }
+void Prover::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
+Scalar Prover::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }
+bool Prover::constraints_satisfied() const {
+  for (auto &lc : c_->constraints) if (c_->eval(lc) != Scalar::zero()) return false;
+  return true;
+}
+std::pair<StarkPoint, Variable> Prover::commit(const Scalar &v, const Scalar &v_blinding) {
+  size_t i = c_->v.size();
+  c_->v.push_back(v);
+  c_->v_blinding.push_back(v_blinding);
+  StarkPoint V = c_->pc_gens.commit(v, v_blinding);
+  c_->V.push_back(V);
+  c_->tr.append_point("V", V);
+  return {V, Variable{Variable::Committed, i}};
+}
+
+R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {
+  CsCore &c = *c_;
+  Transcript &tr = c.tr;
+  Device &d = Device::default_device();
+  tr.append_u64("m", c.v.size());                                                       // prover.rs:420
+  size_t n1 = c.a_L.size();
+  if (bp_gens.gens_capacity < n1) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :450-452
+  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+  Scalar i_b1 = rng.scalar(), o_b1 = rng.scalar(), s_b1 = rng.scalar();                 // :457-462
+  std::vector<Scalar> s_L(n1), s_R(n1);
+  for (auto &x : s_L) x = rng.scalar();
+  for (auto &x : s_R) x = rng.scalar();
+  // three commitments over [B, B_blinding, G_0.., H_0..] -- :465-494
+  auto commit3 = [&](size_t lo, size_t hi, const Scalar &ib, const Scalar &ob, const Scalar &sb, StarkPoint out[3]) {
+    size_t n = hi;   // scalars below `lo` are zero (phase-2 commitments use G[n1..n), H[n1..n))
+    std::vector<Scalar> vec(3 * (2 + 2 * n));
+    auto at = [&](size_t which, size_t j) -> Scalar & { return vec[which * (2 + 2 * n) + j]; };
+    at(0, 1) = ib; at(1, 1) = ob; at(2, 1) = sb;
+    for (size_t i = lo; i < hi; i++) {
+      at(0, 2 + i) = c.a_L[i]; at(0, 2 + n + i) = c.a_R[i];
+      at(1, 2 + i) = c.a_O[i];
+      at(2, 2 + i) = s_L[i]; at(2, 2 + n + i) = s_R[i];
+    }
+    auto bytes = pack_scalars(vec);
+    uint8_t o[3 * 64];
+    d.check(bpgpu_msm_gens(d.ctx(), gens, 3, n, bytes.data(), o), "bpgpu_msm_gens");
+    for (int k = 0; k < 3; k++) memcpy(out[k].xy.data(), o + 64 * k, 64);
+  };
+  R1CSProof proof;
+  StarkPoint c1[3];
+  commit3(0, n1, i_b1, o_b1, s_b1, c1);
+  proof.A_I1 = c1[0]; proof.A_O1 = c1[1]; proof.S1 = c1[2];
+  tr.append_point("A_I1", proof.A_I1);
+  tr.append_point("A_O1", proof.A_O1);
+  tr.append_point("S1", proof.S1);
+  c.create_randomized_constraints();                                                    // :501
+  size_t n = c.a_L.size(), n2 = n - n1, padded_n = next_pow2(n), pad = padded_n - n;
+  if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :511-513
+  Scalar i_b2, o_b2, s_b2;
+  if (n2 > 0) { i_b2 = rng.scalar(); o_b2 = rng.scalar(); s_b2 = rng.scalar(); }        // :519-527
+  s_L.resize(n); s_R.resize(n);
+  for (size_t i = n1; i < n; i++) s_L[i] = rng.scalar();
+  for (size_t i = n1; i < n; i++) s_R[i] = rng.scalar();
+  if (n2 > 0) {                                                                         // :532-565
+    StarkPoint c2[3];
+    commit3(n1, n, i_b2, o_b2, s_b2, c2);
+    proof.A_I2 = c2[0]; proof.A_O2 = c2[1]; proof.S2 = c2[2];
+  }                                                                                     // else identity, :566-576
+  tr.append_point("A_I2", proof.A_I2);
+  tr.append_point("A_O2", proof.A_O2);
+  tr.append_point("S2", proof.S2);
+  Scalar y = tr.challenge_scalar("y"), z = tr.challenge_scalar("z");                    // :584-585
+  Scalar y_inv = y.inverse();
+  // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619
+  size_t m = c.v.size();
+  bpgpu_circuit *circ = c.upload_circuit(n, m);
+  bpgpu_prover *ps = nullptr;
+  std::vector<uint8_t> tco(6 * 32), wVb(m * 32 + 1);
+  auto by = y.to_bytes(), byi = y_inv.to_bytes(), bz = z.to_bytes();
+  auto paL = pack_scalars(c.a_L), paR = pack_scalars(c.a_R), paO = pack_scalars(c.a_O), psL = pack_scalars(s_L), psR = pack_scalars(s_R);
+  uint8_t dummy = 0;
+  int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, 1, by.data(), byi.data(), bz.data(), n ? paL.data() : &dummy, n ? paR.data() : &dummy,
+                                   n ? paO.data() : &dummy, n ? psL.data() : &dummy, n ? psR.data() : &dummy, tco.data(), wVb.data(), &ps);
+  if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
+  auto t = unpack_scalars(tco.data(), 6);   // t1 t2 t3 t4 t5 t6
+  auto wV = unpack_scalars(wVb.data(), m);
+  Scalar tb1 = rng.scalar(), tb3 = rng.scalar(), tb4 = rng.scalar(), tb5 = rng.scalar(), tb6 = rng.scalar();   // :621-625
+  proof.T_1 = c.pc_gens.commit(t[0], tb1);                                              // :627-631
+  proof.T_3 = c.pc_gens.commit(t[2], tb3);
+  proof.T_4 = c.pc_gens.commit(t[3], tb4);
+  proof.T_5 = c.pc_gens.commit(t[4], tb5);
+  proof.T_6 = c.pc_gens.commit(t[5], tb6);
+  tr.append_point("T_1", proof.T_1);
+  tr.append_point("T_3", proof.T_3);
+  tr.append_point("T_4", proof.T_4);
+  tr.append_point("T_5", proof.T_5);
+  tr.append_point("T_6", proof.T_6);
+  Scalar u = tr.challenge_scalar("u"), x = tr.challenge_scalar("x");                    // :639-640
+  Scalar tb2;
+  for (size_t i = 0; i < m; i++) tb2 += wV[i] * c.v_blinding[i];                        // :644-648
+  auto poly6 = [&](const Scalar &c1_, const Scalar &c2_, const Scalar &c3_, const Scalar &c4_, const Scalar &c5_, const Scalar &c6_) {
+    return x * (c1_ + x * (c2_ + x * (c3_ + x * (c4_ + x * (c5_ + x * c6_)))));         // util.rs:192-194
+  };
+  proof.t_x = poly6(t[0], t[1], t[2], t[3], t[4], t[5]);                                // :659-660
+  proof.t_x_blinding = poly6(tb1, tb2, tb3, tb4, tb5, tb6);
+  std::vector<uint8_t> lv(padded_n * 32), rv(padded_n * 32);
+  auto bx = x.to_bytes();
+  rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
+  bpgpu_prover_destroy(d.ctx(), ps);
+  bpgpu_circuit_destroy(d.ctx(), circ);
+  d.check(rc, "bpgpu_r1cs_prover_eval");
+  Scalar i_b = i_b1 + u * i_b2, o_b = o_b1 + u * o_b2, s_b = s_b1 + u * s_b2;           // :674-676
+  proof.e_blinding = x * (i_b + x * (o_b + x * s_b));                                   // :678
+  tr.append_scalar("t_x", proof.t_x);
+  tr.append_scalar("t_x_blinding", proof.t_x_blinding);
+  tr.append_scalar("e_blinding", proof.e_blinding);
+  Scalar w = tr.challenge_scalar("w");                                                  // :686
+  StarkPoint Q = d.msm({w}, {c.pc_gens.B});                                             // :687
+  std::vector<Scalar> Gf(padded_n), Hf(padded_n);                                       // :689-697
+  auto exp_y_inv = util::exp_iter(y_inv, padded_n);
+  for (size_t i = 0; i < padded_n; i++) { Gf[i] = i < n1 ? Scalar::one() : u; Hf[i] = exp_y_inv[i] * Gf[i]; }
+  proof.ipp_proof = InnerProductProof::create(tr, Q, Gf, Hf, bp_gens.share(0).G(padded_n), bp_gens.share(0).H(padded_n),
+                                              unpack_scalars(lv.data(), padded_n), unpack_scalars(rv.data(), padded_n));   // :699-708
+  (void)pad;
+  return proof;
+}
+
+// ---- Verifier --------------------------------------------------------------------------------------
+Verifier::Verifier(const PedersenGens &pc, Transcript &t) : c_(new CsCore(false, pc, t, this)) {}
+Verifier::~Verifier() {}
+Transcript &Verifier::transcript() { return c_->tr; }
+size_t Verifier::num_constraints() const { return c_->constraints.size(); }
+size_t Verifier::num_multipliers() const { return c_->num_vars; }
+std::array<Variable, 3> Verifier::multiply(LinearCombination l, LinearCombination r) { return c_->multiply(std::move(l), std::move(r)); }
+Variable Verifier::allocate(const Scalar *a) { return c_->allocate(a); }
+std::array<Variable, 3> Verifier::allocate_multiplier(const std::pair<Scalar, Scalar> *) { return c_->new_multiplier(Scalar(), Scalar()); }
+Variable Verifier::commit_public(const Scalar &v) { return commit(c_->pc_gens.commit(v, Scalar::one())); }   // verifier.rs:153-160
+void Verifier::constrain(LinearCombination lc) { c_->constraints.push_back(std::move(lc)); }
+Scalar Verifier::eval(const LinearCombination &) const { return Scalar::zero(); }
+void Verifier::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
+Scalar Verifier::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }
+StarkPoint Verifier::last_mega_check() const { return c_->mega; }
+Variable Verifier::commit(const StarkPoint &V) {
+  size_t i = c_->V.size();
+  c_->V.push_back(V);
+  c_->tr.append_point("V", V);
+  return Variable{Variable::Committed, i};
+}
+
+void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
+  CsCore &c = *c_;
+  Transcript &tr = c.tr;
+  try {
+    tr.append_u64("m", c.V.size());                                                     // verifier.rs:398
+    size_t n1 = c.num_vars;
+    tr.validate_and_append_point("A_I1", proof.A_I1);                                   // :401-406
+    tr.validate_and_append_point("A_O1", proof.A_O1);
+    tr.validate_and_append_point("S1", proof.S1);
+    c.create_randomized_constraints();                                                  // :409
+    size_t n = c.num_vars, padded_n = next_pow2(n), m = c.V.size();
+    if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :421-423
+    tr.append_point("A_I2", proof.A_I2);                                                // :428-430
+    tr.append_point("A_O2", proof.A_O2);
+    tr.append_point("S2", proof.S2);
+    Scalar y = tr.challenge_scalar("y"), z = tr.challenge_scalar("z");
+    tr.validate_and_append_point("T_1", proof.T_1);                                     // :435-444
+    tr.validate_and_append_point("T_3", proof.T_3);
+    tr.validate_and_append_point("T_4", proof.T_4);
+    tr.validate_and_append_point("T_5", proof.T_5);
+    tr.validate_and_append_point("T_6", proof.T_6);
+    Scalar u = tr.challenge_scalar("u"), x = tr.challenge_scalar("x");
+    tr.append_scalar("t_x", proof.t_x);                                                 // :449-453
+    tr.append_scalar("t_x_blinding", proof.t_x_blinding);
+    tr.append_scalar("e_blinding", proof.e_blinding);
+    Scalar w = tr.challenge_scalar("w");
+    // transcript half of verification_scalars (inner_product_proof.rs:259-278)
+    size_t k = proof.ipp_proof.L_vec.size();
+    if (k >= 32 || padded_n != ((size_t)1 << k) || proof.ipp_proof.R_vec.size() != k) throw ProofException(ProofError::VerificationError);
+    tr.innerproduct_domain_sep(padded_n);
+    std::vector<Scalar> ch{y, z, u, x, w, Scalar()};
+    for (size_t i = 0; i < k; i++) {
+      tr.validate_and_append_point("L", proof.ipp_proof.L_vec[i]);
+      tr.validate_and_append_point("R", proof.ipp_proof.R_vec[i]);
+      ch.push_back(tr.challenge_scalar("u"));
+    }
+    ch[5] = tr.challenge_scalar("r");                                                   // :506
+    // device: flatten, inversions, scalar assembly, mega_check MSM, identity test -- :457-553
+    Device &d = Device::default_device();
+    bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+    bpgpu_circuit *circ = c.upload_circuit(n, m);
+    std::vector<StarkPoint> pts{proof.A_I1, proof.A_O1, proof.S1, proof.A_I2, proof.A_O2, proof.S2};
+    pts.insert(pts.end(), c.V.begin(), c.V.end());
+    for (auto *q : {&proof.T_1, &proof.T_3, &proof.T_4, &proof.T_5, &proof.T_6}) pts.push_back(*q);
+    pts.insert(pts.end(), proof.ipp_proof.L_vec.begin(), proof.ipp_proof.L_vec.end());
+    pts.insert(pts.end(), proof.ipp_proof.R_vec.begin(), proof.ipp_proof.R_vec.end());
+    auto bp = pack_points(pts);
+    auto bs = pack_scalars({proof.t_x, proof.t_x_blinding, proof.e_blinding, proof.ipp_proof.a, proof.ipp_proof.b});
+    auto bc = pack_scalars(ch);
+    int32_t ok = 0;
+    int rc = bpgpu_r1cs_verify_batch(d.ctx(), gens, circ, 1, n1, k, bp.data(), bs.data(), bc.data(), &ok, c.mega.xy.data(), nullptr);
+    bpgpu_circuit_destroy(d.ctx(), circ);
+    if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+    if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+    d.check(rc, "bpgpu_r1cs_verify_batch");
+    if (!ok) throw R1CSException(R1CSError::VerificationError);                         // :549-551
+  } catch (const ProofException &) {
+    throw R1CSException(R1CSError::VerificationError);                                  // From<ProofError>, errors.rs:179-189
+  }
+}
+
+}  // namespace r1cs
+}  // namespace mpc_bulletproof

@@ -1,0 +1,267 @@
+// mpc_bulletproof.hpp -- host-side mirror of the reference crate's API for the accelerated path
+// (renegade-fi/mpc-bulletproof src/lib.rs:30-49): Transcript, PedersenGens, BulletproofGens,
+// InnerProductProof, inner_product, r1cs::{Prover, Verifier, R1CSProof, Variable, LinearCombination}.
+// Same names, argument meaning and error behaviour; every group / vector operation goes through the
+// C ABI of include/bpgpu.h to the MI355X (there is no CPU arithmetic path for points here).
+// The Rust toolchain is absent from the build image, so this mirror is C++ (the reference is
+// compiled code); INTEGRATION.md shows the Rust-side binding of the same C ABI.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+
+namespace mpc_bulletproof {
+
+// ---- errors (src/errors.rs:13-55,150-177) -------------------------------------------------------
+enum class ProofError { VerificationError, FormatError, WrongNumBlindingFactors, InvalidBitsize, InvalidAggregation,
+                        InvalidGeneratorsLength };
+enum class R1CSError { InvalidGeneratorsLength, FormatError, VerificationError, MissingAssignment, GadgetError };
+struct ProofException : std::runtime_error { ProofError e; explicit ProofException(ProofError e_) : std::runtime_error("ProofError"), e(e_) {} };
+struct R1CSException : std::runtime_error { R1CSError e; explicit R1CSException(R1CSError e_) : std::runtime_error("R1CSError"), e(e_) {} };
+struct DeviceException : std::runtime_error { int code; DeviceException(int c, const std::string &w) : std::runtime_error(w), code(c) {} };
+
+// ---- Scalar: host glue arithmetic in F_n (mpc_stark::algebra::scalar::Scalar) -------------------
+// Only what the host-side orchestration needs (transcript reduction, witness synthesis in
+// ConstraintSystem::multiply, Poly6::eval, blinding combinations).  Vector work is on the device.
+class Scalar {
+ public:
+  Scalar() : v_{0, 0, 0, 0} {}
+  static Scalar zero() { return Scalar(); }
+  static Scalar one();
+  static Scalar from(uint64_t x);
+  static Scalar from_bytes_le(const uint8_t b[32]);        // canonical; throws ProofException(FormatError)
+  static Scalar from_le_bytes_mod_order_wide(const uint8_t b[64]);
+  void to_bytes_le(uint8_t out[32]) const;
+  std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; to_bytes_le(o.data()); return o; }
+  Scalar operator+(const Scalar &o) const;
+  Scalar operator-(const Scalar &o) const;
+  Scalar operator*(const Scalar &o) const;
+  Scalar operator-() const;
+  Scalar &operator+=(const Scalar &o) { return *this = *this + o; }
+  Scalar &operator-=(const Scalar &o) { return *this = *this - o; }
+  Scalar &operator*=(const Scalar &o) { return *this = *this * o; }
+  bool operator==(const Scalar &o) const { return v_[0] == o.v_[0] && v_[1] == o.v_[1] && v_[2] == o.v_[2] && v_[3] == o.v_[3]; }
+  bool operator!=(const Scalar &o) const { return !(*this == o); }
+  Scalar inverse() const;     // Fermat on the host (single values; batches go to bpgpu_batch_inverse)
+ private:
+  uint64_t v_[4];             // Montgomery form, R = 2^256
+};
+
+// injectable randomness (the reference draws from thread_rng(): src/r1cs/prover.rs:435-445)
+class Rng {
+ public:
+  explicit Rng(uint64_t seed) : s_(seed) {}
+  uint64_t next_u64();
+  Scalar scalar();            // 4 x u64 little-endian limbs reduced mod n
+ private:
+  uint64_t s_;
+};
+
+// ---- StarkPoint: canonical affine bytes; arithmetic happens on the device ------------------------
+struct StarkPoint {
+  std::array<uint8_t, 64> xy{};   // x || y little-endian; zeros = identity (src/util.rs:274-289)
+  static StarkPoint identity() { return StarkPoint(); }
+  static StarkPoint generator();
+  bool is_identity() const { for (auto c : xy) if (c) return false; return true; }
+  bool operator==(const StarkPoint &o) const { return xy == o.xy; }
+  bool operator!=(const StarkPoint &o) const { return !(*this == o); }
+};
+
+// ---- Device: owns the bpgpu context --------------------------------------------------------------
+class Device {
+ public:
+  explicit Device(int index = 0);
+  ~Device();
+  Device(const Device &) = delete;
+  Device &operator=(const Device &) = delete;
+  bpgpu_ctx *ctx() const { return ctx_; }
+  static Device &default_device();   // lazily created device 0
+  void check(int rc, const char *what) const;
+  // StarkPoint::msm_iter / msm
+  StarkPoint msm(const std::vector<Scalar> &scalars, const std::vector<StarkPoint> &points) const;
+ private:
+  bpgpu_ctx *ctx_ = nullptr;
+};
+
+// ---- Transcript: stand-in for merlin::HashChainTranscript + TranscriptProtocol (src/transcript.rs) -
+void keccak256(const uint8_t *in, size_t len, uint8_t out[32]);
+Scalar hash_to_scalar(const uint8_t low[32]);                  // src/util.rs:252-267
+class Transcript {
+ public:
+  explicit Transcript(const std::string &label);
+  void append_message(const std::string &label, const uint8_t *msg, size_t len);
+  void append_u64(const std::string &label, uint64_t x);
+  void challenge_bytes(const std::string &label, uint8_t out[32]);
+  // TranscriptProtocol (src/transcript.rs:25-57)
+  void innerproduct_domain_sep(uint64_t n);
+  void r1cs_domain_sep();
+  void r1cs_1phase_domain_sep();
+  void r1cs_2phase_domain_sep();
+  void append_scalar(const std::string &label, const Scalar &s);
+  void append_point(const std::string &label, const StarkPoint &p);
+  void validate_and_append_point(const std::string &label, const StarkPoint &p);   // throws ProofException(VerificationError)
+  Scalar challenge_scalar(const std::string &label);
+ private:
+  uint8_t state_[32];
+};
+
+// ---- generators (src/generators.rs) ----------------------------------------------------------------
+struct PedersenGens {
+  StarkPoint B, B_blinding;
+  PedersenGens();                                              // default(): both = curve generator (:61-70)
+  StarkPoint commit(const Scalar &value, const Scalar &blinding) const;   // :41-43
+};
+class BulletproofGens {
+ public:
+  BulletproofGens(size_t gens_capacity, size_t party_capacity);   // :182-191
+  ~BulletproofGens();
+  void increase_capacity(size_t new_capacity);                    // :210-235
+  size_t gens_capacity = 0, party_capacity = 0;
+  struct Share {                                                   // BulletproofGensShare :302-320
+    const BulletproofGens *gens; size_t share;
+    std::vector<StarkPoint> G(size_t n) const;
+    std::vector<StarkPoint> H(size_t n) const;
+  };
+  Share share(size_t j) const { return Share{this, j}; }
+  // resident fixed-base tables of share 0 for (B, B_blinding) -- built on first use
+  bpgpu_gens *device_tables(const PedersenGens &pc, int window_bits = 8) const;
+ private:
+  std::vector<std::vector<StarkPoint>> G_vec_, H_vec_;
+  mutable bpgpu_gens *tables_ = nullptr;
+  mutable size_t tables_cap_ = 0;
+  mutable std::array<uint8_t, 128> tables_pc_{};
+};
+
+// ---- inner product proof (src/inner_product_proof.rs) ----------------------------------------------
+Scalar inner_product(const std::vector<Scalar> &a, const std::vector<Scalar> &b);   // :463-472 (device)
+struct InnerProductProof {
+  std::vector<StarkPoint> L_vec, R_vec;
+  Scalar a, b;
+  // :49-193 -- panics (std::invalid_argument) on length mismatch / non power of two like the reference asserts
+  static InnerProductProof create(Transcript &transcript, const StarkPoint &Q, const std::vector<Scalar> &G_factors,
+                                  const std::vector<Scalar> &H_factors, std::vector<StarkPoint> G_vec,
+                                  std::vector<StarkPoint> H_vec, std::vector<Scalar> a_vec, std::vector<Scalar> b_vec);
+  struct VerificationScalars { std::vector<Scalar> u_sq, u_inv_sq, s; };
+  // :254-310 -- throws ProofException(VerificationError)
+  VerificationScalars verification_scalars(size_t n, Transcript &transcript, std::vector<Scalar> *challenges = nullptr) const;
+  // :317-372 -- throws ProofException(VerificationError)
+  void verify(size_t n, Transcript &transcript, const std::vector<Scalar> &G_factors, const std::vector<Scalar> &H_factors,
+              const StarkPoint &P, const StarkPoint &Q, const std::vector<StarkPoint> &G, const std::vector<StarkPoint> &H) const;
+  bool operator==(const InnerProductProof &o) const { return L_vec == o.L_vec && R_vec == o.R_vec && a == o.a && b == o.b; }
+};
+
+namespace util {
+std::vector<Scalar> exp_iter(const Scalar &x, size_t n);          // src/util.rs:73-76
+Scalar sum_of_powers(const Scalar &x, size_t n);                  // src/util.rs:218-234
+Scalar sum_of_powers_slow(const Scalar &x, size_t n);             // src/util.rs:237-239
+}  // namespace util
+
+// ---- r1cs (src/r1cs/*) ------------------------------------------------------------------------------
+namespace r1cs {
+
+struct Variable {                                                  // linear_combination.rs:15-28
+  enum Kind : uint32_t { MultiplierLeft = 0, MultiplierRight = 1, MultiplierOutput = 2, Committed = 3, One = 4, Zero = 5 };
+  Kind kind; size_t index;
+  bool operator<(const Variable &o) const { return kind != o.kind ? kind < o.kind : index < o.index; }
+  static Variable one() { return Variable{One, 0}; }
+};
+class LinearCombination {                                          // linear_combination.rs:118-121
+ public:
+  LinearCombination() {}
+  LinearCombination(const Variable &v) { terms[v] = Scalar::one(); }
+  LinearCombination(const Scalar &s) { terms[Variable::one()] = s; }
+  void add_term(const Variable &v, const Scalar &c);               // :129-135
+  LinearCombination operator+(const LinearCombination &o) const;
+  LinearCombination operator-(const LinearCombination &o) const;
+  LinearCombination operator-() const;
+  LinearCombination operator*(const Scalar &s) const;
+  std::map<Variable, Scalar> terms;
+};
+inline LinearCombination operator*(const Variable &v, const Scalar &s) { LinearCombination l; l.terms[v] = s; return l; }
+
+struct R1CSProof {                                                 // proof.rs:35-67
+  StarkPoint A_I1, A_O1, S1, A_I2, A_O2, S2, T_1, T_3, T_4, T_5, T_6;
+  Scalar t_x, t_x_blinding, e_blinding;
+  InnerProductProof ipp_proof;
+  // "flat v0" byte layout shared with the oracle (NOT the reference wire format, whose 32-byte point
+  // compression lives in the absent mpc-stark crate -- proof.rs:82-109)
+  std::vector<uint8_t> to_flat_bytes() const;
+  static R1CSProof from_flat_bytes(const std::vector<uint8_t> &b);   // throws R1CSException(FormatError)
+};
+
+class RandomizedConstraintSystem;
+// constraint_system.rs:55-208
+class ConstraintSystem {
+ public:
+  virtual ~ConstraintSystem() {}
+  virtual Transcript &transcript() = 0;
+  virtual size_t num_constraints() const = 0;
+  virtual size_t num_multipliers() const = 0;
+  virtual std::array<Variable, 3> multiply(LinearCombination left, LinearCombination right) = 0;
+  virtual Variable allocate(const Scalar *assignment) = 0;        // throws R1CSException(MissingAssignment)
+  virtual std::array<Variable, 3> allocate_multiplier(const std::pair<Scalar, Scalar> *input_assignments) = 0;
+  virtual Variable commit_public(const Scalar &value) = 0;
+  virtual void constrain(LinearCombination lc) = 0;
+  virtual Scalar eval(const LinearCombination &lc) const = 0;
+  using Callback = std::function<void(RandomizedConstraintSystem &)>;
+  virtual void specify_randomized_constraints(Callback cb) = 0;
+};
+class RandomizedConstraintSystem : public ConstraintSystem {
+ public:
+  virtual Scalar challenge_scalar(const std::string &label) = 0;
+};
+
+class CsCore;   // shared implementation
+class Prover : public RandomizedConstraintSystem {
+ public:
+  Prover(const PedersenGens &pc_gens, Transcript &transcript);     // prover.rs:285-300
+  ~Prover();
+  std::pair<StarkPoint, Variable> commit(const Scalar &v, const Scalar &v_blinding);   // :319-329
+  R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // :412-727 (RNG injected)
+  bool constraints_satisfied() const;                              // :405-409
+  Transcript &transcript() override;
+  size_t num_constraints() const override;
+  size_t num_multipliers() const override;
+  std::array<Variable, 3> multiply(LinearCombination left, LinearCombination right) override;
+  Variable allocate(const Scalar *assignment) override;
+  std::array<Variable, 3> allocate_multiplier(const std::pair<Scalar, Scalar> *input_assignments) override;
+  Variable commit_public(const Scalar &value) override;
+  void constrain(LinearCombination lc) override;
+  Scalar eval(const LinearCombination &lc) const override;
+  void specify_randomized_constraints(Callback cb) override;
+  Scalar challenge_scalar(const std::string &label) override;
+ private:
+  std::unique_ptr<CsCore> c_;
+};
+class Verifier : public RandomizedConstraintSystem {
+ public:
+  Verifier(const PedersenGens &pc_gens, Transcript &transcript);   // verifier.rs:270-282
+  ~Verifier();
+  Variable commit(const StarkPoint &commitment);                   // :298-306
+  void verify(const R1CSProof &proof, const BulletproofGens &bp_gens);   // :393-554; throws R1CSException
+  // the mega_check point of the last verify() (identity <=> accepted); parity hook
+  StarkPoint last_mega_check() const;
+  Transcript &transcript() override;
+  size_t num_constraints() const override;
+  size_t num_multipliers() const override;
+  std::array<Variable, 3> multiply(LinearCombination left, LinearCombination right) override;
+  Variable allocate(const Scalar *assignment) override;
+  std::array<Variable, 3> allocate_multiplier(const std::pair<Scalar, Scalar> *input_assignments) override;
+  Variable commit_public(const Scalar &value) override;
+  void constrain(LinearCombination lc) override;
+  Scalar eval(const LinearCombination &lc) const override;
+  void specify_randomized_constraints(Callback cb) override;
+  Scalar challenge_scalar(const std::string &label) override;
+ private:
+  std::unique_ptr<CsCore> c_;
+};
+
+}  // namespace r1cs
+}  // namespace mpc_bulletproof

@@ -11,7 +11,8 @@ SYMBOLS = [
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
-    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_prover_destroy",
+    "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev",
 ]
 
@@ -206,6 +207,26 @@ class BpGpu:
 
     def ipp_destroy(self, s):
         _lib.bpgpu_ipp_destroy(self.ctx, s)
+
+    def generator_mul(self, scalars):
+        n = len(scalars) // 32
+        o = _out(64 * n)
+        self._ck(_lib.bpgpu_generator_mul(self.ctx, _buf(scalars), C.c_size_t(n), o))
+        return bytes(o)[:64 * n]
+
+    def prover_polys(self, circuit, nb, n, m, y, y_inv, z, a_L, a_R, a_O, s_L, s_R):
+        t, wV, h = _out(32 * 6 * nb), _out(32 * nb * m), C.c_void_p()
+        self._ck(_lib.bpgpu_r1cs_prover_polys(self.ctx, circuit, C.c_size_t(nb), _buf(y), _buf(y_inv), _buf(z), _buf(a_L),
+                                              _buf(a_R), _buf(a_O), _buf(s_L), _buf(s_R), t, wV, C.byref(h)))
+        return bytes(t)[:32 * 6 * nb], bytes(wV)[:32 * nb * m], h
+
+    def prover_eval(self, sess, nb, padded_n, x):
+        lv, rv = _out(32 * nb * padded_n), _out(32 * nb * padded_n)
+        self._ck(_lib.bpgpu_r1cs_prover_eval(self.ctx, sess, C.c_size_t(padded_n), _buf(x), lv, rv))
+        return bytes(lv)[:32 * nb * padded_n], bytes(rv)[:32 * nb * padded_n]
+
+    def prover_destroy(self, sess):
+        _lib.bpgpu_prover_destroy(self.ctx, sess)
 
     # ---- R1CS
     def circuit_create(self, row_ptr, kind, idx, coeff, n_mul, m):
