@@ -17,6 +17,7 @@
 
 #include "../../include/bpgpu.h"
 
+#pragma GCC visibility push(default)
 namespace mpc_bulletproof {
 
 // ---- errors (src/errors.rs:13-55,150-177) -------------------------------------------------------
@@ -265,3 +266,4 @@ class Verifier : public RandomizedConstraintSystem {
 
 }  // namespace r1cs
 }  // namespace mpc_bulletproof
+#pragma GCC visibility pop
