@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "8")))
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "4")),
+                    help="steps in flight: consecutive steps alternate between this many independent contexts "
+                         "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
@@ -114,41 +117,53 @@ def main():
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    gpu = mb.BpGpu(local_rank)
+    ctxs = [mb.BpGpu(local_rank) for _ in range(max(1, a.inflight))]
+    gpu = ctxs[0]
     circ = gpu.circuit_create(rp, kind, idx, coeff, n1 + n2, m)
     gens = gpu.gens_create(o.gens("G", N_BITS), o.gens("H", N_BITS), o.generator(), o.generator(), a.window_bits)
     d_pts, d_sc, d_ch = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch)
-    d_ok = gpu.malloc(4 * nb)
+    d_oks = [gpu.malloc(4 * nb) for _ in ctxs]
+    counter = [0]
 
     def step():
-        gpu.r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_ok)
+        i = counter[0] % len(ctxs)
+        counter[0] += 1
+        ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[i])
+
+    def sync_all():
+        for c in ctxs:
+            c.sync()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for _ in range(max(a.warmup, len(ctxs))):
         step()
-    gpu.sync()
-    ok = gpu.download(d_ok, 4 * nb)
-    assert ok == (1).to_bytes(4, "little") * nb and gpu.input_flag() == 0, "GPU verification disagrees"
-    gpu.profile_enable(True)
+    sync_all()
+    for c, d in zip(ctxs, d_oks):
+        assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb and c.input_flag() == 0, "GPU verification disagrees"
+        c.profile_enable(True)
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
-    gpu.sync()
+    sync_all()
     fence()
     dt = time.perf_counter() - t0
-    prof = gpu.profile_read()
-    gpu.profile_enable(False)
+    prof = {}
+    for c in ctxs:
+        for name, (ms, cnt) in c.profile_read().items():
+            pm, pc = prof.get(name, (0.0, 0))
+            prof[name] = (pm + ms, pc + cnt)
+        c.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    ok = gpu.download(d_ok, 4 * nb)
-    assert ok == (1).to_bytes(4, "little") * nb
+    for c, d in zip(ctxs, d_oks):
+        assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
 
     if rank == 0:
         nvar = 11 + m + 2 * k
@@ -170,7 +185,7 @@ def main():
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 252-bit prime fields)", "data": "synthetic",
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
-                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb},
+                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
             "roofline": {"bound": "hbm", "kernel": {"straus": "k_straus<1,128>", "fixed_msm": "k_fixed_msm", "verify_scalars": "k_verify_scalars"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
@@ -184,7 +199,8 @@ def main():
         dist.destroy_process_group()
     gpu.gens_destroy(gens)
     gpu.circuit_destroy(circ)
-    gpu.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

@@ -93,6 +93,8 @@ static int ws_get(bpgpu_ctx *ctx, int slot, size_t bytes, void **out) {
   *out = s.p;
   return BPGPU_OK;
 }
+// scratch for the per-lane Straus tables; launches on ctx->st are in order, so they share it
+static int straus_ws(bpgpu_ctx *ctx, int np, size_t n, void **out) { return ws_get(ctx, 13, straus_scratch_bytes(np, n), out); }
 static int flag_reset(bpgpu_ctx *ctx) { HIPCK(ctx, hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->st)); return BPGPU_OK; }
 static int flag_read(bpgpu_ctx *ctx, int *v) {
   HIPCK(ctx, hipMemcpyAsync(v, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st));
@@ -334,7 +336,9 @@ static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *
   StrausArgs a{};
   a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
   a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
-  straus(ctx->st, 1, a, (JacRaw *)dres, tot);
+  void *dstr;
+  CK(straus_ws(ctx, 1, tot, &dstr));
+  straus(ctx->st, 1, a, (JacRaw *)dres, tot, dstr);
   segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nb, n);
   jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nb);
   CK(launch_ok(ctx));
@@ -471,11 +475,13 @@ int bpgpu_fold_witness(bpgpu_ctx *ctx, size_t n, const uint8_t u[32], const uint
   StrausArgs sg{};   // G' = u^-1 G_L + u G_R
   sg.pts[0] = dG; sg.pts[1] = dG + n; sg.pt_stride[0] = sg.pt_stride[1] = 1;
   sg.sc[0] = (uint32_t *)dui; sg.sc[1] = (uint32_t *)du; sg.sc_stride[0] = sg.sc_stride[1] = 0;
-  straus(ctx->st, 2, sg, (JacRaw *)dres, n);
+  void *dstr;
+  CK(straus_ws(ctx, 2, n, &dstr));
+  straus(ctx->st, 2, sg, (JacRaw *)dres, n, dstr);
   StrausArgs sh{};   // H' = u H_L + u^-1 H_R
   sh.pts[0] = dH; sh.pts[1] = dH + n; sh.pt_stride[0] = sh.pt_stride[1] = 1;
   sh.sc[0] = (uint32_t *)du; sh.sc[1] = (uint32_t *)dui; sh.sc_stride[0] = sh.sc_stride[1] = 0;
-  straus(ctx->st, 2, sh, (JacRaw *)dres + n, n);
+  straus(ctx->st, 2, sh, (JacRaw *)dres + n, n, dstr);
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, 2 * n);
   CK(launch_ok(ctx));
   int bad = 0;
@@ -633,6 +639,8 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
   CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
+  void *dstr;
+  CK(straus_ws(ctx, 1, nb * nvar, &dstr));
   VerifyDims d{nb, n1, n, np, k, m};
   CK(flag_reset(ctx));
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
@@ -659,7 +667,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   a.sc[0] = (uint32_t *)dvar; a.sc_stride[0] = 8;
   {
     ProfScope ps(ctx, 3, ctx->st);
-    straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar);
+    straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar, dstr);
   }
   HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
   {
@@ -782,6 +790,8 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
   const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
   const bool shared = s->first && s->shared_gens;
   const size_t gouter = shared ? 0 : n;
+  void *dstr;
+  CK(straus_ws(ctx, 1, nb * h, &dstr));
   sc_dot_batched(st, nb, h, a, n, b + h, n, s->cLR, 2);        // c_L = <a_L, b_R>
   sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
   const Words8 *sLa = a, *sLb = b + h, *sRa = a + h, *sRb = b;
@@ -798,7 +808,7 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     x.pts[0] = pts; x.pt_stride[0] = 1; x.pt_outer[0] = pt_outer;
     x.sc[0] = (const uint32_t *)sc; x.sc_stride[0] = 8; x.sc_outer[0] = sc_outer * 8;
     x.inner = cnt; x.out_outer = 2 * seg;
-    straus(st, 1, x, s->res + off, nb * cnt);
+    straus(st, 1, x, s->res + off, nb * cnt, dstr);
   };
   run(sLa, so, G + h, gouter, h, 0);              // L: a_L (.) G_R
   run(sLb, so, H, gouter, h, h);                  //    b_R (.) H_L
@@ -848,8 +858,10 @@ int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t
     g.sc[0] = (uint32_t *)dui; g.sc[1] = (uint32_t *)du; hh.sc[0] = (uint32_t *)du; hh.sc[1] = (uint32_t *)dui;
     for (int j = 0; j < 2; j++) { g.sc_stride[j] = hh.sc_stride[j] = 0; g.sc_outer[j] = hh.sc_outer[j] = 8; }
   }
-  straus(st, 2, g, fres, nb * h);
-  straus(st, 2, hh, fres + nb * h, nb * h);
+  void *dstr;
+  CK(straus_ws(ctx, 2, nb * h, &dstr));
+  straus(st, 2, g, fres, nb * h, dstr);
+  straus(st, 2, hh, fres + nb * h, nb * h, dstr);
   // when the input generators are shared the folded ones become per-proof: write them to buffer nxt
   batch_normalize(st, fres, s->G[nxt], nb * h, 8);
   batch_normalize(st, fres + nb * h, s->H[nxt], nb * h, 8);
@@ -978,7 +990,9 @@ int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_
   StrausArgs a{};
   a.pts[0] = (AffDev *)dgp; a.pt_stride[0] = 0;
   a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
-  straus(ctx->st, 1, a, (JacRaw *)dres, n);
+  void *dstr;
+  CK(straus_ws(ctx, 1, n, &dstr));
+  straus(ctx->st, 1, a, (JacRaw *)dres, n, dstr);
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, n);
   CK(launch_ok(ctx));
   int bad = 0;

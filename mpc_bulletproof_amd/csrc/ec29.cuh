@@ -13,6 +13,17 @@
 
 namespace bp {
 
+// F_p multiply / square as used by the group law.  With BP_EC_OUTLINE (device builds) they are ONE
+// out-of-line copy per code object: a multiplication is ~1.6 KB of code, a mixed addition inlines 11 of
+// them and k_straus came to 96 KB -- beyond the instruction cache once several kernels share a CU.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(BP_EC_OUTLINE)
+static __device__ __noinline__ Fp fpmul(const Fp &a, const Fp &b) { return mul(a, b); }
+static __device__ __noinline__ Fp fpsqr(const Fp &a) { return sqr(a); }
+#else
+BP_HD Fp fpmul(const Fp &a, const Fp &b) { return mul(a, b); }
+BP_HD Fp fpsqr(const Fp &a) { return sqr(a); }
+#endif
+
 struct Jac { Fp X, Y, Z; };
 struct Aff { Fp x, y; };
 
@@ -36,15 +47,15 @@ BP_HD Jac jac_neg(const Jac &a) { Jac r = a; r.Y = neg(a.Y); return r; }
 BP_HD Jac jac_dbl(const Jac &p) {
   if (jac_is_inf(p)) return jac_inf();
   if (fp_maybe_zero(p.Y) && is_zero_exact(p.Y)) return jac_inf();   // order-2 points do not exist (odd order), kept for completeness
-  Fp XX = sqr(p.X), YY = sqr(p.Y), YYYY = sqr(YY), ZZ = sqr(p.Z);
-  Fp t = sqr(add(p.X, YY));
+  Fp XX = fpsqr(p.X), YY = fpsqr(p.Y), YYYY = fpsqr(YY), ZZ = fpsqr(p.Z);
+  Fp t = fpsqr(add(p.X, YY));
   Fp S = mul_small<2>(norm(sub_nr(sub_nr(t, XX), YYYY)));
-  Fp M = add(norm(add_nr(add_nr(XX, XX), XX)), sqr(ZZ));           // 3 XX + a ZZ^2, a = 1
-  Fp T = norm(sub_nr(sub_nr(sqr(M), S), S));
+  Fp M = add(norm(add_nr(add_nr(XX, XX), XX)), fpsqr(ZZ));           // 3 XX + a ZZ^2, a = 1
+  Fp T = norm(sub_nr(sub_nr(fpsqr(M), S), S));
   Jac r;
   r.X = T;
-  r.Y = sub(mul(M, sub(S, T)), mul_small<8>(YYYY));
-  r.Z = mul_small<2>(mul(p.Y, p.Z));
+  r.Y = sub(fpmul(M, sub(S, T)), mul_small<8>(YYYY));
+  r.Z = mul_small<2>(fpmul(p.Y, p.Z));
   return r;
 }
 
@@ -52,20 +63,20 @@ BP_HD Jac jac_dbl(const Jac &p) {
 BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
   if (aff_is_inf(q)) return p;
   if (jac_is_inf(p)) { Jac r; r.X = q.x; r.Y = q.y; r.Z = fe_one<FP>(); return r; }
-  Fp Z1Z1 = sqr(p.Z);
-  Fp U2 = mul(q.x, Z1Z1);
-  Fp S2 = mul(q.y, mul(p.Z, Z1Z1));
+  Fp Z1Z1 = fpsqr(p.Z);
+  Fp U2 = fpmul(q.x, Z1Z1);
+  Fp S2 = fpmul(q.y, fpmul(p.Z, Z1Z1));
   Fp H = sub(U2, p.X);
   Fp rr = sub(S2, p.Y);
   if (fp_maybe_zero(H) && is_zero_exact(H)) {
     if (is_zero_exact(rr)) { Jac t; t.X = q.x; t.Y = q.y; t.Z = fe_one<FP>(); return jac_dbl(t); }
     return jac_inf();
   }
-  Fp HH = sqr(H), HHH = mul(H, HH), V = mul(p.X, HH);
+  Fp HH = fpsqr(H), HHH = fpmul(H, HH), V = fpmul(p.X, HH);
   Jac r;
-  r.X = norm(sub_nr(sub_nr(sub_nr(sqr(rr), HHH), V), V));
-  r.Y = sub(mul(rr, sub(V, r.X)), mul(p.Y, HHH));
-  r.Z = mul(p.Z, H);
+  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(rr), HHH), V), V));
+  r.Y = sub(fpmul(rr, sub(V, r.X)), fpmul(p.Y, HHH));
+  r.Z = fpmul(p.Z, H);
   return r;
 }
 
@@ -73,29 +84,29 @@ BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
 BP_HD Jac jac_add(const Jac &p, const Jac &q) {
   if (jac_is_inf(p)) return q;
   if (jac_is_inf(q)) return p;
-  Fp Z1Z1 = sqr(p.Z), Z2Z2 = sqr(q.Z);
-  Fp U1 = mul(p.X, Z2Z2), U2 = mul(q.X, Z1Z1);
-  Fp S1 = mul(p.Y, mul(q.Z, Z2Z2)), S2 = mul(q.Y, mul(p.Z, Z1Z1));
+  Fp Z1Z1 = fpsqr(p.Z), Z2Z2 = fpsqr(q.Z);
+  Fp U1 = fpmul(p.X, Z2Z2), U2 = fpmul(q.X, Z1Z1);
+  Fp S1 = fpmul(p.Y, fpmul(q.Z, Z2Z2)), S2 = fpmul(q.Y, fpmul(p.Z, Z1Z1));
   Fp H = sub(U2, U1);
   Fp rr = sub(S2, S1);
   if (fp_maybe_zero(H) && is_zero_exact(H)) {
     if (is_zero_exact(rr)) return jac_dbl(p);
     return jac_inf();
   }
-  Fp HH = sqr(H), HHH = mul(H, HH), V = mul(U1, HH);
+  Fp HH = fpsqr(H), HHH = fpmul(H, HH), V = fpmul(U1, HH);
   Jac r;
-  r.X = norm(sub_nr(sub_nr(sub_nr(sqr(rr), HHH), V), V));
-  r.Y = sub(mul(rr, sub(V, r.X)), mul(S1, HHH));
-  r.Z = mul(mul(p.Z, q.Z), H);
+  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(rr), HHH), V), V));
+  r.Y = sub(fpmul(rr, sub(V, r.X)), fpmul(S1, HHH));
+  r.Z = fpmul(fpmul(p.Z, q.Z), H);
   return r;
 }
 
 // Jacobian -> affine with a known 1/Z
 BP_HD Aff jac_to_aff_with_zinv(const Jac &p, const Fp &zinv) {
   Aff a;
-  Fp zi2 = sqr(zinv);
-  a.x = mul(p.X, zi2);
-  a.y = mul(p.Y, mul(zi2, zinv));
+  Fp zi2 = fpsqr(zinv);
+  a.x = fpmul(p.X, zi2);
+  a.y = fpmul(p.Y, fpmul(zi2, zinv));
   return a;
 }
 BP_HD Aff jac_to_aff(const Jac &p) {
@@ -107,8 +118,8 @@ BP_HD bool aff_on_curve(const Aff &a) {
   Fp B;
   constexpr int32_t C[NL] = CURVE_B_MONT;
   for (int j = 0; j < NL; j++) B.v[j] = C[j];
-  Fp lhs = sqr(a.y);
-  Fp rhs = norm(add_nr(add_nr(mul(sqr(a.x), a.x), a.x), B));
+  Fp lhs = fpsqr(a.y);
+  Fp rhs = norm(add_nr(add_nr(fpmul(fpsqr(a.x), a.x), a.x), B));
   return is_zero_exact(sub(lhs, rhs));
 }
 BP_HD Aff aff_generator() {

@@ -40,93 +40,18 @@ __device__ __forceinline__ void aff_store(AffDev *d, const Aff &a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, AffDev *out, size_t n, int *bad) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  uint32_t w[16];
-#pragma unroll
-  for (int j = 0; j < 8; j++) { w[j] = xy[2 * i].w[j]; w[8 + j] = xy[2 * i + 1].w[j]; }
-  Aff a;
-  bool ok = aff_from_boundary(a, w);
-  if (!ok) {
-    atomicOr(bad, 1);
-    a.x = fe_zero<FP>();
-    a.y = fe_zero<FP>();
-  }
-  aff_store(&out[i], a);
-}
-void points_from_boundary(hipStream_t st, const Words8 *xy, AffDev *out, size_t n, int *bad) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_points_from_boundary, dim3((n + 255) / 256), dim3(256), 0, st, xy, out, n, bad);
-}
-
-__global__ void __launch_bounds__(64) k_jac_to_boundary(const JacRaw *in, Words8 *xy, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  Jac p = raw_load(&in[i]);
-  if (!jac_is_inf(p) && is_zero_exact(p.Z)) p = jac_inf();
-  uint32_t w[16];
-  aff_to_boundary(w, jac_to_aff(p));
-#pragma unroll
-  for (int j = 0; j < 8; j++) { xy[2 * i].w[j] = w[j]; xy[2 * i + 1].w[j] = w[8 + j]; }
-}
-void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy, size_t n) {
-  if (!n) return;
-  hipLaunchKernelGGL(k_jac_to_boundary, dim3((n + 63) / 64), dim3(64), 0, st, in, xy, n);
-}
-
-// Montgomery's trick over RUN consecutive points per lane
-template <int RUN>
-__global__ void __launch_bounds__(128) k_batch_normalize(const JacRaw *in, AffDev *out, size_t n) {
-  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t base = r * RUN;
-  if (base >= n) return;
-  Fp pref[RUN];
-  Fp acc = fe_one<FP>();
-#pragma unroll
-  for (int i = 0; i < RUN; i++) {
-    pref[i] = acc;
-    if (base + i < n) {
-      Fp z;
-#pragma unroll
-      for (int j = 0; j < NL; j++) z.v[j] = in[base + i].v[2 * NL + j];
-      if (!is_zero_limbs(z)) acc = mul(acc, z);
-    }
-  }
-  Fp ai = inv(acc);
-#pragma unroll
-  for (int i = RUN - 1; i >= 0; i--) {
-    if (base + i < n) {
-      Jac p = raw_load(&in[base + i]);
-      Aff a;
-      if (jac_is_inf(p)) {
-        a.x = fe_zero<FP>();
-        a.y = fe_zero<FP>();
-      } else {
-        Fp zi = mul(ai, pref[i]);
-        ai = mul(ai, p.Z);
-        a = jac_to_aff_with_zinv(p, zi);
-      }
-      aff_store(&out[base + i], a);
-    }
-  }
-}
-void batch_normalize(hipStream_t st, const JacRaw *in, AffDev *out, size_t n, int run) {
-  if (!n) return;
-  (void)run;
-  size_t lanes = (n + 7) / 8;
-  hipLaunchKernelGGL(k_batch_normalize<8>, dim3((lanes + 127) / 128), dim3(128), 0, st, in, out, n);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Straus with signed 4-bit windows; one output per lane; tables of {1..8} * P_j in LDS laid out
-// [j][entry][limb][lane] (bank = lane: conflict-free whatever digit each lane picks).
+// Straus with signed 4-bit windows; one output per lane; per-lane tables of {1..8} * P_j.
+// The tables live in an L2-resident global scratch laid out [block][point][entry][limb][lane]: a wave's
+// load of one limb touches at most 8 rows (one per digit magnitude) of 256 contiguous bytes, a few
+// hundred bytes per point addition against ~3 000 integer instructions -- and, unlike the 108 KB LDS
+// image this replaces (1 block per CU), it leaves occupancy to the register file, so the Straus
+// kernels of several in-flight batches overlap (profiles/: 1.75 ms/launch at 0.5 wave/SIMD before).
 constexpr int SW = 4;                 // window bits
 constexpr int SE = 1 << (SW - 1);     // 8 table entries
 template <int NP, int TPB>
-__global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_t n) {
-  extern __shared__ int32_t tab[];    // NP * SE * 27 * TPB
+__global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all) {
   const int tid = threadIdx.x;
+  int32_t *tab = tab_all + (size_t)blockIdx.x * (NP * SE * 27 * TPB);
   size_t i = (size_t)blockIdx.x * TPB + tid;
   const bool live = i < n;
   if (!live) i = n - 1;               // keep the wave uniform; result discarded
@@ -149,25 +74,32 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
       if (e + 1 < SE) m = jac_madd(m, P);
     }
   }
+  // each lane only ever reads back its own stores (same thread, program order): no fence needed
   Jac acc = jac_inf();
   constexpr int W = num_windows<SW>();
 #pragma unroll 1
   for (int w = W - 1; w >= 0; w--) {
+    // issue the table reads of this window before its doublings so L2 latency hides under them
+    Jac q[NP];
+    int dg[NP];
+#pragma unroll
+    for (int j = 0; j < NP; j++) {
+      dg[j] = recode_digit<SW>(sp[j], w);
+      int e = (dg[j] < 0 ? -dg[j] : dg[j]) - 1;
+      if (e < 0) e = 0;
+      const int32_t *src = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
+#pragma unroll
+      for (int t = 0; t < NL; t++) { q[j].X.v[t] = src[t * TPB]; q[j].Y.v[t] = src[(NL + t) * TPB]; q[j].Z.v[t] = src[(2 * NL + t) * TPB]; }
+    }
     if (w != W - 1) {
 #pragma unroll 1
       for (int d = 0; d < SW; d++) acc = jac_dbl(acc);
     }
 #pragma unroll
     for (int j = 0; j < NP; j++) {
-      int dg = recode_digit<SW>(sp[j], w);
-      if (dg != 0) {
-        int e = (dg < 0 ? -dg : dg) - 1;
-        const int32_t *src = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
-        Jac q;
-#pragma unroll
-        for (int t = 0; t < NL; t++) { q.X.v[t] = src[t * TPB]; q.Y.v[t] = src[(NL + t) * TPB]; q.Z.v[t] = src[(2 * NL + t) * TPB]; }
-        if (dg < 0) q.Y = neg(q.Y);
-        acc = jac_add(acc, q);
+      if (dg[j] != 0) {
+        if (dg[j] < 0) q[j].Y = neg(q[j].Y);
+        acc = jac_add(acc, q[j]);
       }
     }
   }
@@ -177,17 +109,15 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
     raw_store(&out[o], acc);
   }
 }
-void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n) {
+size_t straus_scratch_bytes(int np, size_t n) {
+  const size_t tpb = 64;
+  return ((n + tpb - 1) / tpb) * (size_t)np * SE * 27 * tpb * 4;
+}
+void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch) {
   if (!n) return;
-  if (np == 1) {
-    constexpr int TPB = 128;
-    size_t lds = (size_t)1 * SE * 27 * TPB * 4;
-    hipLaunchKernelGGL((k_straus<1, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), lds, st, a, out, n);
-  } else {
-    constexpr int TPB = 64;
-    size_t lds = (size_t)2 * SE * 27 * TPB * 4;
-    hipLaunchKernelGGL((k_straus<2, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), lds, st, a, out, n);
-  }
+  constexpr int TPB = 64;
+  if (np == 1) hipLaunchKernelGGL((k_straus<1, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
+  else hipLaunchKernelGGL((k_straus<2, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,50 +163,6 @@ void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, siz
   if (!nb) return;
   if (n <= 64) hipLaunchKernelGGL((k_segmented_sum<16>), dim3(nb), dim3(16), 0, st, in, out, n);
   else hipLaunchKernelGGL((k_segmented_sum<128>), dim3(nb), dim3(128), 0, st, in, out, n);
-}
-
-// ------------------------------------------------------------------------------------------------
-// fixed-base tables
-size_t fixed_table_entries(int c, size_t ngens) { return ngens * (size_t)(252 / c + 1) << (c - 1); }
-
-// base[g*W + w] = 2^(c w) P_g
-__global__ void __launch_bounds__(64) k_tab_bases(int c, int W, const AffDev *gens, size_t ngens, JacRaw *bases) {
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (g >= ngens) return;
-  Jac b = jac_from_aff(aff_load(&gens[g]));
-  for (int w = 0; w < W; w++) {
-    raw_store(&bases[g * W + w], b);
-    for (int d = 0; d < c; d++) b = jac_dbl(b);
-  }
-}
-// fill[(l << (c-1)) + r*8 + i] = (r*8 + i + 1) * base[l]
-__global__ void __launch_bounds__(128) k_tab_fill(int c, size_t nbases, const JacRaw *bases, JacRaw *fill) {
-  const int runs = 1 << (c - 1 - 3);
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nbases * runs) return;
-  size_t l = t / runs;
-  int r = (int)(t % runs);
-  Jac base = raw_load(&bases[l]);
-  unsigned d0 = (unsigned)r * 8 + 1;
-  Jac acc = jac_inf();
-  for (int bit = 15; bit >= 0; bit--) {
-    acc = jac_dbl(acc);
-    if ((d0 >> bit) & 1) acc = jac_add(acc, base);
-  }
-  JacRaw *dst = fill + (l << (c - 1)) + (size_t)r * 8;
-  for (int i = 0; i < 8; i++) {
-    raw_store(&dst[i], acc);
-    if (i < 7) acc = jac_add(acc, base);
-  }
-}
-void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, AffDev *table, JacRaw *scratch) {
-  const int W = 252 / c + 1;
-  size_t nbases = ngens * W, entries = nbases << (c - 1);
-  JacRaw *bases = scratch, *fill = scratch + nbases;
-  hipLaunchKernelGGL(k_tab_bases, dim3((ngens + 63) / 64), dim3(64), 0, st, c, W, gens, ngens, bases);
-  size_t threads = nbases << (c - 1 - 3);
-  hipLaunchKernelGGL(k_tab_fill, dim3((threads + 127) / 128), dim3(128), 0, st, c, nbases, bases, fill);
-  batch_normalize(st, fill, table, entries, 8);
 }
 
 // One block per MSM; lane l walks (generator, window) pairs l, l+TPB, ...; table row index == pair index.
@@ -360,52 +246,6 @@ void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t ngens, const u
     case 16: launch_fixed<16>(st, table, ngens, scalars, stride, out, nb); break;
     default: break;   // rejected by the C-ABI before reaching here
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// 32 lanes per proof (two proofs per wave): gather, butterfly-reduce with wave shuffles, test identity.
-__global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_t nvar, const JacRaw *fixed,
-                                                        size_t nb, int32_t *ok, Words8 *mega) {
-  const int lane = threadIdx.x & 31;
-  size_t p = (size_t)blockIdx.x * 2 + (threadIdx.x >> 5);
-  const bool live = p < nb;
-  if (!live) p = nb - 1;
-  Jac acc = jac_inf();
-  for (size_t v = lane; v < nvar + 1; v += 32) {
-    Jac q = raw_load(v < nvar ? &var[p * nvar + v] : &fixed[p]);
-    acc = jac_add(acc, q);
-  }
-#pragma unroll 1
-  for (int off = 16; off > 0; off >>= 1) {
-    Jac q;
-#pragma unroll
-    for (int t = 0; t < NL; t++) {
-      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
-      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
-      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
-    }
-    acc = jac_add(acc, q);
-  }
-  if (lane == 0 && live) {
-    bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
-    ok[p] = inf ? 1 : 0;
-    if (mega) {
-      uint32_t w[16];
-      if (inf) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) w[j] = 0;
-      } else {
-        aff_to_boundary(w, jac_to_aff(acc));
-      }
-#pragma unroll
-      for (int j = 0; j < 8; j++) { mega[2 * p].w[j] = w[j]; mega[2 * p + 1].w[j] = w[8 + j]; }
-    }
-  }
-}
-void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRaw *fixed, size_t nb,
-                     int32_t *ok, Words8 *mega) {
-  if (!nb) return;
-  hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega);
 }
 
 }  // namespace bpk

@@ -1,0 +1,214 @@
+// k_ec_misc.hip -- the colder elliptic-curve kernels (import/export, normalisation, table build,
+// verification tail), compiled with the field multiply inlined.  Split from k_ec.hip because the
+// ROCm 7.2 backend crashes (Machine Copy Propagation) on k_verify_finalize with out-of-line calls.
+// k_ec.hip -- elliptic-curve kernels for gfx950 (wave64): point import/export, per-lane Straus
+// scalar multiplication with LDS-resident tables, segmented point sums, signed fixed-window
+// fixed-base tables + lookup MSM, verification tail.
+//
+// Hot-path rows: a1 StarkPoint::msm_iter / msm, a2 fold_witness (point half),
+// a3 first-round generator scaling, a9 mega_check.  All integer work (F_p, 9 x 29-bit limbs); the
+// kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
+#include "ec29.cuh"
+#include "kernels.h"
+
+using namespace bp;
+
+namespace bpk {
+
+__device__ __forceinline__ void raw_store(JacRaw *d, const Jac &p) {
+#pragma unroll
+  for (int j = 0; j < NL; j++) { d->v[j] = p.X.v[j]; d->v[NL + j] = p.Y.v[j]; d->v[2 * NL + j] = p.Z.v[j]; }
+}
+__device__ __forceinline__ Jac raw_load(const JacRaw *s) {
+  Jac p;
+#pragma unroll
+  for (int j = 0; j < NL; j++) { p.X.v[j] = s->v[j]; p.Y.v[j] = s->v[NL + j]; p.Z.v[j] = s->v[2 * NL + j]; }
+  return p;
+}
+__device__ __forceinline__ Aff aff_load(const AffDev *s) {
+  Aff a;
+  uint32_t w[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) w[j] = s->w[j];
+  a.x = unpack<FP>(w);
+  a.y = unpack<FP>(w + 8);
+  return a;
+}
+__device__ __forceinline__ void aff_store(AffDev *d, const Aff &a) {
+  uint32_t w[16];
+  pack(w, canon(a.x));
+  pack(w + 8, canon(a.y));
+#pragma unroll
+  for (int j = 0; j < 16; j++) d->w[j] = w[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, AffDev *out, size_t n, int *bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[16];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { w[j] = xy[2 * i].w[j]; w[8 + j] = xy[2 * i + 1].w[j]; }
+  Aff a;
+  bool ok = aff_from_boundary(a, w);
+  if (!ok) {
+    atomicOr(bad, 1);
+    a.x = fe_zero<FP>();
+    a.y = fe_zero<FP>();
+  }
+  aff_store(&out[i], a);
+}
+void points_from_boundary(hipStream_t st, const Words8 *xy, AffDev *out, size_t n, int *bad) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_points_from_boundary, dim3((n + 255) / 256), dim3(256), 0, st, xy, out, n, bad);
+}
+
+__global__ void __launch_bounds__(64) k_jac_to_boundary(const JacRaw *in, Words8 *xy, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Jac p = raw_load(&in[i]);
+  if (!jac_is_inf(p) && is_zero_exact(p.Z)) p = jac_inf();
+  uint32_t w[16];
+  aff_to_boundary(w, jac_to_aff(p));
+#pragma unroll
+  for (int j = 0; j < 8; j++) { xy[2 * i].w[j] = w[j]; xy[2 * i + 1].w[j] = w[8 + j]; }
+}
+void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy, size_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_jac_to_boundary, dim3((n + 63) / 64), dim3(64), 0, st, in, xy, n);
+}
+
+// Montgomery's trick over RUN consecutive points per lane
+template <int RUN>
+__global__ void __launch_bounds__(128) k_batch_normalize(const JacRaw *in, AffDev *out, size_t n) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t base = r * RUN;
+  if (base >= n) return;
+  Fp pref[RUN];
+  Fp acc = fe_one<FP>();
+#pragma unroll
+  for (int i = 0; i < RUN; i++) {
+    pref[i] = acc;
+    if (base + i < n) {
+      Fp z;
+#pragma unroll
+      for (int j = 0; j < NL; j++) z.v[j] = in[base + i].v[2 * NL + j];
+      if (!is_zero_limbs(z)) acc = mul(acc, z);
+    }
+  }
+  Fp ai = inv(acc);
+#pragma unroll
+  for (int i = RUN - 1; i >= 0; i--) {
+    if (base + i < n) {
+      Jac p = raw_load(&in[base + i]);
+      Aff a;
+      if (jac_is_inf(p)) {
+        a.x = fe_zero<FP>();
+        a.y = fe_zero<FP>();
+      } else {
+        Fp zi = mul(ai, pref[i]);
+        ai = mul(ai, p.Z);
+        a = jac_to_aff_with_zinv(p, zi);
+      }
+      aff_store(&out[base + i], a);
+    }
+  }
+}
+void batch_normalize(hipStream_t st, const JacRaw *in, AffDev *out, size_t n, int run) {
+  if (!n) return;
+  (void)run;
+  size_t lanes = (n + 7) / 8;
+  hipLaunchKernelGGL(k_batch_normalize<8>, dim3((lanes + 127) / 128), dim3(128), 0, st, in, out, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed-base tables
+size_t fixed_table_entries(int c, size_t ngens) { return ngens * (size_t)(252 / c + 1) << (c - 1); }
+
+// base[g*W + w] = 2^(c w) P_g
+__global__ void __launch_bounds__(64) k_tab_bases(int c, int W, const AffDev *gens, size_t ngens, JacRaw *bases) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= ngens) return;
+  Jac b = jac_from_aff(aff_load(&gens[g]));
+  for (int w = 0; w < W; w++) {
+    raw_store(&bases[g * W + w], b);
+    for (int d = 0; d < c; d++) b = jac_dbl(b);
+  }
+}
+// fill[(l << (c-1)) + r*8 + i] = (r*8 + i + 1) * base[l]
+__global__ void __launch_bounds__(128) k_tab_fill(int c, size_t nbases, const JacRaw *bases, JacRaw *fill) {
+  const int runs = 1 << (c - 1 - 3);
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nbases * runs) return;
+  size_t l = t / runs;
+  int r = (int)(t % runs);
+  Jac base = raw_load(&bases[l]);
+  unsigned d0 = (unsigned)r * 8 + 1;
+  Jac acc = jac_inf();
+  for (int bit = 15; bit >= 0; bit--) {
+    acc = jac_dbl(acc);
+    if ((d0 >> bit) & 1) acc = jac_add(acc, base);
+  }
+  JacRaw *dst = fill + (l << (c - 1)) + (size_t)r * 8;
+  for (int i = 0; i < 8; i++) {
+    raw_store(&dst[i], acc);
+    if (i < 7) acc = jac_add(acc, base);
+  }
+}
+void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, AffDev *table, JacRaw *scratch) {
+  const int W = 252 / c + 1;
+  size_t nbases = ngens * W, entries = nbases << (c - 1);
+  JacRaw *bases = scratch, *fill = scratch + nbases;
+  hipLaunchKernelGGL(k_tab_bases, dim3((ngens + 63) / 64), dim3(64), 0, st, c, W, gens, ngens, bases);
+  size_t threads = nbases << (c - 1 - 3);
+  hipLaunchKernelGGL(k_tab_fill, dim3((threads + 127) / 128), dim3(128), 0, st, c, nbases, bases, fill);
+  batch_normalize(st, fill, table, entries, 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 32 lanes per proof (two proofs per wave): gather, butterfly-reduce with wave shuffles, test identity.
+__global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_t nvar, const JacRaw *fixed,
+                                                        size_t nb, int32_t *ok, Words8 *mega) {
+  const int lane = threadIdx.x & 31;
+  size_t p = (size_t)blockIdx.x * 2 + (threadIdx.x >> 5);
+  const bool live = p < nb;
+  if (!live) p = nb - 1;
+  Jac acc = jac_inf();
+  for (size_t v = lane; v < nvar + 1; v += 32) {
+    Jac q = raw_load(v < nvar ? &var[p * nvar + v] : &fixed[p]);
+    acc = jac_add(acc, q);
+  }
+#pragma unroll 1
+  for (int off = 16; off > 0; off >>= 1) {
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
+    }
+    acc = jac_add(acc, q);
+  }
+  if (lane == 0 && live) {
+    bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
+    ok[p] = inf ? 1 : 0;
+    if (mega) {
+      uint32_t w[16];
+      if (inf) {
+#pragma unroll
+        for (int j = 0; j < 16; j++) w[j] = 0;
+      } else {
+        aff_to_boundary(w, jac_to_aff(acc));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; j++) { mega[2 * p].w[j] = w[j]; mega[2 * p + 1].w[j] = w[8 + j]; }
+    }
+  }
+}
+void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRaw *fixed, size_t nb,
+                     int32_t *ok, Words8 *mega) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega);
+}
+
+}  // namespace bpk

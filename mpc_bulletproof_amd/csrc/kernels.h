@@ -34,7 +34,9 @@ struct StrausArgs {
   size_t sc_outer[2];
   size_t out_outer;   // with inner != 0: out[p * out_outer + r]; 0 = dense (out[i])
 };
-void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n);
+// scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
+size_t straus_scratch_bytes(int np, size_t n);
+void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch);
 
 // out[b] = sum_{i<n} in[b*n + i]
 void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, size_t n);
