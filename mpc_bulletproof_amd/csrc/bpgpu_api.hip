@@ -2,6 +2,7 @@
 // No CPU fallback: every entry point needs a live HIP device and fails with BPGPU_E_DEVICE otherwise.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -333,13 +334,22 @@ static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *
   CK(h2d(ctx, dxy, points, tot * 64));
   scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, tot, ctx->d_flag);
-  StrausArgs a{};
-  a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
-  a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
-  void *dstr;
-  CK(straus_ws(ctx, 1, tot, &dstr));
-  straus(ctx->st, 1, a, (JacRaw *)dres, tot, dstr);
-  segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nb, n);
+  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  if (n >= pip_min) {   // bucket method per instance
+    int c = pippenger_window(n);
+    void *dpip;
+    CK(ws_get(ctx, 14, pippenger_scratch_bytes(n, c), &dpip));
+    for (size_t b = 0; b < nb; b++)
+      pippenger(ctx->st, (AffDev *)dpts + b * n, (uint32_t *)dsc + b * n * 8, n, c, (JacRaw *)dsum + b, dpip);
+  } else {
+    StrausArgs a{};
+    a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
+    a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
+    void *dstr;
+    CK(straus_ws(ctx, 1, tot, &dstr));
+    straus(ctx->st, 1, a, (JacRaw *)dres, tot, dstr);
+    segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nb, n);
+  }
   jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nb);
   CK(launch_ok(ctx));
   int bad = 0;

@@ -5,39 +5,11 @@
 // Hot-path rows: a1 StarkPoint::msm_iter / msm, a2 fold_witness (point half),
 // a3 first-round generator scaling, a9 mega_check.  All integer work (F_p, 9 x 29-bit limbs); the
 // kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
-#include "ec29.cuh"
-#include "kernels.h"
+#include "ec_dev.cuh"
 
 using namespace bp;
 
 namespace bpk {
-
-__device__ __forceinline__ void raw_store(JacRaw *d, const Jac &p) {
-#pragma unroll
-  for (int j = 0; j < NL; j++) { d->v[j] = p.X.v[j]; d->v[NL + j] = p.Y.v[j]; d->v[2 * NL + j] = p.Z.v[j]; }
-}
-__device__ __forceinline__ Jac raw_load(const JacRaw *s) {
-  Jac p;
-#pragma unroll
-  for (int j = 0; j < NL; j++) { p.X.v[j] = s->v[j]; p.Y.v[j] = s->v[NL + j]; p.Z.v[j] = s->v[2 * NL + j]; }
-  return p;
-}
-__device__ __forceinline__ Aff aff_load(const AffDev *s) {
-  Aff a;
-  uint32_t w[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) w[j] = s->w[j];
-  a.x = unpack<FP>(w);
-  a.y = unpack<FP>(w + 8);
-  return a;
-}
-__device__ __forceinline__ void aff_store(AffDev *d, const Aff &a) {
-  uint32_t w[16];
-  pack(w, canon(a.x));
-  pack(w + 8, canon(a.y));
-#pragma unroll
-  for (int j = 0; j < 16; j++) d->w[j] = w[j];
-}
 
 // ------------------------------------------------------------------------------------------------
 // Straus with signed 4-bit windows; one output per lane; per-lane tables of {1..8} * P_j.
@@ -118,36 +90,6 @@ void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, 
   constexpr int TPB = 64;
   if (np == 1) hipLaunchKernelGGL((k_straus<1, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
   else hipLaunchKernelGGL((k_straus<2, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
-}
-
-// ------------------------------------------------------------------------------------------------
-// block-level point sum: every lane holds `acc`; result valid in lane 0.  smem: 27 * TPB/2 ints.
-template <int TPB> __device__ __forceinline__ Jac block_sum(Jac acc, int32_t *smem) {
-  const int tid = threadIdx.x;
-#pragma unroll 1
-  for (int s = TPB / 2; s > 0; s >>= 1) {
-    if (tid >= s && tid < 2 * s) {
-#pragma unroll
-      for (int t = 0; t < NL; t++) {
-        smem[t * (TPB / 2) + tid - s] = acc.X.v[t];
-        smem[(NL + t) * (TPB / 2) + tid - s] = acc.Y.v[t];
-        smem[(2 * NL + t) * (TPB / 2) + tid - s] = acc.Z.v[t];
-      }
-    }
-    __syncthreads();
-    if (tid < s) {
-      Jac q;
-#pragma unroll
-      for (int t = 0; t < NL; t++) {
-        q.X.v[t] = smem[t * (TPB / 2) + tid];
-        q.Y.v[t] = smem[(NL + t) * (TPB / 2) + tid];
-        q.Z.v[t] = smem[(2 * NL + t) * (TPB / 2) + tid];
-      }
-      acc = jac_add(acc, q);
-    }
-    __syncthreads();
-  }
-  return acc;
 }
 
 template <int TPB>

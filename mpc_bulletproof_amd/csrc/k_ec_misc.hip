@@ -8,39 +8,11 @@
 // Hot-path rows: a1 StarkPoint::msm_iter / msm, a2 fold_witness (point half),
 // a3 first-round generator scaling, a9 mega_check.  All integer work (F_p, 9 x 29-bit limbs); the
 // kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
-#include "ec29.cuh"
-#include "kernels.h"
+#include "ec_dev.cuh"
 
 using namespace bp;
 
 namespace bpk {
-
-__device__ __forceinline__ void raw_store(JacRaw *d, const Jac &p) {
-#pragma unroll
-  for (int j = 0; j < NL; j++) { d->v[j] = p.X.v[j]; d->v[NL + j] = p.Y.v[j]; d->v[2 * NL + j] = p.Z.v[j]; }
-}
-__device__ __forceinline__ Jac raw_load(const JacRaw *s) {
-  Jac p;
-#pragma unroll
-  for (int j = 0; j < NL; j++) { p.X.v[j] = s->v[j]; p.Y.v[j] = s->v[NL + j]; p.Z.v[j] = s->v[2 * NL + j]; }
-  return p;
-}
-__device__ __forceinline__ Aff aff_load(const AffDev *s) {
-  Aff a;
-  uint32_t w[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) w[j] = s->w[j];
-  a.x = unpack<FP>(w);
-  a.y = unpack<FP>(w + 8);
-  return a;
-}
-__device__ __forceinline__ void aff_store(AffDev *d, const Aff &a) {
-  uint32_t w[16];
-  pack(w, canon(a.x));
-  pack(w + 8, canon(a.y));
-#pragma unroll
-  for (int j = 0; j < 16; j++) d->w[j] = w[j];
-}
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, AffDev *out, size_t n, int *bad) {

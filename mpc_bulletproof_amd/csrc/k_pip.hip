@@ -1,0 +1,175 @@
+// k_pip.hip -- bucket-method (Pippenger) multi-scalar multiplication for large variable-base MSMs
+// (prover commitments and IPP rounds over folded generators, the C4 98 347-term
+// mega_check, combined batch checks).  Replaces StarkPoint::msm_iter for n >~ 1k
+// (call sites: r1cs/verifier.rs:516, r1cs/prover.rs:465-564, inner_product_proof.rs:90-172).
+//
+// Pipeline (all on one stream):
+//   1 k_pip_digits    lane per term: signed c-bit digits via the +K recoding (no serial carry),
+//                     histogram of bucket ids with integer atomics
+//   2 k_pip_scan      exclusive scan of the W * 2^(c-1) bucket counts (single block)
+//   3 k_pip_scatter   counting-sort scatter (order inside a bucket is irrelevant: the sum commutes)
+//   4 k_pip_bucket    lane per bucket: gather its points (64 B rows) and accumulate with mixed adds
+//   5 k_pip_window    block per window: segmented running sums  sum_d d * B_d,  LDS tree sum,
+//                     then the window's 2^(c w) doublings
+//   6 k_pip_final     sum of the W window points
+// Integer work only; step 5's doubling chain (<= 252 sequential doublings, ~1 ms) is the latency
+// floor of any variable-base MSM on this machine.
+#include "ec_dev.cuh"
+
+using namespace bp;
+
+namespace bpk {
+
+struct PipParams {
+  int c, W, half;          // window bits, windows, buckets per window
+  uint32_t K[9];           // sum_w 2^(c-1) 2^(c w)
+};
+
+__device__ __forceinline__ int pip_digit(const uint32_t sp[9], int c, int w) {
+  const int bit = c * w, k = bit >> 5, sft = bit & 31;
+  uint64_t two = (uint64_t)sp[k] | (k + 1 < 9 ? (uint64_t)sp[k + 1] << 32 : 0);
+  return (int)((two >> sft) & ((1u << c) - 1)) - (1 << (c - 1));
+}
+
+__global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t *scalars, size_t n, uint32_t *keys,
+                                                    uint32_t *counts) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t sp[9];
+  uint64_t carry = 0;
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    uint64_t t = (uint64_t)(j < 8 ? scalars[i * 8 + j] : 0u) + pp.K[j] + carry;
+    sp[j] = (uint32_t)t;
+    carry = t >> 32;
+  }
+  for (int w = 0; w < pp.W; w++) {
+    int d = pip_digit(sp, pp.c, w);
+    uint32_t key = 0xFFFFFFFFu;
+    if (d != 0) {
+      uint32_t b = (uint32_t)w * pp.half + (uint32_t)((d < 0 ? -d : d) - 1);
+      key = b | (d < 0 ? 0x80000000u : 0u);
+      atomicAdd(&counts[b], 1u);
+    }
+    keys[(size_t)w * n + i] = key;
+  }
+}
+// exclusive scan of `nb` counts into offsets[nb + 1]; cursor = copy of offsets
+__global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, size_t nb) {
+  __shared__ uint32_t part[1024];
+  const int tid = threadIdx.x;
+  size_t per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+  uint32_t s = 0;
+  for (size_t j = lo; j < hi; j++) s += counts[j];
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+    uint32_t v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  uint32_t run = tid ? part[tid - 1] : 0;
+  for (size_t j = lo; j < hi; j++) {
+    offsets[j] = run;
+    cursor[j] = run;
+    run += counts[j];
+  }
+  if (tid == 1023) offsets[nb] = part[1023];
+}
+__global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_t *keys, size_t n, uint32_t *cursor,
+                                                     uint32_t *sorted) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * (size_t)pp.W) return;
+  uint32_t key = keys[t];
+  if (key == 0xFFFFFFFFu) return;
+  uint32_t b = key & 0x7FFFFFFFu;
+  uint32_t pos = atomicAdd(&cursor[b], 1u);
+  size_t i = t % n;
+  sorted[pos] = (uint32_t)i | (key & 0x80000000u);
+}
+__global__ void __launch_bounds__(64) k_pip_bucket(const AffDev *pts, const uint32_t *offsets, const uint32_t *sorted,
+                                                   size_t nbuckets, JacRaw *buckets) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  Jac acc = jac_inf();
+  for (uint32_t e = offsets[b]; e < offsets[b + 1]; e++) {
+    uint32_t v = sorted[e];
+    Aff q = aff_load(&pts[v & 0x7FFFFFFFu]);
+    if (v & 0x80000000u) q.y = neg(q.y);
+    acc = jac_madd(acc, q);
+  }
+  raw_store(&buckets[b], acc);
+}
+// block per window: S_w = sum_{d=1}^{half} d * B_d ; out = 2^(c w) * S_w
+constexpr int PW_TPB = 128;
+__global__ void __launch_bounds__(PW_TPB) k_pip_window(PipParams pp, const JacRaw *buckets, JacRaw *win_out) {
+  __shared__ int32_t smem[27 * (PW_TPB / 2)];
+  const int w = blockIdx.x, tid = threadIdx.x;
+  const int L = pp.half / PW_TPB;                 // buckets per lane (half >= PW_TPB)
+  const JacRaw *B = buckets + (size_t)w * pp.half + (size_t)tid * L;
+  Jac run = jac_inf(), ws = jac_inf();
+  for (int j = L - 1; j >= 0; j--) {
+    run = jac_add(run, raw_load(&B[j]));
+    ws = jac_add(ws, run);                         // ws = sum (j + 1) * B_j over the segment
+  }
+  // global weight of local bucket j is (j + 1) + tid * L: add (tid * L) * run
+  unsigned mulby = (unsigned)tid * (unsigned)L;
+  Jac sm = jac_inf();
+  for (int bit = 15; bit >= 0; bit--) {
+    sm = jac_dbl(sm);
+    if ((mulby >> bit) & 1) sm = jac_add(sm, run);
+  }
+  Jac acc = block_sum<PW_TPB>(jac_add(ws, sm), smem);
+  if (tid == 0) {
+    for (int d = 0; d < pp.c * w; d++) acc = jac_dbl(acc);
+    raw_store(&win_out[w], acc);
+  }
+}
+__global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, JacRaw *out) {
+  __shared__ int32_t smem[27 * 32];
+  Jac acc = jac_inf();
+  for (int w = threadIdx.x; w < W; w += 64) acc = jac_add(acc, raw_load(&win[w]));
+  acc = block_sum<64>(acc, smem);
+  if (threadIdx.x == 0) raw_store(out, acc);
+}
+
+// window choice: minimise  n * W (bucket adds) + W * 2^(c-1) * ~3 (running sums), c in [8, 16]
+int pippenger_window(size_t n) {
+  int best = 8;
+  double bc = 1e300;
+  for (int c = 8; c <= 16; c++) {
+    double W = 252 / c + 1, cost = (double)n * W + W * (double)(1u << (c - 1)) * 3.0;
+    if (cost < bc) { bc = cost; best = c; }
+  }
+  return best;
+}
+static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t pippenger_scratch_bytes(size_t n, int c) {
+  size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = W * half;
+  return al(n * W * 4) * 2 + al((nbk + 1) * 4) * 3 + al(nbk * sizeof(JacRaw)) + al(W * sizeof(JacRaw));
+}
+void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
+  PipParams pp;
+  pp.c = c; pp.W = 252 / c + 1; pp.half = 1 << (c - 1);
+  for (int j = 0; j < 9; j++) pp.K[j] = 0;
+  for (int w = 0; w < pp.W; w++) { int bit = c * w + c - 1; pp.K[bit >> 5] |= 1u << (bit & 31); }
+  size_t W = pp.W, nbk = W * (size_t)pp.half;
+  uint8_t *p = (uint8_t *)scratch;
+  uint32_t *keys = (uint32_t *)p; p += al(n * W * 4);
+  uint32_t *sorted = (uint32_t *)p; p += al(n * W * 4);
+  uint32_t *counts = (uint32_t *)p; p += al((nbk + 1) * 4);
+  uint32_t *offsets = (uint32_t *)p; p += al((nbk + 1) * 4);
+  uint32_t *cursor = (uint32_t *)p; p += al((nbk + 1) * 4);
+  JacRaw *buckets = (JacRaw *)p; p += al(nbk * sizeof(JacRaw));
+  JacRaw *win = (JacRaw *)p;
+  (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
+  if (n) hipLaunchKernelGGL(k_pip_digits, dim3((n + 255) / 256), dim3(256), 0, st, pp, scalars, n, keys, counts);
+  hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, counts, offsets, cursor, nbk);
+  if (n) hipLaunchKernelGGL(k_pip_scatter, dim3((n * W + 255) / 256), dim3(256), 0, st, pp, keys, n, cursor, sorted);
+  hipLaunchKernelGGL(k_pip_bucket, dim3((nbk + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, nbk, buckets);
+  hipLaunchKernelGGL(k_pip_window, dim3(pp.W), dim3(PW_TPB), 0, st, pp, buckets, win);
+  hipLaunchKernelGGL(k_pip_final, dim3(1), dim3(64), 0, st, win, pp.W, out);
+}
+
+}  // namespace bpk

@@ -38,6 +38,11 @@ struct StrausArgs {
 size_t straus_scratch_bytes(int np, size_t n);
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch);
 
+// bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
+int pippenger_window(size_t n);
+size_t pippenger_scratch_bytes(size_t n, int c);
+void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch);
+
 // out[b] = sum_{i<n} in[b*n + i]
 void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, size_t n);
 

@@ -287,3 +287,49 @@ def sys_path_oracle():
     d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
     if d not in sys.path:
         sys.path.insert(0, d)
+
+
+# ------------------------------------------------------------------ large MSM (bucket method)
+def test_msm_pippenger_edge_cases(gpu):
+    sys_path_oracle()
+    """n >= 512 takes the bucket-method kernels: zero / one / n-1 scalars, identity points, duplicates,
+    P and -P pairs must come out exactly as the oracle's."""
+    import pymodel as pm
+    n = 640
+    Gp = o.gens("G", n)
+    pts = bytearray(Gp)
+    sc = bytearray(o.random_scalars(5, n))
+    for i in range(0, n, 7):
+        pts[64 * i:64 * i + 64] = bytes(64)                       # identity points
+    for i in range(1, n, 11):
+        sc[32 * i:32 * i + 32] = o.s2b([0, 1, N - 1, 2, N - 2][i % 5])
+    for i in range(3, n - 1, 50):                                  # duplicates and opposite pairs
+        pts[64 * (i + 1):64 * (i + 2)] = pts[64 * i:64 * i + 64]
+    G = o.generator()
+    negG = pm.p2b(pm.pt_neg(pm.G))
+    pts[64 * 2:64 * 3], pts[64 * 4:64 * 5] = G, negG
+    sc[32 * 2:32 * 3] = sc[32 * 4:32 * 5]
+    assert gpu.msm(bytes(sc), bytes(pts)) == o.msm(bytes(sc), bytes(pts))
+    # everything cancels
+    half = o.random_scalars(6, 300)
+    neg = b"".join(o.s2b(N - v) for v in o.unscalars(half))
+    assert gpu.msm(half + neg, Gp[:64 * 300] * 2) == bytes(64)
+
+
+@pytest.mark.parametrize("n", [512, 5000, 98347])
+def test_msm_pippenger_sizes(gpu, n):
+    """98 347 = the C4 verification MSM size.  Checked against the oracle-free identity
+    MSM(s_i, k_i G) = (sum s_i k_i) G and, for the smaller sizes, the oracle's own Pippenger."""
+    Gp, Gd = o.gens("G", n, dlogs=True)
+    sc = o.random_scalars(1234 + n, n)
+    got = gpu.msm(sc, Gp)
+    assert got == o.point_mul(o.inner_product(sc, Gd), o.generator())
+    if n <= 5000:
+        assert got == o.msm(sc, Gp, 2)
+
+
+def test_msm_batch_pippenger(gpu):
+    nb, n = 2, 700
+    Gp = o.gens("H", n)
+    sc = o.random_scalars(77, nb * n)
+    assert gpu.msm_batch(nb, n, sc, Gp * nb) == o.msm_batch(sc, Gp * nb, nb, n)
