@@ -71,9 +71,10 @@ __global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t *counts, uint3
   }
   uint32_t run = tid ? part[tid - 1] : 0;
   for (size_t j = lo; j < hi; j++) {
+    uint32_t cj = counts[j];
     offsets[j] = run;
-    cursor[j] = run;
-    run += counts[j];
+    if (cursor) cursor[j] = run;
+    run += cj;
   }
   if (tid == 1023) offsets[nb] = part[1023];
 }
@@ -88,17 +89,45 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_
   size_t i = t % n;
   sorted[pos] = (uint32_t)i | (key & 0x80000000u);
 }
-__global__ void __launch_bounds__(64) k_pip_bucket(const AffDev *pts, const uint32_t *offsets, const uint32_t *sorted,
-                                                   size_t nbuckets, JacRaw *buckets) {
+// Load balance: a bucket list is cut into tasks of at most PIP_TASK entries (the partial top window
+// has only 2^(252 mod c) non-empty buckets holding n / 2^(252 mod c) points each; equal or
+// low-entropy scalars are worse).  tcount[b] = max(1, ceil(len / PIP_TASK)); its scan gives task ids.
+constexpr uint32_t PIP_TASK = 32;
+__global__ void __launch_bounds__(256) k_pip_taskcount(const uint32_t *counts, uint32_t *tcount, size_t nb) {
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nbuckets) return;
+  if (b >= nb) return;
+  uint32_t c = counts[b];
+  tcount[b] = c ? (c + PIP_TASK - 1) / PIP_TASK : 1;
+}
+__global__ void __launch_bounds__(256) k_pip_taskdesc(const uint32_t *toffsets, size_t nb, uint32_t *task_bucket) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  for (uint32_t t = toffsets[b]; t < toffsets[b + 1]; t++) task_bucket[t] = (uint32_t)b;
+}
+__global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, const uint32_t *offsets, const uint32_t *sorted,
+                                                           const uint32_t *toffsets, const uint32_t *task_bucket, size_t nbk,
+                                                           JacRaw *partial) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= toffsets[nbk]) return;
+  uint32_t b = task_bucket[t], slice = (uint32_t)t - toffsets[b];
+  uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1], hi = lo + PIP_TASK < end ? lo + PIP_TASK : end;
   Jac acc = jac_inf();
-  for (uint32_t e = offsets[b]; e < offsets[b + 1]; e++) {
+  for (uint32_t e = lo; e < hi; e++) {
     uint32_t v = sorted[e];
     Aff q = aff_load(&pts[v & 0x7FFFFFFFu]);
     if (v & 0x80000000u) q.y = neg(q.y);
     acc = jac_madd(acc, q);
   }
+  raw_store(&partial[t], acc);
+}
+// bucket = sum of its task partials; long buckets (the rare ones) are summed by a wave-strided loop
+__global__ void __launch_bounds__(64) k_pip_merge(const uint32_t *toffsets, const JacRaw *partial, size_t nbuckets,
+                                                  JacRaw *buckets) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nbuckets) return;
+  uint32_t lo = toffsets[b], hi = toffsets[b + 1];
+  Jac acc = raw_load(&partial[lo]);
+  for (uint32_t t = lo + 1; t < hi; t++) acc = jac_add(acc, raw_load(&partial[t]));
   raw_store(&buckets[b], acc);
 }
 // block per window: S_w = sum_{d=1}^{half} d * B_d ; out = 2^(c w) * S_w
@@ -145,9 +174,11 @@ int pippenger_window(size_t n) {
   return best;
 }
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP_TASK + nbk + 1; }
 size_t pippenger_scratch_bytes(size_t n, int c) {
-  size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = W * half;
-  return al(n * W * 4) * 2 + al((nbk + 1) * 4) * 3 + al(nbk * sizeof(JacRaw)) + al(W * sizeof(JacRaw));
+  size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = W * half, mt = pip_max_tasks(n, W, nbk);
+  return al(n * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
+         al(W * sizeof(JacRaw));
 }
 void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
   PipParams pp;
@@ -161,13 +192,24 @@ void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_
   uint32_t *counts = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *offsets = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *cursor = (uint32_t *)p; p += al((nbk + 1) * 4);
+  uint32_t *tcount = (uint32_t *)p; p += al((nbk + 1) * 4);
+  uint32_t *toffsets = (uint32_t *)p; p += al((nbk + 1) * 4);
+  const size_t mt = pip_max_tasks(n, W, nbk);
+  uint32_t *task_bucket = (uint32_t *)p; p += al(mt * 4);
+  JacRaw *partial = (JacRaw *)p; p += al(mt * sizeof(JacRaw));
   JacRaw *buckets = (JacRaw *)p; p += al(nbk * sizeof(JacRaw));
   JacRaw *win = (JacRaw *)p;
   (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
   if (n) hipLaunchKernelGGL(k_pip_digits, dim3((n + 255) / 256), dim3(256), 0, st, pp, scalars, n, keys, counts);
   hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, counts, offsets, cursor, nbk);
   if (n) hipLaunchKernelGGL(k_pip_scatter, dim3((n * W + 255) / 256), dim3(256), 0, st, pp, keys, n, cursor, sorted);
-  hipLaunchKernelGGL(k_pip_bucket, dim3((nbk + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, nbk, buckets);
+  hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
+  hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, tcount, toffsets, (uint32_t *)nullptr, nbk);
+  hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
+  // the task count is data dependent: launch the upper bound, excess lanes exit on `t >= ntasks` read on device
+  hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
+                     nbk, partial);
+  hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets);
   hipLaunchKernelGGL(k_pip_window, dim3(pp.W), dim3(PW_TPB), 0, st, pp, buckets, win);
   hipLaunchKernelGGL(k_pip_final, dim3(1), dim3(64), 0, st, win, pp.W, out);
 }
