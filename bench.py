@@ -72,37 +72,48 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nb = a.batch
 
-    # ---- synthetic workload from the CPU oracle (setup, untimed; forked before any GPU init)
-    ncpu = max(1, min(os.cpu_count() or 1, 16) // max(1, min(world, 8)))
-    seed0 = 0xB0117E7 + 100003 * rank
+    # ---- synthetic workload from the CPU oracle (setup, untimed; forked before any GPU init).
+    # Every rank verifies the same synthetic batch (weak scaling): local rank 0 generates it once
+    # with the host's cores and publishes it through a file, the other ranks wait for the file.
     import pickle
-    cache = f"{a.workload_cache}.{rank}.{nb}" if a.workload_cache else None
+    import tempfile
+    ncpu = max(1, min(os.cpu_count() or 1, 32))
+    seed0 = 0xB0117E7
+    cache = f"{a.workload_cache}.{nb}" if a.workload_cache else os.path.join(
+        tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}.pkl")
     cpu = None
-    if cache and os.path.exists(cache):
-        with open(cache, "rb") as f:
-            recs = pickle.load(f)
-    else:
-      with mp.get_context("fork").Pool(ncpu) as pool:
-          recs = pool.map(_gen_one, [(i, seed0) for i in range(nb)], chunksize=max(1, nb // (4 * ncpu)))
-          if rank == 0 and world == 1 and not a.no_cpu_baseline:
-              # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
-              plen = len(recs[0][0])
-              per = (nb + ncpu - 1) // ncpu
-              chunks = []
-              for c in range(ncpu):
-                  sub = recs[c * per:(c + 1) * per]
-                  if sub:
-                      chunks.append((b"".join(r[0] for r in sub), b"".join(r[1] for r in sub), plen))
-              t0 = time.perf_counter()
-              res = pool.map(_cpu_verify_chunk, chunks)
-              wall = time.perf_counter() - t0
-              assert sum(r[0] for r in res) == nb
-              cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
-                     "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
-                               f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
-      if cache:
-        with open(cache, "wb") as f:
-          pickle.dump(recs, f)
+    if os.path.exists(cache) and (a.workload_cache or local_rank != 0):
+        pass
+    elif local_rank == 0:
+        with mp.get_context("fork").Pool(ncpu) as pool:
+            recs = pool.map(_gen_one, [(i, seed0) for i in range(nb)], chunksize=max(1, nb // (4 * ncpu)))
+            if rank == 0 and world == 1 and not a.no_cpu_baseline:
+                # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
+                plen = len(recs[0][0])
+                per = (nb + ncpu - 1) // ncpu
+                chunks = []
+                for c in range(ncpu):
+                    sub = recs[c * per:(c + 1) * per]
+                    if sub:
+                        chunks.append((b"".join(r[0] for r in sub), b"".join(r[1] for r in sub), plen))
+                t0 = time.perf_counter()
+                res = pool.map(_cpu_verify_chunk, chunks)
+                wall = time.perf_counter() - t0
+                assert sum(r[0] for r in res) == nb
+                cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
+                       "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
+                                 f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
+        tmp = cache + f".tmp{os.getpid()}"
+        with open(tmp, "wb") as f:
+            pickle.dump(recs, f)
+        os.replace(tmp, cache)
+    deadline = time.time() + 1200
+    while not os.path.exists(cache):
+        if time.time() > deadline:
+            raise RuntimeError("workload file never appeared")
+        time.sleep(0.5)
+    with open(cache, "rb") as f:
+        recs = pickle.load(f)
     n1, n2, k, m = recs[0][5]
     rp, kind, idx, coeff = recs[0][6]
     pts = b"".join(r[2] for r in recs)
@@ -159,9 +170,8 @@ def main():
             prof[name] = (pm + ms, pc + cnt)
         c.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        from mpc_bulletproof_amd import sharding
+        dt = sharding.max_over_ranks(dt)
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
 

@@ -1,0 +1,93 @@
+"""world_size-2 CPU (gloo) test of the multi-GPU plumbing: proof-level sharding, result gathering and
+the partial-point combine.  The per-rank compute is done by the CPU oracle here (no GPU in this
+container); on the GPU box the same functions run over RCCL with the HIP path."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_bits, nb, q):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import bp_helpers as bh
+    import oracle_lib as o
+    from mpc_bulletproof_amd import sharding as sh
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        recs, cap = bh.make_range_batch(n_bits, nb, tamper={1, nb - 2})   # same deterministic batch on every rank
+        lo, hi = sh.shard_bounds(nb, rank, world)
+        local_ok = [1 if o.r1cs_verify(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) == 0 else 0
+                    for proof, com in recs[lo:hi]]
+        full = sh.gather_accept_bits(local_ok, nb)
+        # combined check: each rank reduces its shard to one point; partials are all-gathered and added
+        local_pt = bytes(64)
+        for proof, com in recs[lo:hi]:
+            s = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap)
+            local_pt = o.point_add(local_pt, s.mega_check())
+            s.close()
+        total_pt = sh.combine_partial_points(local_pt, o.point_add)
+        tmax = sh.max_over_ranks(float(rank + 1))
+        q.put((rank, lo, hi, full, total_pt, tmax))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_verification_gloo_world2():
+    sys.path.insert(0, HERE)
+    import bp_helpers as bh
+    import oracle_lib as o
+    from mpc_bulletproof_amd import sharding as sh
+    n_bits, nb, world = 4, 7, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_bits, nb, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # shards partition the batch
+    assert [r[1:3] for r in res] == [sh.shard_bounds(nb, r, world) for r in range(world)]
+    assert res[0][1] == 0 and res[-1][2] == nb and res[0][2] == res[1][1]
+    # every rank sees the same, correct, accept bits
+    recs, cap = bh.make_range_batch(n_bits, nb, tamper={1, nb - 2})
+    want = [1 if o.r1cs_verify(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) == 0 else 0 for proof, com in recs]
+    assert want == [1, 0, 1, 1, 1, 0, 1]
+    assert res[0][3] == res[1][3] == want
+    # the combined point equals the single-process sum of all mega_check points
+    acc = bytes(64)
+    for proof, com in recs:
+        s = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap)
+        acc = o.point_add(acc, s.mega_check())
+        s.close()
+    assert res[0][4] == res[1][4] == acc and acc != bytes(64)
+    assert res[0][5] == res[1][5] == 2.0
+
+
+def test_shard_bounds_cover_everything():
+    sys.path.insert(0, ROOT)
+    from mpc_bulletproof_amd import sharding as sh
+    for total in (0, 1, 7, 8, 1024, 1025):
+        for world in (1, 2, 3, 8):
+            b = [sh.shard_bounds(total, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == total
+            assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            assert max(h - l for l, h in b) - min(h - l for l, h in b) <= 1
