@@ -63,6 +63,7 @@ def main():
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-combined", action="store_true", help="skip the secondary combined-batch-check measurement")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
     a = ap.parse_args()
@@ -175,6 +176,37 @@ def main():
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
 
+    # ---- secondary: combined batch check (sum_p rho_p * check_p, one point per GPU; RCCL all-gather of
+    # the 64-byte partials + local add).  Not the headline (the reference verifies proof by proof).
+    comb = None
+    if not a.no_combined:
+        d_rho = gpu.to_device(o.random_scalars(0xC0B1 + rank, nb))
+        d_parts = [gpu.malloc(64) for _ in ctxs]
+
+        def cstep(i):
+            ctxs[i % len(ctxs)].r1cs_verify_combined_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_rho, d_parts[i % len(ctxs)])
+
+        for i in range(len(ctxs)):
+            cstep(i)
+        sync_all()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            cstep(i)
+        sync_all()
+        fence()
+        cdt = time.perf_counter() - t0
+        part = ctxs[0].download(d_parts[0], 64)
+        if world > 1:
+            from mpc_bulletproof_amd import sharding
+            cdt = sharding.max_over_ranks(cdt)
+            ones = o.s2b(1)
+            part = sharding.combine_partial_points(part, lambda x, y: gpu.msm(ones + ones, x + y))
+        assert part == bytes(64), "combined batch check must be the identity for valid proofs"
+        comb = {"value": world * nb * a.steps / cdt, "unit": "verifications/s", "ms_per_step": cdt / a.steps * 1e3,
+                "note": "sum_p rho_p*mega_check_p == identity (single accept bit per batch; one fixed-base MSM + one "
+                        f"{nb * (11 + m + 2 * k)}-term bucket-method MSM per GPU; partial points all-gathered over RCCL when n_gpus > 1)"}
+
     if rank == 0:
         nvar = 11 + m + 2 * k
         nterms = 13 + m + 2 * (1 << k) + 2 * k
@@ -203,6 +235,7 @@ def main():
                              "peak": MAD_PEAK_TOPS, "unit": "Tmad/s", "frac": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
+            "combined_batch_check": comb,
         }
         print(json.dumps(out))
     if world > 1:

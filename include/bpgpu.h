@@ -181,6 +181,20 @@ int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
                                 const void *challenges_dev, void *ok_dev, void *mega_dev,
                                 void *msm_scalars_dev);
 
+/* Combined batch check (NOT a reference API -- the reference verifies proof by proof; this is
+ * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random
+ * weights rho (nb x 32 B, e.g. from a CSPRNG) computes  sum_p rho_p * mega_check_p  as ONE point:
+ * one fixed-base MSM over the generators with scalars sum_p rho_p s_{p,g} plus one bucket-method MSM over
+ * the nb*(11+m+2k) proof points.  All nb proofs are valid iff the point (summed over all GPUs: all-gather
+ * of the 64-byte partials over RCCL, then a local add) is the identity.  Same input layout as
+ * bpgpu_r1cs_verify_batch. */
+int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
+                               size_t n1, size_t k, const uint8_t *points, const uint8_t *scalars,
+                               const uint8_t *challenges, const uint8_t *rho, uint8_t partial_xy[64]);
+int bpgpu_r1cs_verify_combined_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
+                                   size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
+                                   const void *challenges_dev, const void *rho_dev, void *partial_xy_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -724,6 +724,89 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
 }
 
 
+/* ---------------------------------------------------------------- combined batch check
+ * sum_p rho_p * mega_check_p as ONE point: the generator terms collapse to a single fixed-base MSM with
+ * scalars sum_p rho_p * s_{p,g}; the proof-specific points go through one bucket-method MSM of
+ * nb * (11 + m + 2k) terms.  All proofs are valid iff the (all-GPU) sum of the partial points is the
+ * identity, up to the 2^-252 soundness of the random weights.  Not a reference API: offered
+ * beside the per-proof mode for verifier services; the per-proof mode stays the parity path. */
+static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                  size_t k, const void *points, const void *scalars, const void *challenges,
+                                  const void *rho, void *partial_xy) {
+  if (k >= 32) return BPGPU_E_LEN;
+  size_t np = (size_t)1 << k, n = c->n, m = c->m;
+  if (n > np || n1 > n || (np > 1 && n <= np / 2 && n != 0)) return BPGPU_E_LEN;
+  if (np > g->cap) return BPGPU_E_GENS;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t nvar = 11 + m + 2 * k, nfix = 2 + 2 * np, tot = nb * nvar;
+  void *dpts, *dfix, *dvar, *dzp, *dfsum, *dtwo, *dsum, *dpip;
+  int cw = pippenger_window(tot);
+  CK(ws_get(ctx, 7, tot * sizeof(AffDev), &dpts));
+  CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
+  CK(ws_get(ctx, 9, tot * 32, &dvar));
+  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 10, nfix * 32, &dfsum));
+  CK(ws_get(ctx, 11, 2 * sizeof(JacRaw), &dtwo));
+  CK(ws_get(ctx, 15, sizeof(JacRaw), &dsum));
+  CK(ws_get(ctx, 14, pippenger_scratch_bytes(tot, cw), &dpip));
+  VerifyDims d{nb, n1, n, np, k, m};
+  CK(flag_reset(ctx));
+  scalars_check(ctx->st, (const Words8 *)scalars, nb * 5, ctx->d_flag);
+  scalars_check(ctx->st, (const Words8 *)challenges, nb * (6 + k), ctx->d_flag);
+  scalars_check(ctx->st, (const Words8 *)rho, nb, ctx->d_flag);
+  verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
+                 (Words8 *)dvar, nullptr, (int32_t *)dzp, ctx->d_flag);
+  // generator part on stream 2: weighted column sums, then one fixed-base MSM
+  HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
+  HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
+  sc_weighted_colsum(ctx->st2, nb, nfix, (const Words8 *)dfix, (const Words8 *)rho, (Words8 *)dfsum);
+  CK(msm_gens_dev(ctx, g, 1, np, (const uint32_t *)dfsum, (JacRaw *)dtwo, ctx->st2));
+  HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
+  // proof-specific points on stream 1: scale by rho, bucket-method MSM
+  points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, tot, ctx->d_flag);
+  sc_scale_rows(ctx->st, nb, nvar, (Words8 *)dvar, (const Words8 *)rho);
+  pippenger(ctx->st, (const AffDev *)dpts, (const uint32_t *)dvar, tot, cw, (JacRaw *)dtwo + 1, dpip);
+  HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
+  segmented_sum(ctx->st, (const JacRaw *)dtwo, (JacRaw *)dsum, 1, 2);
+  jac_to_boundary(ctx->st, (const JacRaw *)dsum, (Words8 *)partial_xy, 1);
+  return launch_ok(ctx);
+}
+int bpgpu_r1cs_verify_combined_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                   size_t k, const void *points, const void *scalars, const void *challenges,
+                                   const void *rho, void *partial_xy_dev) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !rho)) || !partial_xy_dev) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_combined_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, rho, partial_xy_dev);
+}
+int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                               size_t k, const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges,
+                               const uint8_t *rho, uint8_t partial_xy[64]) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !rho)) || !partial_xy) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) { memset(partial_xy, 0, 64); return BPGPU_OK; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t m = c->m, nvar = 11 + m + 2 * k;
+  void *dP, *dS, *dC, *dR, *dout;
+  CK(ws_get(ctx, 0, nb * nvar * 64, &dP));
+  CK(ws_get(ctx, 1, nb * 5 * 32, &dS));
+  CK(ws_get(ctx, 2, nb * (6 + k) * 32, &dC));
+  CK(ws_get(ctx, 3, nb * 32, &dR));
+  CK(ws_get(ctx, 4, 64, &dout));
+  CK(h2d(ctx, dP, points, nb * nvar * 64));
+  CK(h2d(ctx, dS, scalars, nb * 5 * 32));
+  CK(h2d(ctx, dC, challenges, nb * (6 + k) * 32));
+  CK(h2d(ctx, dR, rho, nb * 32));
+  CK(verify_combined_locked(ctx, g, c, nb, n1, k, dP, dS, dC, dR, dout));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, partial_xy, dout, 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
 /* ---------------------------------------------------------------- IPP prover session */
 static void ipp_free_all(bpgpu_ipp *s) {
   for (int i = 0; i < 2; i++) { hipFree(s->a[i]); hipFree(s->b[i]); hipFree(s->G[i]); hipFree(s->H[i]); }

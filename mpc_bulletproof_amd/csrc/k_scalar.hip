@@ -214,6 +214,39 @@ void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, 
   hipLaunchKernelGGL(k_fold_scalars_batched, dim3((h + 255) / 256, nb), dim3(256), 0, st, h, u, u_inv, a, b, a_out, b_out);
 }
 
+// combined batch check helpers: per-proof random weights rho_p
+__global__ void __launch_bounds__(256) k_sc_scale_rows(size_t cnt, Words8 *x, const Words8 *w) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= cnt) return;
+  store_plain(&x[p * cnt + i], mul(load_plain(&x[p * cnt + i]), load_plain(&w[p])));
+}
+void sc_scale_rows(hipStream_t st, size_t nb, size_t cnt, Words8 *x, const Words8 *w) {
+  if (!nb || !cnt) return;
+  hipLaunchKernelGGL(k_sc_scale_rows, dim3((cnt + 255) / 256, nb), dim3(256), 0, st, cnt, x, w);
+}
+__global__ void __launch_bounds__(256) k_sc_weighted_colsum(size_t nb, size_t cnt, const Words8 *x, const Words8 *w, Words8 *out) {
+  __shared__ int32_t sm[NL * 4];
+  size_t i = blockIdx.x;
+  Fn acc = fe_zero<FN>();
+  int c = 0;
+  for (size_t p = threadIdx.x; p < nb; p += 256) {
+    acc = add(acc, mul(load_plain(&x[p * cnt + i]), load_plain(&w[p])));
+    if ((++c & 15) == 0) acc = fn_reduce(acc);
+  }
+  acc = wave_sum(fn_reduce(acc));
+  if ((threadIdx.x & 63) == 0) raw_put(sm + (threadIdx.x >> 6) * NL, acc);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Fn t = raw_get(sm);
+    for (int wv = 1; wv < 4; wv++) t = add(t, raw_get(sm + wv * NL));
+    store_plain(&out[i], t);
+  }
+}
+void sc_weighted_colsum(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, const Words8 *w, Words8 *out) {
+  if (!cnt) return;
+  hipLaunchKernelGGL(k_sc_weighted_colsum, dim3(cnt), dim3(256), 0, st, nb, cnt, x, w, out);
+}
+
 // inner_product_proof.rs:280-309.  One block; lane 0 inverts (Montgomery trick over the k challenges);
 // s_i = allinv * prod_{b : bit b of i} u_sq[(k-1)-b]  (closed form of the reference's induction :298-307)
 __global__ void __launch_bounds__(256) k_verification_scalars(const Words8 *ch, int k, size_t n, Words8 *u_sq,

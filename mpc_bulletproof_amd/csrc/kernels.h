@@ -81,6 +81,10 @@ void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size
 void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, const Words8 *u_inv, const Words8 *a,
                           const Words8 *b, Words8 *a_out, Words8 *b_out);
 
+// x[p][i] *= w[p]  (in place, nb x cnt) ; out[i] = sum_p w[p] * x[p][i]
+void sc_scale_rows(hipStream_t st, size_t nb, size_t cnt, Words8 *x, const Words8 *w);
+void sc_weighted_colsum(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, const Words8 *w, Words8 *out);
+
 // column-major constraint weights: for output o in [0, 3n + m + 1): terms col_ptr[o]..col_ptr[o+1]
 // outputs ordered wL[0..n) wR[0..n) wO[0..n) wV[0..m) wc
 struct CircuitDev {

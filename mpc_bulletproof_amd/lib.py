@@ -13,7 +13,8 @@ SYMBOLS = [
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_prover_destroy",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
-    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev",
+    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
+    "bpgpu_r1cs_verify_combined_dev",
 ]
 
 
@@ -268,6 +269,19 @@ class BpGpu:
                                               _buf(points), _buf(scalars), _buf(challenges), ok, mega, full))
         return (list(ok)[:nb], bytes(mega)[:64 * nb] if want_mega else None,
                 bytes(full)[:32 * nb * nterms] if want_scalars else None)
+
+    def r1cs_verify_combined(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, rho):
+        nvar = 11 + m + 2 * k
+        if len(points) != 64 * nb * nvar or len(scalars) != 160 * nb or len(challenges) != 32 * nb * (6 + k) or len(rho) != 32 * nb:
+            raise BpGpuError(E_LEN, "r1cs_verify_combined: length mismatch")
+        o = _out(64)
+        self._ck(_lib.bpgpu_r1cs_verify_combined(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                 _buf(points), _buf(scalars), _buf(challenges), _buf(rho), o))
+        return bytes(o)
+
+    def r1cs_verify_combined_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_rho, d_out):
+        self._ck(_lib.bpgpu_r1cs_verify_combined_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                     d_points, d_scalars, d_challenges, d_rho, d_out))
 
     def r1cs_verify_batch_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_ok, d_mega=None,
                               d_full=None):

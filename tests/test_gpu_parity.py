@@ -333,3 +333,30 @@ def test_msm_batch_pippenger(gpu):
     Gp = o.gens("H", n)
     sc = o.random_scalars(77, nb * n)
     assert gpu.msm_batch(nb, n, sc, Gp * nb) == o.msm_batch(sc, Gp * nb, nb, n)
+
+
+# ------------------------------------------------------------------ combined batch check
+@pytest.mark.parametrize("tamper", [set(), {3}])
+def test_combined_batch_check(gpu, tamper):
+    """sum_p rho_p * mega_check_p as one point: equals the oracle's weighted sum of the per-proof
+    mega_check points (identity iff every proof is valid)."""
+    n_bits, nb = 8, 9
+    recs, cap = bh.make_range_batch(n_bits, nb, tamper=tamper)
+    sessions = [o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+    s0 = sessions[0]
+    rp, kind, idx, coeff = s0.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        pts = sc = ch = b""
+        for (proof, com), s in zip(recs, sessions):
+            k, p, q = bh.verify_inputs(proof, com)
+            pts, sc, ch = pts + p, sc + q, ch + s.challenges()
+        rho = o.random_scalars(4242, nb)
+        got = gpu.r1cs_verify_combined(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, rho)
+        want = o.msm(rho, b"".join(s.mega_check() for s in sessions), 1)
+        assert got == want
+        assert (got == bytes(64)) == (not tamper)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
