@@ -278,4 +278,90 @@ template <class F> BP_HD Fe<F> inv(const Fe<F> &x) {
   }
 }
 
+
+// ---- binary extended GCD inversion on plain 256-bit words (HAC 14.61 for an odd modulus) ----------
+// ~250 subtract steps + ~500 halvings of 8-word integers (~20 k instructions) instead of the ~380
+// Montgomery multiplications (~125 k instructions) of Fermat: the one serial dependency chain per proof
+// in the verifier's scalar assembly (y^-1 and u_j^-1, r1cs/verifier.rs:468, inner_product_proof.rs:283).
+// Variable time (verification handles public data only).  a in [1, m); returns a^-1 mod m; 0 -> 0.
+BP_HD bool w8_is_even(const uint32_t a[8]) { return (a[0] & 1u) == 0; }
+BP_HD bool w8_is_one(const uint32_t a[8]) {
+  uint32_t o = a[0] ^ 1u;
+#pragma unroll
+  for (int j = 1; j < 8; j++) o |= a[j];
+  return o == 0;
+}
+BP_HD bool w8_is_zero(const uint32_t a[8]) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o |= a[j];
+  return o == 0;
+}
+BP_HD bool w8_geq(const uint32_t a[8], const uint32_t b[8]) {
+  bool ge = true, decided = false;
+#pragma unroll
+  for (int j = 7; j >= 0; j--) {
+    bool l = a[j] < b[j], g = a[j] > b[j];
+    ge = decided ? ge : !l;
+    decided = decided || l || g;
+  }
+  return ge;
+}
+BP_HD uint32_t w8_add(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { c += (uint64_t)a[j] + b[j]; r[j] = (uint32_t)c; c >>= 32; }
+  return (uint32_t)c;
+}
+BP_HD void w8_sub(uint32_t r[8], const uint32_t a[8], const uint32_t b[8]) {
+  int64_t br = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { int64_t d = (int64_t)a[j] - (int64_t)b[j] + br; r[j] = (uint32_t)d; br = d >> 32; }
+}
+BP_HD void w8_shr1(uint32_t a[8], uint32_t top) {
+#pragma unroll
+  for (int j = 0; j < 7; j++) a[j] = (a[j] >> 1) | (a[j + 1] << 31);
+  a[7] = (a[7] >> 1) | (top << 31);
+}
+template <class F> BP_HD void w8_inv_mod(uint32_t out[8], const uint32_t a[8]) {
+  uint32_t M[8];
+  if constexpr (F::sparse) { constexpr uint32_t C[8] = FP_MOD_W; for (int j = 0; j < 8; j++) M[j] = C[j]; }
+  else { constexpr uint32_t C[8] = FN_MOD_W; for (int j = 0; j < 8; j++) M[j] = C[j]; }
+  uint32_t u[8], v[8], x1[8], x2[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { u[j] = a[j]; v[j] = M[j]; x1[j] = j == 0; x2[j] = 0; }
+  if (w8_is_zero(u)) { for (int j = 0; j < 8; j++) out[j] = 0; return; }
+  for (int guard = 0; guard < 1100 && !w8_is_one(u) && !w8_is_one(v); guard++) {
+    if (w8_is_even(u)) {
+      w8_shr1(u, 0);
+      uint32_t top = 0;
+      if (!w8_is_even(x1)) top = w8_add(x1, x1, M);
+      w8_shr1(x1, top);
+    } else if (w8_is_even(v)) {
+      w8_shr1(v, 0);
+      uint32_t top = 0;
+      if (!w8_is_even(x2)) top = w8_add(x2, x2, M);
+      w8_shr1(x2, top);
+    } else if (w8_geq(u, v)) {
+      w8_sub(u, u, v);
+      if (w8_geq(x1, x2)) w8_sub(x1, x1, x2);
+      else { uint32_t t[8]; w8_sub(t, x2, x1); w8_sub(x1, M, t); }
+    } else {
+      w8_sub(v, v, u);
+      if (w8_geq(x2, x1)) w8_sub(x2, x2, x1);
+      else { uint32_t t[8]; w8_sub(t, x1, x2); w8_sub(x2, M, t); }
+    }
+  }
+  const bool pick_u = w8_is_one(u);
+#pragma unroll
+  for (int j = 0; j < 8; j++) out[j] = pick_u ? x1[j] : x2[j];
+}
+// Montgomery-form inverse through the word-level GCD: x = aR -> a = x/R -> a^-1 -> a^-1 R
+template <class F> BP_HD Fe<F> inv_gcd(const Fe<F> &x) {
+  uint32_t w[8], iw[8];
+  pack(w, from_mont(x));
+  w8_inv_mod<F>(iw, w);
+  return to_mont(unpack<F>(iw));
+}
+
 }  // namespace bp

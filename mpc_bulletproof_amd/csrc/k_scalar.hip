@@ -423,8 +423,8 @@ constexpr int VS_TPB = 128;
 __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
                                                            const Words8 *proof_scalars, Words8 *fixed_sc,
                                                            Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all) {
-  __shared__ int32_t sm[(40 + 2 * 32) * NL + NL * (VS_TPB / 64)];
-  // sm slots (NL ints each): 0 y_inv, 1 allinv, 2 delta, 3 wc, 8.. u_sq[k], 40.. u_inv_sq[k], tail: wave partials
+  __shared__ int32_t sm[(40 + 2 * 32) * NL + 2 * NL * (VS_TPB / 64)];
+  // sm slots (NL ints each): 0 y_inv, 1 allinv, 8.. u_sq[k], 40.. u_inv_sq[k], tail: per-wave partials (delta, wc)
   int32_t *s_usq = sm + 8 * NL, *s_uinvsq = sm + 40 * NL, *s_part = sm + (40 + 64) * NL;
   const size_t p = blockIdx.x;
   const int tid = threadIdx.x;
@@ -435,12 +435,12 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
 
   if (tid == 64) {   // inversions: y^-1 and u_j^-1 (verifier.rs:468, inner_product_proof.rs:283)
-    Fn pref[33], val[33];
+    Fn pref[33], val[33];   // Montgomery's trick: one (binary-GCD) inversion for the 1 + k values
     Fn acc = fe_one<FN>();
     val[0] = y;
     for (size_t i = 0; i < k; i++) val[1 + i] = load_plain(&ch[6 + i]);
     for (size_t i = 0; i <= k; i++) { pref[i] = acc; acc = mul(acc, val[i]); }
-    Fn ai = inv(acc);
+    Fn ai = inv_gcd(acc);
     Fn allinv = fe_one<FN>();
     for (int i = (int)k; i >= 0; i--) {
       Fn vi = mul(ai, pref[i]);
@@ -459,8 +459,9 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   __syncthreads();
   Fn y_inv = raw_get(sm + 0 * NL), allinv = raw_get(sm + 1 * NL);
   Fn a = load_plain(&ps[3]), b = load_plain(&ps[4]);
-  const size_t nterms = 13 + m + 2 * np + 2 * k;
+  const size_t nvar = 11 + m + 2 * k, nterms = 13 + m + 2 * np + 2 * k;
   Words8 *fx = fixed_sc + p * (2 + 2 * np);
+  Words8 *vs = var_sc + p * nvar;
   Words8 *full = full_sc ? full_sc + p * nterms : nullptr;
   const size_t off_g = 13 + m, off_h = 13 + m + np;   // positions in verifier.rs:517-532 order
 
@@ -492,49 +493,55 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
     store_plain(&fx[2 + np + i], h);
     if (full) { store_plain(&full[off_g + i], g); store_plain(&full[off_h + i], h); }
   }
-  dpart = wave_sum(fn_reduce(dpart));
-  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, fn_reduce(dpart));
-  __syncthreads();
-  if (tid == 0) {
-    Fn delta = raw_get(s_part);
-    for (int w = 1; w < VS_TPB / 64; w++) delta = add(delta, raw_get(s_part + w * NL));
-    Fn wc = flatten_column(c, 3 * n + m, zpow);
-    Fn w_ch = load_plain(&ch[4]), r = load_plain(&ch[5]);
-    Fn t_x = load_plain(&ps[0]), t_xb = load_plain(&ps[1]), e_b = load_plain(&ps[2]);
-    Fn xx = sqr(x), rxx = mul(r, xx), xxx = mul(x, xx);
-    Words8 *vs = var_sc + p * (11 + m + 2 * k);
-    auto put = [&](size_t vpos, size_t fpos, const Fn &v) {
-      store_plain(&vs[vpos], v);
-      if (full) store_plain(&full[fpos], v);
-    };
-    put(0, 0, x); put(1, 1, xx); put(2, 2, xxx);                              // A_I1 A_O1 S1
-    put(3, 3, mul(u, x)); put(4, 4, mul(u, xx)); put(5, 5, mul(u, xxx));      // A_I2 A_O2 S2
-    Fn rx = mul(r, x);
-    put(6 + m, 6 + m, rx);                                                    // T_1: r x
-    put(7 + m, 7 + m, mul(rxx, x));                                           // T_3: r x^3
-    put(8 + m, 8 + m, mul(rxx, xx));                                          // T_4
-    put(9 + m, 9 + m, mul(rxx, xxx));                                         // T_5
-    put(10 + m, 10 + m, mul(mul(rxx, xx), xx));                               // T_6
-    // B: w (t_x - a b) + r (xx (wc + delta) - t_x) ; B_blinding: -e_blinding - r t_x_blinding
-    Fn sB = add(mul(w_ch, sub(t_x, mul(a, b))), mul(r, sub(mul(xx, add(wc, delta)), t_x)));
-    Fn sBb = neg(add(e_b, mul(r, t_xb)));
-    store_plain(&fx[0], sB);
-    store_plain(&fx[1], sBb);
-    if (full) { store_plain(&full[11 + m], sB); store_plain(&full[12 + m], sBb); }
-    for (size_t j = 0; j < k; j++) {
-      put(11 + m + j, 13 + m + 2 * np + j, raw_get(s_usq + j * NL));          // L_j: u_j^2
-      put(11 + m + k + j, 13 + m + 2 * np + k + j, raw_get(s_uinvsq + j * NL)); // R_j: u_j^-2
+  // w_c: the `One` column, its terms strided over the block (verifier.rs:352-354)
+  Fn wcp = fe_zero<FN>();
+  {
+    const size_t o = 3 * n + m;
+    int cnt = 0;
+    for (uint32_t t = c.col_ptr[o] + tid; t < c.col_ptr[o + 1]; t += VS_TPB) {
+      uint32_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = c.coeff[t].w[j];
+      wcp = add(wcp, mul(unpack<FN>(w), raw_get(zpow + (size_t)c.row[t] * NL)));
+      if ((++cnt & 15) == 0) wcp = fn_reduce(wcp);
     }
-    raw_put(sm + 2 * NL, rxx);
+  }
+  dpart = wave_sum(fn_reduce(dpart));
+  wcp = wave_sum(fn_reduce(wcp));
+  if ((tid & 63) == 0) {
+    raw_put(s_part + (tid >> 6) * 2 * NL, fn_reduce(dpart));
+    raw_put(s_part + ((tid >> 6) * 2 + 1) * NL, fn_reduce(wcp));
   }
   __syncthreads();
-  {   // V_j: wV_j * r x^2 (verifier.rs:523)
-    Fn rxx = raw_get(sm + 2 * NL);
-    Words8 *vs = var_sc + p * (11 + m + 2 * k);
-    for (size_t j = tid; j < m; j += VS_TPB) {
-      Fn v = mul(flatten_column(c, 3 * n + j, zpow), rxx);
-      store_plain(&vs[6 + j], v);
-      if (full) store_plain(&full[6 + j], v);
+  // one lane per remaining output scalar (verifier.rs:508-532)
+  if ((size_t)tid < nvar + 2 || m > (size_t)VS_TPB) {
+    Fn delta = raw_get(s_part), wc = raw_get(s_part + NL);
+    for (int w = 1; w < VS_TPB / 64; w++) { delta = add(delta, raw_get(s_part + w * 2 * NL)); wc = add(wc, raw_get(s_part + (w * 2 + 1) * NL)); }
+    wc = neg(wc);
+    Fn r = load_plain(&ch[5]);
+    Fn xx = sqr(x), rxx = mul(r, xx), xxx = mul(x, xx);
+    for (size_t v = tid; v < nvar + 2; v += VS_TPB) {
+      Fn val;
+      size_t fpos = v;
+      if (v < 3) val = v == 0 ? x : (v == 1 ? xx : xxx);                                  // A_I1 A_O1 S1
+      else if (v < 6) val = mul(u, v == 3 ? x : (v == 4 ? xx : xxx));                    // A_I2 A_O2 S2
+      else if (v < 6 + m) val = mul(flatten_column(c, 3 * n + (v - 6), zpow), rxx);      // V_j: wV_j r x^2
+      else if (v < 11 + m) {                                                              // T_1 T_3 T_4 T_5 T_6
+        size_t ti = v - 6 - m;
+        val = ti == 0 ? mul(r, x) : ti == 1 ? mul(rxx, x) : ti == 2 ? mul(rxx, xx) : ti == 3 ? mul(rxx, xxx) : mul(mul(rxx, xx), xx);
+      } else if (v < 11 + m + k) { val = raw_get(s_usq + (v - 11 - m) * NL); fpos = 13 + m + 2 * np + (v - 11 - m); }           // L_j: u_j^2
+      else if (v < nvar) { val = raw_get(s_uinvsq + (v - 11 - m - k) * NL); fpos = 13 + m + 2 * np + k + (v - 11 - m - k); }     // R_j: u_j^-2
+      else if (v == nvar) {   // B: w (t_x - a b) + r (xx (wc + delta) - t_x)
+        Fn w_ch = load_plain(&ch[4]), t_x = load_plain(&ps[0]);
+        val = add(mul(w_ch, sub(t_x, mul(a, b))), mul(r, sub(mul(xx, add(wc, delta)), t_x)));
+        fpos = 11 + m;
+      } else {                // B_blinding: -e_blinding - r t_x_blinding
+        val = neg(add(load_plain(&ps[2]), mul(r, load_plain(&ps[1]))));
+        fpos = 12 + m;
+      }
+      if (v < nvar) store_plain(&vs[v], val);
+      else store_plain(&fx[v - nvar], val);
+      if (full) store_plain(&full[fpos], val);
     }
   }
 }

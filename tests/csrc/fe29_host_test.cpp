@@ -33,6 +33,7 @@ template <class F> static int binop(int op, const uint8_t *a, const uint8_t *b, 
     case 7: r = mul(sub(x, y), add(x, y)); break;                  // x^2 - y^2
     case 8: r = sqr(sub(sub(x, y), y)); break;                     // (x - 2y)^2
     case 9: r = mul(norm(add_nr(add_nr(x, x), x)), sub(y, x)); break;  // 3x (y - x)
+    case 10: r = inv_gcd(x); break;
     default: return -2;
   }
   store_fe(out, r);
