@@ -24,6 +24,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_BITS = 64
 LABEL = b"RangeProofTest"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+# HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+# runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
+TRAFFIC_BYTES_PER_LAUNCH = {}
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
 
@@ -53,13 +56,16 @@ def _cpu_verify_chunk(args):
 
 
 def main():
+    # deep step pipelining needs hardware queues (ROCm default: 4) and is better with one stream per context
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "8")))
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "4")),
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "16")))
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -230,7 +236,10 @@ def main():
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
             "roofline": {"bound": "hbm", "kernel": {"straus": "k_straus<1,128>", "fixed_msm": "k_fixed_msm", "verify_scalars": "k_verify_scalars"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "avg_launch_ms": avg_s * 1e3, "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "avg_launch_ms": avg_s * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
+                         "note": "avg launch duration is measured with steps overlapping on the GPU (steps_in_flight); "
+                                 "solo launch times are in DESIGN.md.  The path is VALU-integer bound: see roofline_int"},
             "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "achieved": fpmul * 94 / avg_s / 1e12 if avg_s else None,
                              "peak": MAD_PEAK_TOPS, "unit": "Tmad/s", "frac": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},

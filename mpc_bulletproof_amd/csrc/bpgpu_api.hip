@@ -178,8 +178,11 @@ int bpgpu_create(int device, bpgpu_ctx **out) {
   bpgpu_ctx *ctx = new (std::nothrow) bpgpu_ctx();
   if (!ctx) return BPGPU_E_OOM;
   ctx->device = device;
+  // BPGPU_SINGLE_STREAM=1: one stream per context (deeply pipelined callers overlap ACROSS contexts and
+  // hardware queues are a limited resource: GPU_MAX_HW_QUEUES, 4 by default)
+  const bool single = getenv("BPGPU_SINGLE_STREAM") && atoi(getenv("BPGPU_SINGLE_STREAM")) != 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking) != hipSuccess ||
+      (single ? ((ctx->st2 = ctx->st), hipSuccess) : hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking)) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess ||
       hipMalloc((void **)&ctx->d_flag, sizeof(int)) != hipSuccess) {
@@ -198,8 +201,8 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   hipFree(ctx->d_flag);
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev2);
+  if (ctx->st2 != ctx->st) hipStreamDestroy(ctx->st2);
   hipStreamDestroy(ctx->st);
-  hipStreamDestroy(ctx->st2);
   delete ctx;
 }
 const char *bpgpu_last_error(bpgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
@@ -650,7 +653,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
   CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
   void *dstr;
-  CK(straus_ws(ctx, 1, nb * nvar, &dstr));
+  CK(straus_ws(ctx, 4, nb * nvar, &dstr));
   VerifyDims d{nb, n1, n, np, k, m};
   CK(flag_reset(ctx));
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
@@ -672,17 +675,34 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     ProfScope ps(ctx, 2, ctx->st);
     points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
   }
-  StrausArgs a{};
-  a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
-  a.sc[0] = (uint32_t *)dvar; a.sc_stride[0] = 8;
+  // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp))
+  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 2;
+  const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
+  const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
+  const size_t nres = lanes + rem;
   {
     ProfScope ps(ctx, 3, ctx->st);
-    straus(ctx->st, 1, a, (JacRaw *)dvres, nb * nvar, dstr);
+    if (lanes) {
+      StrausArgs a{};
+      for (int j = 0; j < vnp; j++) {
+        a.pts[j] = (AffDev *)dpts + j * lanes; a.pt_stride[j] = 1; a.pt_outer[j] = nvar;
+        a.sc[j] = (uint32_t *)dvar + j * lanes * 8; a.sc_stride[j] = 8; a.sc_outer[j] = nvar * 8;
+      }
+      a.inner = lanes; a.out_outer = nres;
+      straus(ctx->st, vnp, a, (JacRaw *)dvres, nb * lanes, dstr);
+    }
+    if (rem) {
+      StrausArgs a{};
+      a.pts[0] = (AffDev *)dpts + vnp * lanes; a.pt_stride[0] = 1; a.pt_outer[0] = nvar;
+      a.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; a.sc_stride[0] = 8; a.sc_outer[0] = nvar * 8;
+      a.inner = rem; a.out_outer = nres;
+      straus(ctx->st, 1, a, (JacRaw *)dvres + lanes, nb * rem, dstr);
+    }
   }
   HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
   {
     ProfScope ps(ctx, 4, ctx->st);
-    verify_finalize(ctx->st, (JacRaw *)dvres, nvar, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
+    verify_finalize(ctx->st, (JacRaw *)dvres, nres, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
   }
   return launch_ok(ctx);
 }

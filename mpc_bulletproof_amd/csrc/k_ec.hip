@@ -51,27 +51,21 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
   constexpr int W = num_windows<SW>();
 #pragma unroll 1
   for (int w = W - 1; w >= 0; w--) {
-    // issue the table reads of this window before its doublings so L2 latency hides under them
-    Jac q[NP];
-    int dg[NP];
-#pragma unroll
-    for (int j = 0; j < NP; j++) {
-      dg[j] = recode_digit<SW>(sp[j], w);
-      int e = (dg[j] < 0 ? -dg[j] : dg[j]) - 1;
-      if (e < 0) e = 0;
-      const int32_t *src = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
-#pragma unroll
-      for (int t = 0; t < NL; t++) { q[j].X.v[t] = src[t * TPB]; q[j].Y.v[t] = src[(NL + t) * TPB]; q[j].Z.v[t] = src[(2 * NL + t) * TPB]; }
-    }
     if (w != W - 1) {
 #pragma unroll 1
       for (int d = 0; d < SW; d++) acc = jac_dbl(acc);
     }
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < NP; j++) {
-      if (dg[j] != 0) {
-        if (dg[j] < 0) q[j].Y = neg(q[j].Y);
-        acc = jac_add(acc, q[j]);
+      int dg = recode_digit<SW>(sp[j], w);
+      if (dg != 0) {
+        int e = (dg < 0 ? -dg : dg) - 1;
+        const int32_t *src = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
+        Jac q;
+#pragma unroll
+        for (int t = 0; t < NL; t++) { q.X.v[t] = src[t * TPB]; q.Y.v[t] = src[(NL + t) * TPB]; q.Z.v[t] = src[(2 * NL + t) * TPB]; }
+        if (dg < 0) q.Y = neg(q.Y);
+        acc = jac_add(acc, q);
       }
     }
   }
@@ -88,8 +82,14 @@ size_t straus_scratch_bytes(int np, size_t n) {
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch) {
   if (!n) return;
   constexpr int TPB = 64;
-  if (np == 1) hipLaunchKernelGGL((k_straus<1, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
-  else hipLaunchKernelGGL((k_straus<2, TPB>), dim3((n + TPB - 1) / TPB), dim3(TPB), 0, st, a, out, n, (int32_t *)scratch);
+  dim3 grid((n + TPB - 1) / TPB), blk(TPB);
+  switch (np) {
+    case 1: hipLaunchKernelGGL((k_straus<1, TPB>), grid, blk, 0, st, a, out, n, (int32_t *)scratch); break;
+    case 2: hipLaunchKernelGGL((k_straus<2, TPB>), grid, blk, 0, st, a, out, n, (int32_t *)scratch); break;
+    case 3: hipLaunchKernelGGL((k_straus<3, TPB>), grid, blk, 0, st, a, out, n, (int32_t *)scratch); break;
+    case 4: hipLaunchKernelGGL((k_straus<4, TPB>), grid, blk, 0, st, a, out, n, (int32_t *)scratch); break;
+    default: break;
+  }
 }
 
 template <int TPB>

@@ -19,19 +19,20 @@ void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy_out, size_t n)
 // JacRaw[n] -> device affine, Montgomery's trick in runs of `run` points per lane
 void batch_normalize(hipStream_t st, const JacRaw *in, AffDev *out, size_t n, int run);
 
-// out[i] = sum_{j<np} scalar_j(i) * point_j(i), np in {1, 2}.  Two-level indexing for batched
+// out[i] = sum_{j<np} scalar_j(i) * point_j(i), np in {1..4} (the np points of a lane share one
+// doubling chain: ~2 270 + 1 080 np field multiplications per lane instead of 3 350 np).  Two-level indexing for batched
 // (proof-major) arrays: i = p * inner + r;
 //   point_j(i)  = pts[j] + p * pt_outer[j] + r * pt_stride[j]          (AffDev units)
 //   scalar_j(i) = sc[j]  + p * sc_outer[j] + r * sc_stride[j]          (u32 words; stride 0 = broadcast)
 // inner == 0 means a flat array (p = 0, r = i).
 struct StrausArgs {
-  const AffDev *pts[2];
-  size_t pt_stride[2];
-  const uint32_t *sc[2];
-  size_t sc_stride[2];
+  const AffDev *pts[4];
+  size_t pt_stride[4];
+  const uint32_t *sc[4];
+  size_t sc_stride[4];
   size_t inner;
-  size_t pt_outer[2];
-  size_t sc_outer[2];
+  size_t pt_outer[4];
+  size_t sc_outer[4];
   size_t out_outer;   // with inner != 0: out[p * out_outer + r]; 0 = dense (out[i])
 };
 // scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
