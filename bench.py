@@ -26,7 +26,12 @@ LABEL = b"RangeProofTest"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-TRAFFIC_BYTES_PER_LAUNCH = {}
+TRAFFIC_BYTES_PER_LAUNCH = {
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 2 points per lane; k_straus: 12 174 / 22 032 KB --
+    # the writes are the per-lane window tables (21 MB) that live in L2/HBM scratch instead of LDS
+    "straus": int((2 * 12174.1 + 22032.0) * 1024),
+    "verify_scalars": int((2 * 12571.6 + 13653.2) * 1024),
+}
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
 
