@@ -59,6 +59,8 @@ struct bpgpu_ipp {
   Words8 *t1 = nullptr, *t2 = nullptr, *t3 = nullptr, *t4 = nullptr;   // nb x n0/2 temporaries
   Words8 *cLR = nullptr, *uu = nullptr;                            // nb x 2 each (uu: u | u_inv as 2 arrays of nb)
   JacRaw *res = nullptr, *sums = nullptr;                          // nb x 2 x (n0 + 1), nb x 2
+  AffDev *mpts = nullptr;                                          // nb x 2 x (n0 + 1): contiguous MSM operands
+  Words8 *msc = nullptr;                                           //   (bucket-method rounds)
   Words8 *out_xy = nullptr;                                        // nb x 2 points
   int cur = 0;                                                     // index of the live a/b/G/H buffers
 };
@@ -831,7 +833,7 @@ int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
 static void ipp_free_all(bpgpu_ipp *s) {
   for (int i = 0; i < 2; i++) { hipFree(s->a[i]); hipFree(s->b[i]); hipFree(s->G[i]); hipFree(s->H[i]); }
   hipFree(s->Q); hipFree(s->Gf); hipFree(s->Hf); hipFree(s->t1); hipFree(s->t2); hipFree(s->t3); hipFree(s->t4);
-  hipFree(s->cLR); hipFree(s->uu); hipFree(s->res); hipFree(s->sums); hipFree(s->out_xy);
+  hipFree(s->cLR); hipFree(s->uu); hipFree(s->res); hipFree(s->sums); hipFree(s->out_xy); hipFree(s->mpts); hipFree(s->msc);
   delete s;
 }
 int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
@@ -857,6 +859,7 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
   M((void **)&s->res, nb * 2 * (n + 1) * sizeof(JacRaw)); M((void **)&s->sums, nb * 2 * sizeof(JacRaw));
   M((void **)&s->out_xy, nb * 2 * 64);
+  M((void **)&s->mpts, nb * 2 * (n + 1) * sizeof(AffDev)); M((void **)&s->msc, nb * 2 * (n + 1) * 32);
   M(&stage, (2 * gtot + nb) * 64);
   if (!okk) { hipFree(stage); ipp_free_all(s); return BPGPU_E_OOM; }
   int rc = BPGPU_OK;
@@ -916,20 +919,36 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     sc_mul_strided(st, nb, h, b, n, 1, s->Hf + h, s->n0, 1, s->t4);       // b_L * H_factors[n..2n]
     sLa = s->t1; sLb = s->t2; sRa = s->t3; sRb = s->t4; so = h;
   }
-  auto run = [&](const Words8 *sc, size_t sc_outer, const AffDev *pts, size_t pt_outer, size_t cnt, size_t off) {
-    StrausArgs x{};
-    x.pts[0] = pts; x.pt_stride[0] = 1; x.pt_outer[0] = pt_outer;
-    x.sc[0] = (const uint32_t *)sc; x.sc_stride[0] = 8; x.sc_outer[0] = sc_outer * 8;
-    x.inner = cnt; x.out_outer = 2 * seg;
-    straus(st, 1, x, s->res + off, nb * cnt, dstr);
-  };
-  run(sLa, so, G + h, gouter, h, 0);              // L: a_L (.) G_R
-  run(sLb, so, H, gouter, h, h);                  //    b_R (.) H_L
-  run(s->cLR, 2, s->Q, 1, 1, 2 * h);              //    c_L Q
-  run(sRa, so, G, gouter, h, seg);                // R: a_R (.) G_L
-  run(sRb, so, H + h, gouter, h, seg + h);        //    b_L (.) H_R
-  run(s->cLR + 1, 2, s->Q, 1, 1, seg + 2 * h);    //    c_R Q
-  segmented_sum(st, s->res, s->sums, nb * 2, seg);
+  static const size_t pip_min = getenv("BPGPU_IPP_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_IPP_PIPPENGER_MIN")) : 257;
+  if (seg >= pip_min) {
+    // bucket method: make the 2 nb instances contiguous ([a_L | b_R | c_L] x [G_R | H_L | Q], then R's), one batched launch
+    const size_t io = 2 * seg;
+    gather_points(st, G + h, gouter, h, nb, s->mpts, io);            gather_scalars(st, sLa, so, h, nb, s->msc, io);
+    gather_points(st, H, gouter, h, nb, s->mpts + h, io);            gather_scalars(st, sLb, so, h, nb, s->msc + h, io);
+    gather_points(st, s->Q, 1, 1, nb, s->mpts + 2 * h, io);          gather_scalars(st, s->cLR, 2, 1, nb, s->msc + 2 * h, io);
+    gather_points(st, G, gouter, h, nb, s->mpts + seg, io);          gather_scalars(st, sRa, so, h, nb, s->msc + seg, io);
+    gather_points(st, H + h, gouter, h, nb, s->mpts + seg + h, io);  gather_scalars(st, sRb, so, h, nb, s->msc + seg + h, io);
+    gather_points(st, s->Q, 1, 1, nb, s->mpts + seg + 2 * h, io);    gather_scalars(st, s->cLR + 1, 2, 1, nb, s->msc + seg + 2 * h, io);
+    int cw = pippenger_window(seg);
+    void *dpip;
+    CK(ws_get(ctx, 14, pippenger_scratch_bytes_batch(nb * 2, seg, cw), &dpip));
+    pippenger_batch(st, s->mpts, (const uint32_t *)s->msc, nb * 2, seg, cw, s->sums, 1, dpip);
+  } else {
+    auto run = [&](const Words8 *sc, size_t sc_outer, const AffDev *pts, size_t pt_outer, size_t cnt, size_t off) {
+      StrausArgs x{};
+      x.pts[0] = pts; x.pt_stride[0] = 1; x.pt_outer[0] = pt_outer;
+      x.sc[0] = (const uint32_t *)sc; x.sc_stride[0] = 8; x.sc_outer[0] = sc_outer * 8;
+      x.inner = cnt; x.out_outer = 2 * seg;
+      straus(st, 1, x, s->res + off, nb * cnt, dstr);
+    };
+    run(sLa, so, G + h, gouter, h, 0);              // L: a_L (.) G_R
+    run(sLb, so, H, gouter, h, h);                  //    b_R (.) H_L
+    run(s->cLR, 2, s->Q, 1, 1, 2 * h);              //    c_L Q
+    run(sRa, so, G, gouter, h, seg);                // R: a_R (.) G_L
+    run(sRb, so, H + h, gouter, h, seg + h);        //    b_L (.) H_R
+    run(s->cLR + 1, 2, s->Q, 1, 1, seg + 2 * h);    //    c_R Q
+    segmented_sum(st, s->res, s->sums, nb * 2, seg);
+  }
   jac_to_boundary(st, s->sums, s->out_xy, nb * 2);
   CK(launch_ok(ctx));
   std::vector<uint8_t> tmp(nb * 128);

@@ -183,4 +183,19 @@ void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRa
   hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega);
 }
 
+// dst[p * dst_outer + i] = src[p * src_outer + i], i < cnt (16-byte vector copies)
+__global__ void __launch_bounds__(256) k_gather16(const uint4 *src, size_t src_outer, size_t cnt, uint4 *dst, size_t dst_outer, int vec) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (t >= cnt * vec) return;
+  dst[p * dst_outer * vec + t] = src[p * src_outer * vec + t];
+}
+void gather_points(hipStream_t st, const AffDev *src, size_t src_outer, size_t cnt, size_t nb, AffDev *dst, size_t dst_outer) {
+  if (!nb || !cnt) return;
+  hipLaunchKernelGGL(k_gather16, dim3((cnt * 4 + 255) / 256, nb), dim3(256), 0, st, (const uint4 *)src, src_outer, cnt, (uint4 *)dst, dst_outer, 4);
+}
+void gather_scalars(hipStream_t st, const Words8 *src, size_t src_outer, size_t cnt, size_t nb, Words8 *dst, size_t dst_outer) {
+  if (!nb || !cnt) return;
+  hipLaunchKernelGGL(k_gather16, dim3((cnt * 2 + 255) / 256, nb), dim3(256), 0, st, (const uint4 *)src, src_outer, cnt, (uint4 *)dst, dst_outer, 2);
+}
+
 }  // namespace bpk

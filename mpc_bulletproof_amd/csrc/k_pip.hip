@@ -31,10 +31,12 @@ __device__ __forceinline__ int pip_digit(const uint32_t sp[9], int c, int w) {
   return (int)((two >> sft) & ((1u << c) - 1)) - (1 << (c - 1));
 }
 
-__global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t *scalars, size_t n, uint32_t *keys,
-                                                    uint32_t *counts) {
+// `ninst` independent instances of n terms each (term-major per instance); bucket ids carry the instance
+__global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t *scalars, size_t n, size_t ninst,
+                                                    uint32_t *keys, uint32_t *counts) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n * ninst) return;
+  const size_t inst = i / n, r = i - inst * n;
   uint32_t sp[9];
   uint64_t carry = 0;
 #pragma unroll
@@ -47,11 +49,11 @@ __global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t
     int d = pip_digit(sp, pp.c, w);
     uint32_t key = 0xFFFFFFFFu;
     if (d != 0) {
-      uint32_t b = (uint32_t)w * pp.half + (uint32_t)((d < 0 ? -d : d) - 1);
+      uint32_t b = (uint32_t)((inst * pp.W + w) * pp.half) + (uint32_t)((d < 0 ? -d : d) - 1);
       key = b | (d < 0 ? 0x80000000u : 0u);
       atomicAdd(&counts[b], 1u);
     }
-    keys[(size_t)w * n + i] = key;
+    keys[((size_t)inst * pp.W + w) * n + r] = key;
   }
 }
 // exclusive scan of `nb` counts into offsets[nb + 1]; cursor = copy of offsets
@@ -78,16 +80,16 @@ __global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t *counts, uint3
   }
   if (tid == 1023) offsets[nb] = part[1023];
 }
-__global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_t *keys, size_t n, uint32_t *cursor,
-                                                     uint32_t *sorted) {
+__global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_t *keys, size_t n, size_t ninst,
+                                                     uint32_t *cursor, uint32_t *sorted) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * (size_t)pp.W) return;
+  if (t >= n * ninst * (size_t)pp.W) return;
   uint32_t key = keys[t];
   if (key == 0xFFFFFFFFu) return;
   uint32_t b = key & 0x7FFFFFFFu;
   uint32_t pos = atomicAdd(&cursor[b], 1u);
-  size_t i = t % n;
-  sorted[pos] = (uint32_t)i | (key & 0x80000000u);
+  size_t inst = t / (n * (size_t)pp.W), r = t % n;
+  sorted[pos] = (uint32_t)(inst * n + r) | (key & 0x80000000u);   // global term index
 }
 // Load balance: a bucket list is cut into tasks of at most PIP_TASK entries (the partial top window
 // has only 2^(252 mod c) non-empty buckets holding n / 2^(252 mod c) points each; equal or
@@ -135,8 +137,9 @@ constexpr int PW_TPB = 128;
 __global__ void __launch_bounds__(PW_TPB) k_pip_window(PipParams pp, const JacRaw *buckets, JacRaw *win_out) {
   __shared__ int32_t smem[27 * (PW_TPB / 2)];
   const int w = blockIdx.x, tid = threadIdx.x;
+  const size_t inst = blockIdx.y;
   const int L = pp.half / PW_TPB;                 // buckets per lane (half >= PW_TPB)
-  const JacRaw *B = buckets + (size_t)w * pp.half + (size_t)tid * L;
+  const JacRaw *B = buckets + ((size_t)inst * pp.W + w) * pp.half + (size_t)tid * L;
   Jac run = jac_inf(), ws = jac_inf();
   for (int j = L - 1; j >= 0; j--) {
     run = jac_add(run, raw_load(&B[j]));
@@ -152,15 +155,16 @@ __global__ void __launch_bounds__(PW_TPB) k_pip_window(PipParams pp, const JacRa
   Jac acc = block_sum<PW_TPB>(jac_add(ws, sm), smem);
   if (tid == 0) {
     for (int d = 0; d < pp.c * w; d++) acc = jac_dbl(acc);
-    raw_store(&win_out[w], acc);
+    raw_store(&win_out[inst * pp.W + w], acc);
   }
 }
-__global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, JacRaw *out) {
+__global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, JacRaw *out, size_t out_stride) {
   __shared__ int32_t smem[27 * 32];
+  const size_t inst = blockIdx.x;
   Jac acc = jac_inf();
-  for (int w = threadIdx.x; w < W; w += 64) acc = jac_add(acc, raw_load(&win[w]));
+  for (int w = threadIdx.x; w < W; w += 64) acc = jac_add(acc, raw_load(&win[inst * W + w]));
   acc = block_sum<64>(acc, smem);
-  if (threadIdx.x == 0) raw_store(out, acc);
+  if (threadIdx.x == 0) raw_store(&out[inst * out_stride], acc);
 }
 
 // window choice: minimise  n * W (bucket adds) + W * 2^(c-1) * ~3 (running sums), c in [8, 16]
@@ -175,43 +179,50 @@ int pippenger_window(size_t n) {
 }
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP_TASK + nbk + 1; }
-size_t pippenger_scratch_bytes(size_t n, int c) {
-  size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = W * half, mt = pip_max_tasks(n, W, nbk);
-  return al(n * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-         al(W * sizeof(JacRaw));
+size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
+  size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
+  return al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
+         al(ninst * W * sizeof(JacRaw));
 }
-void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
+size_t pippenger_scratch_bytes(size_t n, int c) { return pippenger_scratch_bytes_batch(1, n, c); }
+// ninst instances of n terms: pts / scalars hold instance-major arrays; out[inst * out_stride]
+void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t ninst, size_t n, int c, JacRaw *out,
+                     size_t out_stride, void *scratch) {
+  if (!ninst) return;
   PipParams pp;
   pp.c = c; pp.W = 252 / c + 1; pp.half = 1 << (c - 1);
   for (int j = 0; j < 9; j++) pp.K[j] = 0;
   for (int w = 0; w < pp.W; w++) { int bit = c * w + c - 1; pp.K[bit >> 5] |= 1u << (bit & 31); }
-  size_t W = pp.W, nbk = W * (size_t)pp.half;
+  size_t W = pp.W, nbk = ninst * W * (size_t)pp.half, tot = ninst * n;
   uint8_t *p = (uint8_t *)scratch;
-  uint32_t *keys = (uint32_t *)p; p += al(n * W * 4);
-  uint32_t *sorted = (uint32_t *)p; p += al(n * W * 4);
+  uint32_t *keys = (uint32_t *)p; p += al(tot * W * 4);
+  uint32_t *sorted = (uint32_t *)p; p += al(tot * W * 4);
   uint32_t *counts = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *offsets = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *cursor = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *tcount = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *toffsets = (uint32_t *)p; p += al((nbk + 1) * 4);
-  const size_t mt = pip_max_tasks(n, W, nbk);
+  const size_t mt = pip_max_tasks(tot, W, nbk);
   uint32_t *task_bucket = (uint32_t *)p; p += al(mt * 4);
   JacRaw *partial = (JacRaw *)p; p += al(mt * sizeof(JacRaw));
   JacRaw *buckets = (JacRaw *)p; p += al(nbk * sizeof(JacRaw));
   JacRaw *win = (JacRaw *)p;
   (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
-  if (n) hipLaunchKernelGGL(k_pip_digits, dim3((n + 255) / 256), dim3(256), 0, st, pp, scalars, n, keys, counts);
+  if (tot) hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, counts);
   hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, counts, offsets, cursor, nbk);
-  if (n) hipLaunchKernelGGL(k_pip_scatter, dim3((n * W + 255) / 256), dim3(256), 0, st, pp, keys, n, cursor, sorted);
+  if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
   hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
   hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, tcount, toffsets, (uint32_t *)nullptr, nbk);
   hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
-  // the task count is data dependent: launch the upper bound, excess lanes exit on `t >= ntasks` read on device
+  // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
   hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
                      nbk, partial);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets);
-  hipLaunchKernelGGL(k_pip_window, dim3(pp.W), dim3(PW_TPB), 0, st, pp, buckets, win);
-  hipLaunchKernelGGL(k_pip_final, dim3(1), dim3(64), 0, st, win, pp.W, out);
+  hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst), dim3(PW_TPB), 0, st, pp, buckets, win);
+  hipLaunchKernelGGL(k_pip_final, dim3(ninst), dim3(64), 0, st, win, pp.W, out, out_stride);
+}
+void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
+  pippenger_batch(st, pts, scalars, 1, n, c, out, 1, scratch);
 }
 
 }  // namespace bpk

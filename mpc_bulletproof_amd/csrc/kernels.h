@@ -43,6 +43,13 @@ void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, 
 int pippenger_window(size_t n);
 size_t pippenger_scratch_bytes(size_t n, int c);
 void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch);
+// ninst independent instances of n terms each (instance-major arrays); out[inst * out_stride]
+size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c);
+void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t ninst, size_t n, int c, JacRaw *out,
+                     size_t out_stride, void *scratch);
+// gather helper: dst[i] = src[idx(i)] for two-level strided sources (IPP round operands -> contiguous MSM inputs)
+void gather_points(hipStream_t st, const AffDev *src, size_t src_outer, size_t cnt, size_t nb, AffDev *dst, size_t dst_outer);
+void gather_scalars(hipStream_t st, const Words8 *src, size_t src_outer, size_t cnt, size_t nb, Words8 *dst, size_t dst_outer);
 
 // out[b] = sum_{i<n} in[b*n + i]
 void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, size_t n);

@@ -360,3 +360,18 @@ def test_combined_batch_check(gpu, tamper):
     finally:
         gpu.gens_destroy(g)
         gpu.circuit_destroy(circ)
+
+
+def test_ipp_create_bucket_rounds(gpu):
+    """n = 512: the first rounds (2h + 1 >= 257 terms) use the batched bucket-method MSM."""
+    sys_path_oracle()
+    nb, n = 2, 512
+    Gp, Hp = o.gens("G", n), o.gens("H", n)
+    a, b = o.random_scalars(41, nb * n), o.random_scalars(42, nb * n)
+    Gf, Hf = o.scalars([1] * (nb * n)), o.random_scalars(44, nb * n)
+    Q = b"".join(o.point_mul(o.random_scalars(50 + p, 1), o.generator()) for p in range(nb))
+    Ls, Rs, aa, bb, _ = _ipp_create_gpu(gpu, b"innerproducttest", nb, n, Q, Gf, Hf, Gp, Hp, True, a, b)
+    for p in range(nb):
+        sl = slice(32 * n * p, 32 * n * (p + 1))
+        L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q[64 * p:64 * p + 64], Gf[sl], Hf[sl], Gp, Hp, a[sl], b[sl])
+        assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo)
