@@ -9,7 +9,7 @@
 using namespace mpc_bulletproof;
 using namespace mpc_bulletproof::r1cs;
 
-enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3 };
+enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4 };
 
 static int map_error(const R1CSException &e) {
   switch (e.e) {
@@ -97,6 +97,7 @@ int bph_r1cs_verify(int kind, size_t param, const uint8_t *label, size_t label_l
       vars.push_back(verifier.commit(V));
     }
     if (kind == K_RANGE && m == 1) gadgets::range_proof(verifier, LinearCombination(vars[0]), nullptr, param);
+    else if (kind == K_RANGE_MULTI && m == (param >> 16)) { for (size_t i = 0; i < m; i++) gadgets::range_proof(verifier, LinearCombination(vars[i]), nullptr, param & 0xffff); }
     else if (kind == K_SHUFFLE && m == 2 * param)
       gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + param),
                               std::vector<Variable>(vars.begin() + param, vars.end()));
@@ -113,6 +114,43 @@ int bph_r1cs_verify(int kind, size_t param, const uint8_t *label, size_t label_l
       return map_error(e);
     }
     if (mega_out) memcpy(mega_out, verifier.last_mega_check().xy.data(), 64);
+    return 0;
+  })
+}
+
+// nb provers, each proving `nvals` values of `n_bits` bits in ONE constraint system (BASELINE config 3 shape:
+// 16 x 64-bit -> n = 1024 multipliers, q = 2064, m = 16), all in lock-step.  values: nb x nvals.
+// proofs_out: nb x proof_len (returned), commitments_out: nb x nvals x 64.
+int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t *label, size_t label_len,
+                          const uint64_t *values, uint64_t seed0, size_t gens_capacity, uint8_t *proofs_out,
+                          size_t *proof_len, uint8_t *commitments_out) {
+  GUARD({
+    PedersenGens pc_gens;
+    BulletproofGens bp_gens(gens_capacity, 1);
+    std::vector<std::unique_ptr<Transcript>> trs;
+    std::vector<std::unique_ptr<Prover>> provers;
+    std::vector<std::unique_ptr<Rng>> rngs;
+    std::vector<Prover *> pp;
+    std::vector<Rng *> rr;
+    for (size_t p = 0; p < nb; p++) {
+      trs.emplace_back(new Transcript(std::string((const char *)label, label_len)));
+      provers.emplace_back(new Prover(pc_gens, *trs.back()));
+      rngs.emplace_back(new Rng(seed0 + p));
+      for (size_t j = 0; j < nvals; j++) {
+        uint64_t v = values[p * nvals + j];
+        auto cv = provers.back()->commit(Scalar::from(v), rngs.back()->scalar());
+        memcpy(commitments_out + (p * nvals + j) * 64, cv.first.xy.data(), 64);
+        gadgets::range_proof(*provers.back(), LinearCombination(cv.second), &v, n_bits);
+      }
+      pp.push_back(provers.back().get());
+      rr.push_back(rngs.back().get());
+    }
+    auto proofs = Prover::prove_batch(pp, bp_gens, rr);
+    for (size_t p = 0; p < nb; p++) {
+      auto bytes = proofs[p].to_flat_bytes();
+      *proof_len = bytes.size();
+      memcpy(proofs_out + p * bytes.size(), bytes.data(), bytes.size());
+    }
     return 0;
   })
 }

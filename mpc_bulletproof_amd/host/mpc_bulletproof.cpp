@@ -563,6 +563,18 @@ class CsCore {
     deferred.clear();
     for (auto &cb : cbs) cb(*self_);
   }
+  bool same_rows(const CsCore &o) const {
+    if (constraints.size() != o.constraints.size()) return false;
+    for (size_t r = 0; r < constraints.size(); r++) {
+      const auto &a = constraints[r].terms, &b = o.constraints[r].terms;
+      if (a.size() != b.size()) return false;
+      auto ia = a.begin();
+      auto ib = b.begin();
+      for (; ia != a.end(); ++ia, ++ib)
+        if (ia->first < ib->first || ib->first < ia->first || ia->second != ib->second) return false;
+    }
+    return true;
+  }
   // constraint rows -> CSR arrays of the C ABI (the reference's Vec<LinearCombination>)
   bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
     std::vector<uint32_t> rp{0}, kind, idx;
@@ -621,110 +633,221 @@ std::pair<StarkPoint, Variable> Prover::commit(const Scalar &v, const Scalar &v_
 }
 
 R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {
-  CsCore &c = *c_;
-  Transcript &tr = c.tr;
+  std::vector<Prover *> ps{this};
+  std::vector<Rng *> rs{&rng};
+  return prove_batch(ps, bp_gens, rs)[0];
+}
+
+// Lock-step Prover::prove (prover.rs:412-727) for nb provers of circuits with identical constraint rows
+// (1-phase gadgets, or 2-phase ones whose randomized rows happen to coincide): every device call is
+// batched over the provers; only the transcripts run per prover on the host.
+std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
+                                           std::vector<Rng *> &rngs) {
+  const size_t nb = provers.size();
+  if (!nb || rngs.size() != nb) throw std::invalid_argument("prove_batch: one Rng per prover");
   Device &d = Device::default_device();
-  tr.append_u64("m", c.v.size());                                                       // prover.rs:420
-  size_t n1 = c.a_L.size();
+  std::vector<CsCore *> cs(nb);
+  for (size_t p = 0; p < nb; p++) cs[p] = provers[p]->c_.get();
+  const PedersenGens &pc = cs[0]->pc_gens;
+  bpgpu_gens *gens = bp_gens.device_tables(pc);
+  const size_t n1 = cs[0]->a_L.size(), m = cs[0]->v.size();
+  for (auto *c : cs) {
+    if (c->a_L.size() != n1 || c->v.size() != m) throw std::invalid_argument("prove_batch: circuits differ in shape");
+    c->tr.append_u64("m", c->v.size());                                                  // prover.rs:420
+  }
   if (bp_gens.gens_capacity < n1) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :450-452
-  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
-  Scalar i_b1 = rng.scalar(), o_b1 = rng.scalar(), s_b1 = rng.scalar();                 // :457-462
-  std::vector<Scalar> s_L(n1), s_R(n1);
-  for (auto &x : s_L) x = rng.scalar();
-  for (auto &x : s_R) x = rng.scalar();
-  // three commitments over [B, B_blinding, G_0.., H_0..] -- :465-494
-  auto commit3 = [&](size_t lo, size_t hi, const Scalar &ib, const Scalar &ob, const Scalar &sb, StarkPoint out[3]) {
-    size_t n = hi;   // scalars below `lo` are zero (phase-2 commitments use G[n1..n), H[n1..n))
-    std::vector<Scalar> vec(3 * (2 + 2 * n));
-    auto at = [&](size_t which, size_t j) -> Scalar & { return vec[which * (2 + 2 * n) + j]; };
-    at(0, 1) = ib; at(1, 1) = ob; at(2, 1) = sb;
-    for (size_t i = lo; i < hi; i++) {
-      at(0, 2 + i) = c.a_L[i]; at(0, 2 + n + i) = c.a_R[i];
-      at(1, 2 + i) = c.a_O[i];
-      at(2, 2 + i) = s_L[i]; at(2, 2 + n + i) = s_R[i];
+  std::vector<R1CSProof> proofs(nb);
+  std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
+  std::vector<std::vector<Scalar>> s_L(nb), s_R(nb);
+  for (size_t p = 0; p < nb; p++) {                                                      // :457-462
+    i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
+    s_L[p].resize(n1); s_R[p].resize(n1);
+    for (auto &x : s_L[p]) x = rngs[p]->scalar();
+    for (auto &x : s_R[p]) x = rngs[p]->scalar();
+  }
+  // three commitments per prover over [B, B_blinding, G_0.., H_0..] -- :465-494 / :532-565
+  auto commit3 = [&](size_t lo, size_t hi, const std::vector<Scalar> &ib, const std::vector<Scalar> &ob,
+                     const std::vector<Scalar> &sb, int which_phase) {
+    const size_t n = hi, per = 2 + 2 * n;
+    std::vector<Scalar> vec(nb * 3 * per);
+    for (size_t p = 0; p < nb; p++) {
+      auto at = [&](size_t w, size_t j) -> Scalar & { return vec[(p * 3 + w) * per + j]; };
+      at(0, 1) = ib[p]; at(1, 1) = ob[p]; at(2, 1) = sb[p];
+      for (size_t i = lo; i < hi; i++) {
+        at(0, 2 + i) = cs[p]->a_L[i]; at(0, 2 + n + i) = cs[p]->a_R[i];
+        at(1, 2 + i) = cs[p]->a_O[i];
+        at(2, 2 + i) = s_L[p][i]; at(2, 2 + n + i) = s_R[p][i];
+      }
     }
     auto bytes = pack_scalars(vec);
-    uint8_t o[3 * 64];
-    d.check(bpgpu_msm_gens(d.ctx(), gens, 3, n, bytes.data(), o), "bpgpu_msm_gens");
-    for (int k = 0; k < 3; k++) memcpy(out[k].xy.data(), o + 64 * k, 64);
+    std::vector<uint8_t> o(nb * 3 * 64);
+    d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 3, n, bytes.data(), o.data()), "bpgpu_msm_gens");
+    for (size_t p = 0; p < nb; p++) {
+      StarkPoint *dst[3] = {which_phase == 1 ? &proofs[p].A_I1 : &proofs[p].A_I2, which_phase == 1 ? &proofs[p].A_O1 : &proofs[p].A_O2,
+                            which_phase == 1 ? &proofs[p].S1 : &proofs[p].S2};
+      for (int k = 0; k < 3; k++) memcpy(dst[k]->xy.data(), &o[(p * 3 + k) * 64], 64);
+    }
   };
-  R1CSProof proof;
-  StarkPoint c1[3];
-  commit3(0, n1, i_b1, o_b1, s_b1, c1);
-  proof.A_I1 = c1[0]; proof.A_O1 = c1[1]; proof.S1 = c1[2];
-  tr.append_point("A_I1", proof.A_I1);
-  tr.append_point("A_O1", proof.A_O1);
-  tr.append_point("S1", proof.S1);
-  c.create_randomized_constraints();                                                    // :501
-  size_t n = c.a_L.size(), n2 = n - n1, padded_n = next_pow2(n), pad = padded_n - n;
+  commit3(0, n1, i_b1, o_b1, s_b1, 1);
+  for (size_t p = 0; p < nb; p++) {
+    cs[p]->tr.append_point("A_I1", proofs[p].A_I1);
+    cs[p]->tr.append_point("A_O1", proofs[p].A_O1);
+    cs[p]->tr.append_point("S1", proofs[p].S1);
+    cs[p]->create_randomized_constraints();                                              // :501
+  }
+  const size_t n = cs[0]->a_L.size(), n2 = n - n1, padded_n = next_pow2(n);
+  for (auto *c : cs) if (c->a_L.size() != n) throw std::invalid_argument("prove_batch: circuits differ after randomization");
   if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :511-513
-  Scalar i_b2, o_b2, s_b2;
-  if (n2 > 0) { i_b2 = rng.scalar(); o_b2 = rng.scalar(); s_b2 = rng.scalar(); }        // :519-527
-  s_L.resize(n); s_R.resize(n);
-  for (size_t i = n1; i < n; i++) s_L[i] = rng.scalar();
-  for (size_t i = n1; i < n; i++) s_R[i] = rng.scalar();
-  if (n2 > 0) {                                                                         // :532-565
-    StarkPoint c2[3];
-    commit3(n1, n, i_b2, o_b2, s_b2, c2);
-    proof.A_I2 = c2[0]; proof.A_O2 = c2[1]; proof.S2 = c2[2];
-  }                                                                                     // else identity, :566-576
-  tr.append_point("A_I2", proof.A_I2);
-  tr.append_point("A_O2", proof.A_O2);
-  tr.append_point("S2", proof.S2);
-  Scalar y = tr.challenge_scalar("y"), z = tr.challenge_scalar("z");                    // :584-585
-  Scalar y_inv = y.inverse();
-  // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619
-  size_t m = c.v.size();
-  bpgpu_circuit *circ = c.upload_circuit(n, m);
+  for (size_t p = 0; p < nb; p++) {
+    if (n2 > 0) { i_b2[p] = rngs[p]->scalar(); o_b2[p] = rngs[p]->scalar(); s_b2[p] = rngs[p]->scalar(); }   // :519-527
+    s_L[p].resize(n); s_R[p].resize(n);
+    for (size_t i = n1; i < n; i++) s_L[p][i] = rngs[p]->scalar();
+    for (size_t i = n1; i < n; i++) s_R[p][i] = rngs[p]->scalar();
+  }
+  if (n2 > 0) commit3(n1, n, i_b2, o_b2, s_b2, 2);                                        // else identity, :566-576
+  std::vector<Scalar> y(nb), z(nb), y_inv(nb);
+  for (size_t p = 0; p < nb; p++) {
+    cs[p]->tr.append_point("A_I2", proofs[p].A_I2);
+    cs[p]->tr.append_point("A_O2", proofs[p].A_O2);
+    cs[p]->tr.append_point("S2", proofs[p].S2);
+    y[p] = cs[p]->tr.challenge_scalar("y");                                               // :584-585
+    z[p] = cs[p]->tr.challenge_scalar("z");
+  }
+  {   // y^-1 for all provers: Scalar::inverse (prover.rs:593) as one batched device inversion
+    auto by = pack_scalars(y);
+    d.check(bpgpu_batch_inverse(d.ctx(), by.data(), nb), "bpgpu_batch_inverse");
+    y_inv = unpack_scalars(by.data(), nb);
+  }
+  // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619.  One circuit for all
+  // provers: the constraint rows must coincide (checked through their CSR bytes).
+  for (size_t p = 1; p < nb; p++)
+    if (!cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+  bpgpu_circuit *circ = cs[0]->upload_circuit(n, m);
   bpgpu_prover *ps = nullptr;
-  std::vector<uint8_t> tco(6 * 32), wVb(m * 32 + 1);
-  auto by = y.to_bytes(), byi = y_inv.to_bytes(), bz = z.to_bytes();
-  auto paL = pack_scalars(c.a_L), paR = pack_scalars(c.a_R), paO = pack_scalars(c.a_O), psL = pack_scalars(s_L), psR = pack_scalars(s_R);
-  uint8_t dummy = 0;
-  int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, 1, by.data(), byi.data(), bz.data(), n ? paL.data() : &dummy, n ? paR.data() : &dummy,
-                                   n ? paO.data() : &dummy, n ? psL.data() : &dummy, n ? psR.data() : &dummy, tco.data(), wVb.data(), &ps);
-  if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
-  auto t = unpack_scalars(tco.data(), 6);   // t1 t2 t3 t4 t5 t6
-  auto wV = unpack_scalars(wVb.data(), m);
-  Scalar tb1 = rng.scalar(), tb3 = rng.scalar(), tb4 = rng.scalar(), tb5 = rng.scalar(), tb6 = rng.scalar();   // :621-625
-  proof.T_1 = c.pc_gens.commit(t[0], tb1);                                              // :627-631
-  proof.T_3 = c.pc_gens.commit(t[2], tb3);
-  proof.T_4 = c.pc_gens.commit(t[3], tb4);
-  proof.T_5 = c.pc_gens.commit(t[4], tb5);
-  proof.T_6 = c.pc_gens.commit(t[5], tb6);
-  tr.append_point("T_1", proof.T_1);
-  tr.append_point("T_3", proof.T_3);
-  tr.append_point("T_4", proof.T_4);
-  tr.append_point("T_5", proof.T_5);
-  tr.append_point("T_6", proof.T_6);
-  Scalar u = tr.challenge_scalar("u"), x = tr.challenge_scalar("x");                    // :639-640
-  Scalar tb2;
-  for (size_t i = 0; i < m; i++) tb2 += wV[i] * c.v_blinding[i];                        // :644-648
-  auto poly6 = [&](const Scalar &c1_, const Scalar &c2_, const Scalar &c3_, const Scalar &c4_, const Scalar &c5_, const Scalar &c6_) {
-    return x * (c1_ + x * (c2_ + x * (c3_ + x * (c4_ + x * (c5_ + x * c6_)))));         // util.rs:192-194
-  };
-  proof.t_x = poly6(t[0], t[1], t[2], t[3], t[4], t[5]);                                // :659-660
-  proof.t_x_blinding = poly6(tb1, tb2, tb3, tb4, tb5, tb6);
-  std::vector<uint8_t> lv(padded_n * 32), rv(padded_n * 32);
-  auto bx = x.to_bytes();
-  rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
-  bpgpu_prover_destroy(d.ctx(), ps);
-  bpgpu_circuit_destroy(d.ctx(), circ);
-  d.check(rc, "bpgpu_r1cs_prover_eval");
-  Scalar i_b = i_b1 + u * i_b2, o_b = o_b1 + u * o_b2, s_b = s_b1 + u * s_b2;           // :674-676
-  proof.e_blinding = x * (i_b + x * (o_b + x * s_b));                                   // :678
-  tr.append_scalar("t_x", proof.t_x);
-  tr.append_scalar("t_x_blinding", proof.t_x_blinding);
-  tr.append_scalar("e_blinding", proof.e_blinding);
-  Scalar w = tr.challenge_scalar("w");                                                  // :686
-  StarkPoint Q = d.msm({w}, {c.pc_gens.B});                                             // :687
-  std::vector<Scalar> Gf(padded_n), Hf(padded_n);                                       // :689-697
-  auto exp_y_inv = util::exp_iter(y_inv, padded_n);
-  for (size_t i = 0; i < padded_n; i++) { Gf[i] = i < n1 ? Scalar::one() : u; Hf[i] = exp_y_inv[i] * Gf[i]; }
-  proof.ipp_proof = InnerProductProof::create(tr, Q, Gf, Hf, bp_gens.share(0).G(padded_n), bp_gens.share(0).H(padded_n),
-                                              unpack_scalars(lv.data(), padded_n), unpack_scalars(rv.data(), padded_n));   // :699-708
-  (void)pad;
-  return proof;
+  std::vector<uint8_t> tco(nb * 6 * 32), wVb(nb * m * 32 + 1);
+  {
+    std::vector<Scalar> aL, aR, aO, sl, sr;
+    for (size_t p = 0; p < nb; p++) {
+      aL.insert(aL.end(), cs[p]->a_L.begin(), cs[p]->a_L.end());
+      aR.insert(aR.end(), cs[p]->a_R.begin(), cs[p]->a_R.end());
+      aO.insert(aO.end(), cs[p]->a_O.begin(), cs[p]->a_O.end());
+      sl.insert(sl.end(), s_L[p].begin(), s_L[p].end());
+      sr.insert(sr.end(), s_R[p].begin(), s_R[p].end());
+    }
+    auto by = pack_scalars(y), byi = pack_scalars(y_inv), bz = pack_scalars(z);
+    auto paL = pack_scalars(aL), paR = pack_scalars(aR), paO = pack_scalars(aO), psL = pack_scalars(sl), psR = pack_scalars(sr);
+    uint8_t dummy = 0;
+    int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), n ? paL.data() : &dummy,
+                                     n ? paR.data() : &dummy, n ? paO.data() : &dummy, n ? psL.data() : &dummy,
+                                     n ? psR.data() : &dummy, tco.data(), wVb.data(), &ps);
+    if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
+  }
+  auto t = unpack_scalars(tco.data(), nb * 6);   // per prover: t1 t2 t3 t4 t5 t6
+  auto wV = unpack_scalars(wVb.data(), nb * m);
+  std::vector<Scalar> tb(nb * 6);                                                         // :621-625 (tb2 filled below)
+  {   // T_1, T_3, T_4, T_5, T_6 = commit(t_i, tb_i): 5 nb two-term MSMs over (B, B_blinding) -- :627-631
+    std::vector<Scalar> vec(nb * 5 * 2);
+    const int idx[5] = {0, 2, 3, 4, 5};
+    for (size_t p = 0; p < nb; p++)
+      for (int k = 0; k < 5; k++) {
+        tb[p * 6 + idx[k]] = rngs[p]->scalar();
+        vec[(p * 5 + k) * 2] = t[p * 6 + idx[k]];
+        vec[(p * 5 + k) * 2 + 1] = tb[p * 6 + idx[k]];
+      }
+    auto bytes = pack_scalars(vec);
+    std::vector<uint8_t> o(nb * 5 * 64);
+    d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 5, 0, bytes.data(), o.data()), "bpgpu_msm_gens");
+    for (size_t p = 0; p < nb; p++) {
+      StarkPoint *dst[5] = {&proofs[p].T_1, &proofs[p].T_3, &proofs[p].T_4, &proofs[p].T_5, &proofs[p].T_6};
+      for (int k = 0; k < 5; k++) memcpy(dst[k]->xy.data(), &o[(p * 5 + k) * 64], 64);
+    }
+  }
+  std::vector<Scalar> u(nb), x(nb), w(nb);
+  for (size_t p = 0; p < nb; p++) {
+    Transcript &tr = cs[p]->tr;
+    tr.append_point("T_1", proofs[p].T_1);
+    tr.append_point("T_3", proofs[p].T_3);
+    tr.append_point("T_4", proofs[p].T_4);
+    tr.append_point("T_5", proofs[p].T_5);
+    tr.append_point("T_6", proofs[p].T_6);
+    u[p] = tr.challenge_scalar("u");                                                      // :639-640
+    x[p] = tr.challenge_scalar("x");
+    Scalar tb2;
+    for (size_t i = 0; i < m; i++) tb2 += wV[p * m + i] * cs[p]->v_blinding[i];           // :644-648
+    tb[p * 6 + 1] = tb2;
+    auto poly6 = [&](const Scalar *c6) {                                                  // util.rs:192-194
+      return x[p] * (c6[0] + x[p] * (c6[1] + x[p] * (c6[2] + x[p] * (c6[3] + x[p] * (c6[4] + x[p] * c6[5])))));
+    };
+    proofs[p].t_x = poly6(&t[p * 6]);                                                     // :659-660
+    proofs[p].t_x_blinding = poly6(&tb[p * 6]);
+    Scalar i_b = i_b1[p] + u[p] * i_b2[p], o_b = o_b1[p] + u[p] * o_b2[p], s_b = s_b1[p] + u[p] * s_b2[p];   // :674-676
+    proofs[p].e_blinding = x[p] * (i_b + x[p] * (o_b + x[p] * s_b));                      // :678
+    tr.append_scalar("t_x", proofs[p].t_x);
+    tr.append_scalar("t_x_blinding", proofs[p].t_x_blinding);
+    tr.append_scalar("e_blinding", proofs[p].e_blinding);
+    w[p] = tr.challenge_scalar("w");                                                      // :686
+  }
+  std::vector<uint8_t> lv(nb * padded_n * 32), rv(nb * padded_n * 32);
+  {
+    auto bx = pack_scalars(x);
+    int rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
+    bpgpu_prover_destroy(d.ctx(), ps);
+    bpgpu_circuit_destroy(d.ctx(), circ);
+    d.check(rc, "bpgpu_r1cs_prover_eval");
+  }
+  // Q_p = w_p * B (:687): nb one-term MSMs over (B, B_blinding) with a zero blinding scalar
+  std::vector<uint8_t> Qb(nb * 64);
+  {
+    std::vector<Scalar> vec(nb * 2);
+    for (size_t p = 0; p < nb; p++) vec[2 * p] = w[p];
+    auto bytes = pack_scalars(vec);
+    d.check(bpgpu_msm_gens(d.ctx(), gens, nb, 0, bytes.data(), Qb.data()), "bpgpu_msm_gens");
+  }
+  // InnerProductProof::create for all provers in lock-step (:689-708; inner_product_proof.rs:49-193)
+  std::vector<Scalar> Gf(nb * padded_n), Hf(nb * padded_n);
+  for (size_t p = 0; p < nb; p++) {
+    auto exp_y_inv = util::exp_iter(y_inv[p], padded_n);
+    for (size_t i = 0; i < padded_n; i++) {
+      Gf[p * padded_n + i] = i < n1 ? Scalar::one() : u[p];
+      Hf[p * padded_n + i] = exp_y_inv[i] * Gf[p * padded_n + i];
+    }
+    cs[p]->tr.innerproduct_domain_sep(padded_n);                                          // inner_product_proof.rs:72
+  }
+  auto pG = pack_points(bp_gens.share(0).G(padded_n)), pH = pack_points(bp_gens.share(0).H(padded_n));
+  auto pgf = pack_scalars(Gf), phf = pack_scalars(Hf);
+  bpgpu_ipp *ipp = nullptr;
+  d.check(bpgpu_ipp_begin(d.ctx(), nb, padded_n, Qb.data(), pgf.data(), phf.data(), pG.data(), pH.data(), 1, lv.data(), rv.data(), &ipp),
+          "bpgpu_ipp_begin");
+  try {
+    std::vector<uint8_t> L(nb * 64), R(nb * 64), ub(nb * 32), uib(nb * 32);
+    while (bpgpu_ipp_len(ipp) > 1) {
+      d.check(bpgpu_ipp_round(d.ctx(), ipp, L.data(), R.data()), "bpgpu_ipp_round");
+      for (size_t p = 0; p < nb; p++) {
+        StarkPoint Lp, Rp;
+        memcpy(Lp.xy.data(), &L[64 * p], 64);
+        memcpy(Rp.xy.data(), &R[64 * p], 64);
+        proofs[p].ipp_proof.L_vec.push_back(Lp);
+        proofs[p].ipp_proof.R_vec.push_back(Rp);
+        cs[p]->tr.append_point("L", Lp);                                                  // :119-123 / :177-181
+        cs[p]->tr.append_point("R", Rp);
+        cs[p]->tr.challenge_scalar("u").to_bytes_le(&ub[32 * p]);
+      }
+      uib = ub;
+      d.check(bpgpu_batch_inverse(d.ctx(), uib.data(), nb), "bpgpu_batch_inverse");
+      d.check(bpgpu_ipp_fold(d.ctx(), ipp, ub.data(), uib.data()), "bpgpu_ipp_fold");
+    }
+    std::vector<uint8_t> a(nb * 32), b(nb * 32);
+    d.check(bpgpu_ipp_finish(d.ctx(), ipp, a.data(), b.data()), "bpgpu_ipp_finish");
+    for (size_t p = 0; p < nb; p++) {
+      proofs[p].ipp_proof.a = Scalar::from_bytes_le(&a[32 * p]);
+      proofs[p].ipp_proof.b = Scalar::from_bytes_le(&b[32 * p]);
+    }
+  } catch (...) {
+    bpgpu_ipp_destroy(d.ctx(), ipp);
+    throw;
+  }
+  bpgpu_ipp_destroy(d.ctx(), ipp);
+  return proofs;
 }
 
 // ---- Verifier --------------------------------------------------------------------------------------

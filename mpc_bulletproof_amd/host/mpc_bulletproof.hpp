@@ -226,6 +226,9 @@ class Prover : public RandomizedConstraintSystem {
   ~Prover();
   std::pair<StarkPoint, Variable> commit(const Scalar &v, const Scalar &v_blinding);   // :319-329
   R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // :412-727 (RNG injected)
+  // the same for nb provers of one circuit in lock-step (every device call batched over the provers)
+  static std::vector<R1CSProof> prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
+                                            std::vector<Rng *> &rngs);
   bool constraints_satisfied() const;                              // :405-409
   Transcript &transcript() override;
   size_t num_constraints() const override;

@@ -218,7 +218,7 @@ API int bpo_ipp_verify(const uint8_t *label, size_t label_len, size_t n, const u
 }
 
 /* ------------------------------------------------------------------ R1CS sessions */
-enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3 };
+enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4 };   /* 4: param = n_bits | nvals << 16 */
 
 static size_t proof_flat_size(size_t k) { return 8 + 11 * 64 + 3 * 32 + 2 * k * 64 + 64; }
 API size_t bpo_proof_flat_size(size_t k) { return proof_flat_size(k); }
@@ -284,6 +284,14 @@ API int bpo_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t labe
     fe_from_u64(SC, &v, values[0]); sm_scalar(&rng, &bl);
     var_t var = cs_commit_prover(&cs, &v, &bl, NULL);
     gadget_range_proof(&cs, var, 1, values[0], param);
+  } else if (kind == K_RANGE_MULTI) {   /* several values range-proved in ONE constraint system (BASELINE config 3 shape) */
+    size_t nb_ = param & 0xffff, nv = param >> 16;
+    if (nvalues != nv) return -3;
+    for (size_t i = 0; i < nv; i++) {
+      fe_from_u64(SC, &v, values[i]); sm_scalar(&rng, &bl);
+      var_t var = cs_commit_prover(&cs, &v, &bl, NULL);
+      gadget_range_proof(&cs, var, 1, values[i], nb_);
+    }
   } else if (kind == K_SHUFFLE) {
     size_t k = param;
     if (nvalues != 2 * k) return -3;
@@ -349,6 +357,7 @@ API void *bpo_verify_open(int kind, size_t param, const uint8_t *label, size_t l
     for (size_t i = 0; i < m; i++) vars[i] = cs_commit_verifier(&s->cs, &V[i]);
     int ok = 1;
     if (kind == K_RANGE && m == 1) gadget_range_proof(&s->cs, vars[0], 0, 0, param);
+    else if (kind == K_RANGE_MULTI && m == (param >> 16)) { for (size_t i = 0; i < m; i++) gadget_range_proof(&s->cs, vars[i], 0, 0, param & 0xffff); }
     else if (kind == K_SHUFFLE && m == 2 * param) gadget_shuffle(&s->cs, vars, vars + param, param);
     else if (kind == K_EXAMPLE && m == 5 && nvalues == 1) gadget_example(&s->cs, vars, values[0]);
     else if (kind == K_DUMMY && m == 1) {
@@ -471,6 +480,7 @@ API int bpo_r1cs_verify_many(int kind, size_t param, const uint8_t *label, size_
       for (size_t j = 0; j < m; j++) vars[j] = cs_commit_verifier(&cs, &V[j]);
       int good = 1;
       if (kind == K_RANGE && m == 1) gadget_range_proof(&cs, vars[0], 0, 0, param);
+      else if (kind == K_RANGE_MULTI && m == (param >> 16)) { for (size_t j = 0; j < m; j++) gadget_range_proof(&cs, vars[j], 0, 0, param & 0xffff); }
       else if (kind == K_SHUFFLE && m == 2 * param) gadget_shuffle(&cs, vars, vars + param, param);
       else if (kind == K_EXAMPLE && m == 5 && nvalues == 1) gadget_example(&cs, vars, values[0]);
       else good = 0;

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ORACLE_DIR = os.path.join(os.path.dirname(_HERE), "oracle")
 _SO = os.path.join(_ORACLE_DIR, "liboracle.so")
 
-K_RANGE, K_SHUFFLE, K_EXAMPLE, K_DUMMY = 0, 1, 2, 3
+K_RANGE, K_SHUFFLE, K_EXAMPLE, K_DUMMY, K_RANGE_MULTI = 0, 1, 2, 3, 4
 N = 0x0800000000000010FFFFFFFFFFFFFFFFB781126DCAE7B2321E66A241ADC64D2F
 P = 2**251 + 17 * 2**192 + 1
 
@@ -179,7 +179,7 @@ def r1cs_prove(kind, param, label, values, seed, gens_capacity):
     vals = (C.c_uint64 * max(len(values), 1))(*values)
     proof = _out(lib.bpo_proof_flat_size(C.c_size_t(32)))
     plen, m = C.c_size_t(0), C.c_size_t(0)
-    mmax = {K_RANGE: 1, K_SHUFFLE: 2 * param, K_EXAMPLE: 5, K_DUMMY: 1}[kind]
+    mmax = {K_RANGE: 1, K_SHUFFLE: 2 * param, K_EXAMPLE: 5, K_DUMMY: 1, K_RANGE_MULTI: param >> 16}[kind]
     com = _out(64 * mmax)
     rc = lib.bpo_r1cs_prove(kind, C.c_size_t(param), _buf(label), C.c_size_t(len(label)), vals,
                             C.c_size_t(len(values)), C.c_uint64(seed), C.c_size_t(gens_capacity), proof,

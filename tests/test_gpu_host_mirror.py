@@ -95,3 +95,29 @@ def test_reference_tests_restated_in_cpp():
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all passed" in r.stdout
+
+
+def test_prove_batch_lockstep_matches_oracle(host):
+    """Prover::prove_batch (config 3 shape: several range-proved values per constraint system, provers in
+    lock-step on the GPU) reproduces the oracle's proofs prover by prover, and they verify."""
+    nb, nvals, n_bits = 3, 4, 8
+    n = nvals * n_bits
+    cap = 32
+    vals = [(17 * (i + 1) + 101 * p) % (1 << n_bits) for p in range(nb) for i in range(nvals)]
+    arr = (C.c_uint64 * len(vals))(*vals)
+    proofs = (C.c_uint8 * (nb * 8192))()
+    plen = C.c_size_t(0)
+    com = (C.c_uint8 * (nb * nvals * 64))()
+    rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(nvals), C.c_size_t(n_bits), o._buf(b"RangeProofTest"),
+                                    C.c_size_t(14), arr, C.c_uint64(500), C.c_size_t(cap), proofs, C.byref(plen), com)
+    assert rc == 0
+    L = plen.value
+    param = n_bits | (nvals << 16)
+    for p in range(nb):
+        rc_o, proof_o, com_o = o.r1cs_prove(o.K_RANGE_MULTI, param, b"RangeProofTest", vals[p * nvals:(p + 1) * nvals], 500 + p, cap)
+        assert rc_o == 0
+        assert bytes(proofs)[p * L:(p + 1) * L] == proof_o
+        assert bytes(com)[p * nvals * 64:(p + 1) * nvals * 64] == com_o
+        assert o.r1cs_verify(o.K_RANGE_MULTI, param, b"RangeProofTest", [], com_o, proof_o, cap) == 0
+        assert _verify(host, o.K_RANGE_MULTI, param, b"RangeProofTest", [], com_o, proof_o, cap)[0] == 0
+    assert n == 32
