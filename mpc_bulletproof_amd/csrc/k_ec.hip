@@ -111,25 +111,16 @@ void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, siz
 template <int C, int TPB>
 __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t ngens, const uint32_t *scalars,
                                                    size_t sc_stride, JacRaw *out) {
-  extern __shared__ int32_t sm[];          // [ngens * 9] recoded scalars, then 27 * TPB/2 reduction
-  uint32_t *sp = (uint32_t *)sm;
-  int32_t *red = sm + ((ngens * 9 + 3) & ~(size_t)3);
+  __shared__ int32_t red[27 * (TPB / 2)];
   constexpr int W = num_windows<C>();
   constexpr int HALF = 1 << (C - 1);
   const int tid = threadIdx.x;
   const uint32_t *sc = scalars + (size_t)blockIdx.x * sc_stride;
-  for (size_t g = tid; g < ngens; g += TPB) {
-    uint32_t s[8], r[9];
-#pragma unroll
-    for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
-    recode_add_k<C>(r, s);
-#pragma unroll
-    for (int t = 0; t < 9; t++) sp[g * 9 + t] = r[t];
-  }
-  __syncthreads();
   const size_t total = ngens * W;
   Jac acc = jac_inf();
-  // software prefetch of the next table row while the current madd runs
+  // software prefetch of the next table row while the current madd runs.  The scalar words come from
+  // L1/L2 (the W lanes of one generator read the same 32 bytes) and are recoded on the fly: staging all
+  // recoded scalars in LDS needs 36 B per generator -- 81 KB at capacity 1024, past the 64 KB dynamic limit.
   uint32_t cur[16];
   int dcur = 0;
   size_t l = tid;
@@ -138,9 +129,10 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
     if (ll < total) {
       size_t g = ll / W;
       int w = (int)(ll - g * W);
-      uint32_t r[9];
+      uint32_t s[8], r[9];
 #pragma unroll
-      for (int t = 0; t < 9; t++) r[t] = sp[g * 9 + t];
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+      recode_add_k<C>(r, s);
       dg = recode_digit<C>(r, w);
       if (dg != 0) {
         const AffDev *e = table + ll * HALF + ((dg < 0 ? -dg : dg) - 1);
@@ -173,8 +165,7 @@ template <int C>
 static void launch_fixed(hipStream_t st, const AffDev *table, size_t ngens, const uint32_t *scalars, size_t stride,
                          JacRaw *out, size_t nb) {
   constexpr int TPB = 128;
-  size_t lds = (((ngens * 9 + 3) & ~(size_t)3) + 27 * (TPB / 2)) * 4;
-  hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(nb), dim3(TPB), lds, st, table, ngens, scalars, stride, out);
+  hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(nb), dim3(TPB), 0, st, table, ngens, scalars, stride, out);
 }
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t ngens, const uint32_t *scalars,
                size_t stride, JacRaw *out, size_t nb) {

@@ -132,18 +132,26 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
     std::vector<std::unique_ptr<Rng>> rngs;
     std::vector<Prover *> pp;
     std::vector<Rng *> rr;
+    // all nb * nvals Pedersen commitments in one device call (the blinding factors are drawn first, in
+    // the order tests/r1cs.rs:684 draws them)
+    std::vector<Scalar> vs, bls;
+    for (size_t p = 0; p < nb; p++) {
+      rngs.emplace_back(new Rng(seed0 + p));
+      for (size_t j = 0; j < nvals; j++) { vs.push_back(Scalar::from(values[p * nvals + j])); bls.push_back(rngs.back()->scalar()); }
+    }
+    auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
     for (size_t p = 0; p < nb; p++) {
       trs.emplace_back(new Transcript(std::string((const char *)label, label_len)));
       provers.emplace_back(new Prover(pc_gens, *trs.back()));
-      rngs.emplace_back(new Rng(seed0 + p));
       for (size_t j = 0; j < nvals; j++) {
         uint64_t v = values[p * nvals + j];
-        auto cv = provers.back()->commit(Scalar::from(v), rngs.back()->scalar());
-        memcpy(commitments_out + (p * nvals + j) * 64, cv.first.xy.data(), 64);
-        gadgets::range_proof(*provers.back(), LinearCombination(cv.second), &v, n_bits);
+        size_t ix = p * nvals + j;
+        memcpy(commitments_out + ix * 64, Vs[ix].xy.data(), 64);
+        Variable var = provers.back()->commit_precomputed(vs[ix], bls[ix], Vs[ix]);
+        gadgets::range_proof(*provers.back(), LinearCombination(var), &v, n_bits);
       }
       pp.push_back(provers.back().get());
-      rr.push_back(rngs.back().get());
+      rr.push_back(rngs[p].get());
     }
     auto proofs = Prover::prove_batch(pp, bp_gens, rr);
     for (size_t p = 0; p < nb; p++) {

@@ -268,6 +268,18 @@ PedersenGens::PedersenGens() : B(StarkPoint::generator()), B_blinding(StarkPoint
 StarkPoint PedersenGens::commit(const Scalar &value, const Scalar &blinding) const {
   return Device::default_device().msm({value, blinding}, {B, B_blinding});
 }
+std::vector<StarkPoint> PedersenGens::commit_batch(const BulletproofGens &bp_gens, const std::vector<Scalar> &values,
+                                                   const std::vector<Scalar> &blindings) const {
+  if (values.size() != blindings.size()) throw std::invalid_argument("commit_batch: length mismatch");
+  size_t nb = values.size();
+  std::vector<Scalar> vec(2 * nb);
+  for (size_t i = 0; i < nb; i++) { vec[2 * i] = values[i]; vec[2 * i + 1] = blindings[i]; }
+  auto bytes = pack_scalars(vec);
+  std::vector<uint8_t> o(nb * 64 + 1);
+  Device &d = Device::default_device();
+  d.check(bpgpu_msm_gens(d.ctx(), bp_gens.device_tables(*this), nb, 0, bytes.data(), o.data()), "bpgpu_msm_gens");
+  return unpack_points(o.data(), nb);
+}
 static std::vector<StarkPoint> generators_chain(char which, uint32_t party, size_t skip, size_t count) {
   // GeneratorsChain::new + fast_forward + next, generators.rs:82-124
   std::string lab = "GeneratorsChain";
@@ -630,6 +642,15 @@ std::pair<StarkPoint, Variable> Prover::commit(const Scalar &v, const Scalar &v_
   c_->V.push_back(V);
   c_->tr.append_point("V", V);
   return {V, Variable{Variable::Committed, i}};
+}
+
+Variable Prover::commit_precomputed(const Scalar &v, const Scalar &v_blinding, const StarkPoint &V) {
+  size_t i = c_->v.size();
+  c_->v.push_back(v);
+  c_->v_blinding.push_back(v_blinding);
+  c_->V.push_back(V);
+  c_->tr.append_point("V", V);
+  return Variable{Variable::Committed, i};
 }
 
 R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {

@@ -118,6 +118,9 @@ struct PedersenGens {
   StarkPoint B, B_blinding;
   PedersenGens();                                              // default(): both = curve generator (:61-70)
   StarkPoint commit(const Scalar &value, const Scalar &blinding) const;   // :41-43
+  // many commitments in one device call (fixed-base tables of (B, B_blinding) from `bp_gens`)
+  std::vector<StarkPoint> commit_batch(const class BulletproofGens &bp_gens, const std::vector<Scalar> &values,
+                                       const std::vector<Scalar> &blindings) const;
 };
 class BulletproofGens {
  public:
@@ -225,6 +228,8 @@ class Prover : public RandomizedConstraintSystem {
   Prover(const PedersenGens &pc_gens, Transcript &transcript);     // prover.rs:285-300
   ~Prover();
   std::pair<StarkPoint, Variable> commit(const Scalar &v, const Scalar &v_blinding);   // :319-329
+  // same, with the commitment V = commit(v, v_blinding) already computed (PedersenGens::commit_batch)
+  Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const StarkPoint &V);
   R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // :412-727 (RNG injected)
   // the same for nb provers of one circuit in lock-step (every device call batched over the provers)
   static std::vector<R1CSProof> prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,

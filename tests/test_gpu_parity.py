@@ -375,3 +375,15 @@ def test_ipp_create_bucket_rounds(gpu):
         sl = slice(32 * n * p, 32 * n * (p + 1))
         L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q[64 * p:64 * p + 64], Gf[sl], Hf[sl], Gp, Hp, a[sl], b[sl])
         assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo)
+
+
+def test_msm_gens_capacity_1024(gpu):
+    """capacity 1024 (BASELINE config 3: n = 1024 multipliers): 2050 resident generators."""
+    cap = 1024
+    Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
+    g = gpu.gens_create(Gp, Hp, B, B, 8)
+    try:
+        sc = o.random_scalars(99, 2 + 2 * cap)
+        assert gpu.msm_gens(g, 1, cap, sc) == o.msm(sc, B + B + Gp + Hp)
+    finally:
+        gpu.gens_destroy(g)
