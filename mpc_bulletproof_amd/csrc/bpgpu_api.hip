@@ -920,8 +920,8 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     sLa = s->t1; sLb = s->t2; sRa = s->t3; sRb = s->t4; so = h;
   }
   static const size_t pip_min = getenv("BPGPU_IPP_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_IPP_PIPPENGER_MIN")) : 257;
-  if (seg >= pip_min) {
-    // bucket method: make the 2 nb instances contiguous ([a_L | b_R | c_L] x [G_R | H_L | Q], then R's), one batched launch
+  {
+    // make the 2 nb MSM instances contiguous: L = [a_L | b_R | c_L] x [G_R | H_L | Q], then R = [a_R | b_L | c_R] x [G_L | H_R | Q]
     const size_t io = 2 * seg;
     gather_points(st, G + h, gouter, h, nb, s->mpts, io);            gather_scalars(st, sLa, so, h, nb, s->msc, io);
     gather_points(st, H, gouter, h, nb, s->mpts + h, io);            gather_scalars(st, sLb, so, h, nb, s->msc + h, io);
@@ -929,24 +929,18 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     gather_points(st, G, gouter, h, nb, s->mpts + seg, io);          gather_scalars(st, sRa, so, h, nb, s->msc + seg, io);
     gather_points(st, H + h, gouter, h, nb, s->mpts + seg + h, io);  gather_scalars(st, sRb, so, h, nb, s->msc + seg + h, io);
     gather_points(st, s->Q, 1, 1, nb, s->mpts + seg + 2 * h, io);    gather_scalars(st, s->cLR + 1, 2, 1, nb, s->msc + seg + 2 * h, io);
+  }
+  if (seg >= pip_min) {   // bucket method, one batched launch for all instances
     int cw = pippenger_window(seg);
     void *dpip;
     CK(ws_get(ctx, 14, pippenger_scratch_bytes_batch(nb * 2, seg, cw), &dpip));
     pippenger_batch(st, s->mpts, (const uint32_t *)s->msc, nb * 2, seg, cw, s->sums, 1, dpip);
-  } else {
-    auto run = [&](const Words8 *sc, size_t sc_outer, const AffDev *pts, size_t pt_outer, size_t cnt, size_t off) {
-      StrausArgs x{};
-      x.pts[0] = pts; x.pt_stride[0] = 1; x.pt_outer[0] = pt_outer;
-      x.sc[0] = (const uint32_t *)sc; x.sc_stride[0] = 8; x.sc_outer[0] = sc_outer * 8;
-      x.inner = cnt; x.out_outer = 2 * seg;
-      straus(st, 1, x, s->res + off, nb * cnt, dstr);
-    };
-    run(sLa, so, G + h, gouter, h, 0);              // L: a_L (.) G_R
-    run(sLb, so, H, gouter, h, h);                  //    b_R (.) H_L
-    run(s->cLR, 2, s->Q, 1, 1, 2 * h);              //    c_L Q
-    run(sRa, so, G, gouter, h, seg);                // R: a_R (.) G_L
-    run(sRb, so, H + h, gouter, h, seg + h);        //    b_L (.) H_R
-    run(s->cLR + 1, 2, s->Q, 1, 1, seg + 2 * h);    //    c_R Q
+  } else {                // short rounds: one Straus lane per term (a single launch), then a tree sum per instance
+    StrausArgs x{};
+    x.pts[0] = s->mpts; x.pt_stride[0] = 1;
+    x.sc[0] = (const uint32_t *)s->msc; x.sc_stride[0] = 8;
+    CK(straus_ws(ctx, 1, nb * 2 * seg, &dstr));
+    straus(st, 1, x, s->res, nb * 2 * seg, dstr);
     segmented_sum(st, s->res, s->sums, nb * 2, seg);
   }
   jac_to_boundary(st, s->sums, s->out_xy, nb * 2);

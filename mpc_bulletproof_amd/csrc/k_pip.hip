@@ -9,9 +9,8 @@
 //   2 k_pip_scan      exclusive scan of the W * 2^(c-1) bucket counts (single block)
 //   3 k_pip_scatter   counting-sort scatter (order inside a bucket is irrelevant: the sum commutes)
 //   4 k_pip_bucket    lane per bucket: gather its points (64 B rows) and accumulate with mixed adds
-//   5 k_pip_window    block per window: segmented running sums  sum_d d * B_d,  LDS tree sum,
-//                     then the window's 2^(c w) doublings
-//   6 k_pip_final     sum of the W window points
+//   5 k_pip_window    block per window: segmented running sums  S_w = sum_d d * B_d,  LDS tree sum
+//   6 k_pip_final     Horner over the windows: sum_w 2^(c w) S_w (252 doublings, one lane per instance)
 // Integer work only; step 5's doubling chain (<= 252 sequential doublings, ~1 ms) is the latency
 // floor of any variable-base MSM on this machine.
 #include "ec_dev.cuh"
@@ -56,29 +55,62 @@ __global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t
     keys[((size_t)inst * pp.W + w) * n + r] = key;
   }
 }
-// exclusive scan of `nb` counts into offsets[nb + 1]; cursor = copy of offsets
-__global__ void __launch_bounds__(1024) k_pip_scan(const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, size_t nb) {
+// exclusive scan of `nb` counts into offsets[nb + 1] (cursor = optional copy), three phases:
+// per-block sums of 2048-element tiles, single-block scan of the tile sums, per-tile scan + offset
+constexpr int SCAN_TILE = 2048;
+__global__ void __launch_bounds__(256) k_pip_scan_tiles(const uint32_t *counts, size_t nb, uint32_t *tile_sum) {
+  __shared__ uint32_t sm[4];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE;
+  uint32_t s = 0;
+  for (int j = threadIdx.x; j < SCAN_TILE; j += 256) { size_t i = base + j; if (i < nb) s += counts[i]; }
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) tile_sum[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void __launch_bounds__(1024) k_pip_scan_top(uint32_t *tile_sum, size_t ntiles, uint32_t *total_out) {
   __shared__ uint32_t part[1024];
   const int tid = threadIdx.x;
-  size_t per = (nb + 1023) / 1024, lo = tid * per, hi = lo + per < nb ? lo + per : nb;
+  size_t per = (ntiles + 1023) / 1024, lo = tid * per, hi = lo + per < ntiles ? lo + per : ntiles;
   uint32_t s = 0;
-  for (size_t j = lo; j < hi; j++) s += counts[j];
+  for (size_t j = lo; j < hi; j++) s += tile_sum[j];
   part[tid] = s;
   __syncthreads();
-  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+  for (int off = 1; off < 1024; off <<= 1) {
     uint32_t v = tid >= off ? part[tid - off] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
   uint32_t run = tid ? part[tid - 1] : 0;
-  for (size_t j = lo; j < hi; j++) {
-    uint32_t cj = counts[j];
-    offsets[j] = run;
-    if (cursor) cursor[j] = run;
-    run += cj;
+  for (size_t j = lo; j < hi; j++) { uint32_t c = tile_sum[j]; tile_sum[j] = run; run += c; }   // exclusive tile offsets
+  if (tid == 1023) *total_out = part[1023];
+}
+__global__ void __launch_bounds__(256) k_pip_scan_apply(const uint32_t *counts, const uint32_t *tile_off, size_t nb,
+                                                        uint32_t *offsets, uint32_t *cursor) {
+  __shared__ uint32_t sm[256];
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+  for (int j = 0; j < 8; j++) { v[j] = base + j < nb ? counts[base + j] : 0; s += v[j]; }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t t = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
   }
-  if (tid == 1023) offsets[nb] = part[1023];
+  uint32_t run = tile_off[blockIdx.x] + (threadIdx.x ? sm[threadIdx.x - 1] : 0);
+  for (int j = 0; j < 8; j++) {
+    if (base + j < nb) { offsets[base + j] = run; if (cursor) cursor[base + j] = run; }
+    run += v[j];
+  }
+}
+static void pip_scan(hipStream_t st, const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, size_t nb, uint32_t *tile_tmp) {
+  size_t ntiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(k_pip_scan_tiles, dim3(ntiles), dim3(256), 0, st, counts, nb, tile_tmp);
+  hipLaunchKernelGGL(k_pip_scan_top, dim3(1), dim3(1024), 0, st, tile_tmp, ntiles, offsets + nb);
+  hipLaunchKernelGGL(k_pip_scan_apply, dim3(ntiles), dim3(256), 0, st, counts, tile_tmp, nb, offsets, cursor);
 }
 __global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_t *keys, size_t n, size_t ninst,
                                                      uint32_t *cursor, uint32_t *sorted) {
@@ -153,18 +185,19 @@ __global__ void __launch_bounds__(PW_TPB) k_pip_window(PipParams pp, const JacRa
     if ((mulby >> bit) & 1) sm = jac_add(sm, run);
   }
   Jac acc = block_sum<PW_TPB>(jac_add(ws, sm), smem);
-  if (tid == 0) {
-    for (int d = 0; d < pp.c * w; d++) acc = jac_dbl(acc);
-    raw_store(&win_out[inst * pp.W + w], acc);
-  }
+  if (tid == 0) raw_store(&win_out[inst * pp.W + w], acc);
 }
-__global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, JacRaw *out, size_t out_stride) {
-  __shared__ int32_t smem[27 * 32];
-  const size_t inst = blockIdx.x;
-  Jac acc = jac_inf();
-  for (int w = threadIdx.x; w < W; w += 64) acc = jac_add(acc, raw_load(&win[inst * W + w]));
-  acc = block_sum<64>(acc, smem);
-  if (threadIdx.x == 0) raw_store(&out[inst * out_stride], acc);
+// Horner over the windows, one lane per instance: sum_w 2^(c w) S_w with 252 doublings in all
+// (per-window doubling would cost c W^2 / 2 of them)
+__global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, int c, size_t ninst, JacRaw *out, size_t out_stride) {
+  size_t inst = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (inst >= ninst) return;
+  Jac acc = raw_load(&win[inst * W + W - 1]);
+  for (int w = W - 2; w >= 0; w--) {
+    for (int d = 0; d < c; d++) acc = jac_dbl(acc);
+    acc = jac_add(acc, raw_load(&win[inst * W + w]));
+  }
+  raw_store(&out[inst * out_stride], acc);
 }
 
 // window choice: minimise  n * W (bucket adds) + W * 2^(c-1) * ~3 (running sums), c in [8, 16]
@@ -182,7 +215,7 @@ static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
   return al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-         al(ninst * W * sizeof(JacRaw));
+         al(ninst * W * sizeof(JacRaw)) + al((nbk / SCAN_TILE + 2) * 4);
 }
 size_t pippenger_scratch_bytes(size_t n, int c) { return pippenger_scratch_bytes_batch(1, n, c); }
 // ninst instances of n terms: pts / scalars hold instance-major arrays; out[inst * out_stride]
@@ -206,20 +239,21 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   uint32_t *task_bucket = (uint32_t *)p; p += al(mt * 4);
   JacRaw *partial = (JacRaw *)p; p += al(mt * sizeof(JacRaw));
   JacRaw *buckets = (JacRaw *)p; p += al(nbk * sizeof(JacRaw));
-  JacRaw *win = (JacRaw *)p;
+  JacRaw *win = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw));
+  uint32_t *tile_tmp = (uint32_t *)p;
   (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
   if (tot) hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, counts);
-  hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, counts, offsets, cursor, nbk);
+  pip_scan(st, counts, offsets, cursor, nbk, tile_tmp);
   if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
   hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
-  hipLaunchKernelGGL(k_pip_scan, dim3(1), dim3(1024), 0, st, tcount, toffsets, (uint32_t *)nullptr, nbk);
+  pip_scan(st, tcount, toffsets, nullptr, nbk, tile_tmp);
   hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
   hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
                      nbk, partial);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets);
   hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst), dim3(PW_TPB), 0, st, pp, buckets, win);
-  hipLaunchKernelGGL(k_pip_final, dim3(ninst), dim3(64), 0, st, win, pp.W, out, out_stride);
+  hipLaunchKernelGGL(k_pip_final, dim3((ninst + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
 }
 void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
   pippenger_batch(st, pts, scalars, 1, n, c, out, 1, scratch);

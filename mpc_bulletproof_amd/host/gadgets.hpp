@@ -54,7 +54,7 @@ inline void range_proof(ConstraintSystem &cs, LinearCombination v, const uint64_
     // Enforce that a = 1 - b, so they both are 1 or 0.
     cs.constrain(LinearCombination(abo[0]) + (LinearCombination(abo[1]) - LinearCombination(Scalar::one())));
     // Add `-b_i*2^i` to the linear combination
-    v = v - abo[1] * exp_2;
+    v.add_term(abo[1], -exp_2);   // v -= b * exp_2 (SubAssign in place, as the reference)
     exp_2 = exp_2 + exp_2;
   }
   // Enforce that v = Sum(b_i * 2^i, i = 0..n-1)
