@@ -187,6 +187,37 @@ def main():
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
 
+    # ---- secondary: the same per-proof verification with the Fiat-Shamir transcript replayed on the device
+    # (SURVEY 8f N1): inputs are the proofs + one 32-byte initial chain state per proof, no host challenges
+    fs = None
+    if not a.no_combined:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pymodel as pm
+        d_init = gpu.to_device(pm.Transcript(LABEL).state * nb)
+
+        def fstep(i):
+            j = i % len(ctxs)
+            ctxs[j].r1cs_verify_batch_fs_dev(gens, circ, nb, n1, k, d_init, d_pts, d_sc, d_oks[j])
+
+        for i in range(len(ctxs)):
+            fstep(i)
+        sync_all()
+        for c, d in zip(ctxs, d_oks):
+            assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            fstep(i)
+        sync_all()
+        fence()
+        fdt = time.perf_counter() - t0
+        if world > 1:
+            from mpc_bulletproof_amd import sharding
+            fdt = sharding.max_over_ranks(fdt)
+        fs = {"value": world * nb * a.steps / fdt, "unit": "verifications/s", "ms_per_step": fdt / a.steps * 1e3,
+              "note": "whole Verifier::verify incl. the transcript replay (keccak256 chain, hash_to_scalar) on the GPU; "
+                      "per-proof accept bits"}
+
     # ---- secondary: combined batch check (sum_p rho_p * check_p, one point per GPU; RCCL all-gather of
     # the 64-byte partials + local add).  Not the headline (the reference verifies proof by proof).
     comb = None
@@ -249,6 +280,7 @@ def main():
                              "peak": MAD_PEAK_TOPS, "unit": "Tmad/s", "frac": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
+            "with_device_transcript": fs,
             "combined_batch_check": comb,
         }
         print(json.dumps(out))

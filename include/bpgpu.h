@@ -53,7 +53,7 @@ int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
  * bench.py's `roofline` uses).  kinds: 0 verify_scalars, 1 fixed-base MSM, 2 point import,
- * 3 variable-base Straus, 4 verify tail.  read() synchronises, returns sums since the last read. */
+ * 3 variable-base Straus, 4 verify tail, 5 device transcript.  read() synchronises, returns sums since the last read. */
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]);
 
@@ -180,6 +180,21 @@ int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
                                 size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
                                 const void *challenges_dev, void *ok_dev, void *mega_dev,
                                 void *msm_scalars_dev);
+
+/* The same with the Fiat-Shamir transcript replayed ON THE DEVICE for circuits without
+ * randomized constraints: instead of challenges the caller passes, per proof, the 32-byte hash-chain state it
+ * holds when it would call Verifier::new (after Transcript::new(label) + any application preamble).  The
+ * device performs verifier.rs:271,303,398-455,506 and inner_product_proof.rs:269-278 (keccak256, LE
+ * absorption, hash_to_scalar util.rs:252-267), rejects identity points where the reference validates
+ * (transcript.rs:101-113 -> ok = 0), then proceeds as bpgpu_r1cs_verify_batch.  challenges_out (optional):
+ * nb x (6 + k) x 32 B, y z u x w r u_1..u_k.  The hash chain is the build's stand-in for merlin's
+ * HashChainTranscript (absent from the reference tree; parity unpinned -- DESIGN.md). */
+int bpgpu_r1cs_verify_batch_fs(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                               size_t k, const uint8_t *init_states, const uint8_t *points, const uint8_t *scalars,
+                               int32_t *ok, uint8_t *mega, uint8_t *challenges_out);
+int bpgpu_r1cs_verify_batch_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
+                                   size_t n1, size_t k, const void *init_states_dev, const void *points_dev,
+                                   const void *scalars_dev, void *ok_dev, void *mega_dev, void *challenges_out_dev);
 
 /* Combined batch check (NOT a reference API -- the reference verifies proof by proof; this is
  * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random

@@ -28,10 +28,13 @@ struct bpgpu_ctx {
   std::mutex mu;
   std::string err;
   int *d_flag = nullptr;          // device int: bad-input flag
-  Slot ws[16];                    // grow-only workspace slots
+  Slot ws[20];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
   std::vector<hipEvent_t> prof_ev[8];
+  // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
+  size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
+  int sched_len = 0;
 };
 struct ProfScope {   // records start/stop events on `st` around a launch when profiling is on
   bpgpu_ctx *c; int kind; hipStream_t st;
@@ -745,6 +748,72 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   return BPGPU_OK;
 }
 
+
+/* ---------------------------------------------------------------- Verifier::verify with the transcript on the device */
+static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                            const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
+                            void *challenges_out) {
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t m = c->m, np = (size_t)1 << k;
+  void *dsteps, *dch, *dbad;
+  CK(ws_get(ctx, 19, transcript_schedule_max(m, k) * sizeof(TrStep) + 64, &dsteps));
+  CK(ws_get(ctx, 17, nb * (6 + k) * 32, &dch));
+  CK(ws_get(ctx, 18, nb * 4, &dbad));
+  if (ctx->sched_key[0] != m || ctx->sched_key[1] != k || ctx->sched_key[2] != np) {
+    std::vector<TrStep> steps(transcript_schedule_max(m, k));
+    ctx->sched_len = transcript_schedule(steps.data(), m, k, np);
+    HIPCK(ctx, hipMemcpyAsync(dsteps, steps.data(), ctx->sched_len * sizeof(TrStep), hipMemcpyHostToDevice, ctx->st));
+    HIPCK(ctx, hipStreamSynchronize(ctx->st));   // `steps` is a local
+    ctx->sched_key[0] = m; ctx->sched_key[1] = k; ctx->sched_key[2] = np;
+  }
+  Words8 *chp = challenges_out ? (Words8 *)challenges_out : (Words8 *)dch;
+  {
+    ProfScope ps(ctx, 5, ctx->st);
+    verify_transcript(ctx->st, nb, m, k, (const TrStep *)dsteps, ctx->sched_len, (const Words8 *)init_states,
+                      (const Words8 *)points, (const Words8 *)scalars, chp, (int32_t *)dbad);
+  }
+  CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, chp, ok, mega, nullptr));
+  and_not(ctx->st, (int32_t *)ok, (const int32_t *)dbad, nb);
+  return launch_ok(ctx);
+}
+int bpgpu_r1cs_verify_batch_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                   const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
+                                   void *challenges_out) {
+  if (!ctx || !g || !c || (nb && (!init_states || !points || !scalars || !ok))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_fs_locked(ctx, g, c, nb, n1, k, init_states, points, scalars, ok, mega, challenges_out);
+}
+int bpgpu_r1cs_verify_batch_fs(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                               const uint8_t *init_states, const uint8_t *points, const uint8_t *scalars, int32_t *ok,
+                               uint8_t *mega, uint8_t *challenges_out) {
+  if (!ctx || !g || !c || (nb && (!init_states || !points || !scalars || !ok))) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t m = c->m, nvar = 11 + m + 2 * k;
+  void *dP, *dS, *dI, *dok, *dmega, *dcho;
+  CK(ws_get(ctx, 0, nb * nvar * 64, &dP));
+  CK(ws_get(ctx, 1, nb * 5 * 32, &dS));
+  CK(ws_get(ctx, 2, nb * 32, &dI));
+  CK(ws_get(ctx, 3, nb * 4 + nb * 64, &dok));
+  dmega = (uint8_t *)dok + ((nb * 4 + 63) / 64) * 64;
+  CK(ws_get(ctx, 16, nb * (6 + k) * 32, &dcho));
+  CK(h2d(ctx, dP, points, nb * nvar * 64));
+  CK(h2d(ctx, dS, scalars, nb * 5 * 32));
+  CK(h2d(ctx, dI, init_states, nb * 32));
+  CK(verify_fs_locked(ctx, g, c, nb, n1, k, dI, dP, dS, dok, mega ? dmega : nullptr, dcho));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, ok, dok, nb * 4));
+  if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
+  if (challenges_out) CK(d2h(ctx, challenges_out, dcho, nb * (6 + k) * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
 
 /* ---------------------------------------------------------------- combined batch check
  * sum_p rho_p * mega_check_p as ONE point: the generator terms collapse to a single fixed-base MSM with

@@ -117,6 +117,14 @@ void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Wor
                  const int32_t *polys, Words8 *l_vec, Words8 *r_vec);
 void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow);
 
+// ---- device-side verifier transcript (k_transcript.hip) ------------------------------
+struct TrStep { uint8_t kind, label, validate, pad; uint32_t src; uint64_t value; };
+size_t transcript_schedule_max(size_t m, size_t k);
+int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n);   // host: fills the step list, returns its length
+void verify_transcript(hipStream_t st, size_t nb, size_t m, size_t k, const TrStep *steps_dev, int nsteps, const Words8 *init_state,
+                       const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad);
+void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n);
+
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 // Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]

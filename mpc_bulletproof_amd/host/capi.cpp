@@ -2,6 +2,9 @@
 // oracle's flat API, so tests compare proof bytes / accept results one to one.
 // Return codes: 0 Ok, -1 VerificationError, -2 InvalidGeneratorsLength, -3 malformed/FormatError,
 // -4 MissingAssignment, -10 device failure (no CPU fallback).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "gadgets.hpp"
@@ -125,8 +128,17 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
                           const uint64_t *values, uint64_t seed0, size_t gens_capacity, uint8_t *proofs_out,
                           size_t *proof_len, uint8_t *commitments_out) {
   GUARD({
+    const bool timing = getenv("BPH_TIMING") != nullptr;
+    auto T0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+      if (!timing) return;
+      auto t = std::chrono::steady_clock::now();
+      std::fprintf(stderr, "[bph] %-22s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(t - T0).count());
+      T0 = t;
+    };
     PedersenGens pc_gens;
     BulletproofGens bp_gens(gens_capacity, 1);
+    lap("generators");
     std::vector<std::unique_ptr<Transcript>> trs;
     std::vector<std::unique_ptr<Prover>> provers;
     std::vector<std::unique_ptr<Rng>> rngs;
@@ -140,6 +152,7 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
       for (size_t j = 0; j < nvals; j++) { vs.push_back(Scalar::from(values[p * nvals + j])); bls.push_back(rngs.back()->scalar()); }
     }
     auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
+    lap("tables + commitments");
     for (size_t p = 0; p < nb; p++) {
       trs.emplace_back(new Transcript(std::string((const char *)label, label_len)));
       provers.emplace_back(new Prover(pc_gens, *trs.back()));
@@ -153,7 +166,9 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
       pp.push_back(provers.back().get());
       rr.push_back(rngs[p].get());
     }
+    lap("circuit building");
     auto proofs = Prover::prove_batch(pp, bp_gens, rr);
+    lap("prove_batch");
     for (size_t p = 0; p < nb; p++) {
       auto bytes = proofs[p].to_flat_bytes();
       *proof_len = bytes.size();

