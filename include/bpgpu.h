@@ -124,6 +124,14 @@ typedef struct bpgpu_ipp bpgpu_ipp;
 int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
                     const uint8_t *H_factors, const uint8_t *G, const uint8_t *H, int shared_gens,
                     const uint8_t *a, const uint8_t *b, bpgpu_ipp **out);
+/* The same session over RESIDENT generators (G, H = the first n of `g`, Q = w * B with B = g's Pedersen base:
+ * exactly what r1cs/prover.rs:687-708 passes).  No generator is ever folded: round j's L, R are fixed-base
+ * MSMs over the original generators with the accumulated challenge products folded into the scalars, so a
+ * round costs table lookups instead of two 252-doubling chains.  Same outputs as bpgpu_ipp_begin.
+ * w: nb x 32 B. */
+int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *w,
+                         const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *a, const uint8_t *b,
+                         bpgpu_ipp **out);
 void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s);
 size_t bpgpu_ipp_len(const bpgpu_ipp *s);
 int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R);

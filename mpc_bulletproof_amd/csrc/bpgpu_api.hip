@@ -66,6 +66,8 @@ struct bpgpu_ipp {
   Words8 *msc = nullptr;                                           //   (bucket-method rounds)
   Words8 *out_xy = nullptr;                                        // nb x 2 points
   int cur = 0;                                                     // index of the live a/b/G/H buffers
+  const bpgpu_gens *gens = nullptr;                                // resident-generator mode: no G/H buffers,
+  Words8 *cG = nullptr, *cH = nullptr, *w = nullptr;               //   coefficient vectors nb x n0 and Q = w * B
 };
 struct bpgpu_circuit {
   size_t q = 0, n = 0, m = 0, nnz = 0;
@@ -128,31 +130,12 @@ __global__ void k_coeff_to_mont(Words8 *io, size_t n, int *bad) {
   bp::pack(w, x);
   for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
 }
-// expand [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] scalars (2 + 2n per MSM) to table-row order when n < cap
-__global__ void k_expand_gens_scalars(const uint32_t *in, uint32_t *out, size_t n, size_t cap, size_t nb) {
-  size_t per_out = 2 + 2 * cap;
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= nb * per_out) return;
-  size_t b = t / per_out, g = t % per_out;
-  long src = -1;
-  if (g < 2) src = (long)g;
-  else if (g < 2 + cap) { if (g - 2 < n) src = (long)g; }
-  else { if (g - 2 - cap < n) src = (long)(2 + n + (g - 2 - cap)); }
-  for (int j = 0; j < 8; j++) out[t * 8 + j] = src >= 0 ? in[(b * (2 + 2 * n) + (size_t)src) * 8 + j] : 0u;
-}
 static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
                         hipStream_t st) {
-  size_t ng = 2 + 2 * g->cap;
-  if (n == g->cap) {
-    fixed_msm(st, g->c, g->table, ng, dsc, ng * 8, dres, nb);
-  } else {
-    void *dexp;
-    CK(ws_get(ctx, 12, nb * ng * 32, &dexp));
-    size_t tot = nb * ng;
-    hipLaunchKernelGGL(k_expand_gens_scalars, dim3((tot + 255) / 256), dim3(256), 0, st, dsc, (uint32_t *)dexp, n,
-                       g->cap, nb);
-    fixed_msm(st, g->c, g->table, ng, (const uint32_t *)dexp, ng * 8, dres, nb);
-  }
+  size_t chunks = fixed_msm_chunks(g->c, n, nb);
+  void *dpart = nullptr;
+  if (chunks > 1) CK(ws_get(ctx, 12, nb * chunks * sizeof(JacRaw), &dpart));
+  fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart);
   return BPGPU_OK;
 }
 
@@ -654,7 +637,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   CK(ws_get(ctx, 7, nb * nvar * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, nb * nvar * 32, &dvar));
-  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m}) * 4, &dzp));
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
   CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
   void *dstr;
@@ -836,7 +819,7 @@ static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(ws_get(ctx, 7, tot * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, tot * 32, &dvar));
-  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m}) * 4, &dzp));
   CK(ws_get(ctx, 10, nfix * 32, &dfsum));
   CK(ws_get(ctx, 11, 2 * sizeof(JacRaw), &dtwo));
   CK(ws_get(ctx, 15, sizeof(JacRaw), &dsum));
@@ -903,6 +886,7 @@ static void ipp_free_all(bpgpu_ipp *s) {
   for (int i = 0; i < 2; i++) { hipFree(s->a[i]); hipFree(s->b[i]); hipFree(s->G[i]); hipFree(s->H[i]); }
   hipFree(s->Q); hipFree(s->Gf); hipFree(s->Hf); hipFree(s->t1); hipFree(s->t2); hipFree(s->t3); hipFree(s->t4);
   hipFree(s->cLR); hipFree(s->uu); hipFree(s->res); hipFree(s->sums); hipFree(s->out_xy); hipFree(s->mpts); hipFree(s->msc);
+  hipFree(s->cG); hipFree(s->cH); hipFree(s->w);
   delete s;
 }
 int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
@@ -956,6 +940,47 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   *out = s;
   return BPGPU_OK;
 }
+int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *w,
+                         const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *a, const uint8_t *b,
+                         bpgpu_ipp **out) {
+  if (!ctx || !g || !out || !nb || !w || !G_factors || !H_factors || !a || !b) return BPGPU_E_ARG;
+  if (!n || (n & (n - 1))) return BPGPU_E_LEN;   // assert!(n.is_power_of_two()), inner_product_proof.rs:70
+  if (n > g->cap) return BPGPU_E_GENS;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
+  if (!s) return BPGPU_E_OOM;
+  s->nb = nb; s->n0 = s->n = n; s->gens = g;
+  size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
+  bool okk = true;
+  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
+  M((void **)&s->cG, tot * 32); M((void **)&s->cH, tot * 32); M((void **)&s->w, nb * 32);
+  M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
+  M((void **)&s->sums, nb * 2 * sizeof(JacRaw)); M((void **)&s->out_xy, nb * 2 * 64);
+  M((void **)&s->msc, nb * 2 * (2 + 2 * n) * 32);
+  if (!okk) { ipp_free_all(s); return BPGPU_E_OOM; }
+  int rc = BPGPU_OK;
+  do {
+    if ((rc = flag_reset(ctx))) break;
+    if ((rc = h2d(ctx, s->a[0], a, tot * 32)) || (rc = h2d(ctx, s->b[0], b, tot * 32)) ||
+        (rc = h2d(ctx, s->cG, G_factors, tot * 32)) || (rc = h2d(ctx, s->cH, H_factors, tot * 32)) ||
+        (rc = h2d(ctx, s->w, w, nb * 32))) break;
+    scalars_check(ctx->st, s->a[0], tot, ctx->d_flag);
+    scalars_check(ctx->st, s->b[0], tot, ctx->d_flag);
+    scalars_check(ctx->st, s->cG, tot, ctx->d_flag);
+    scalars_check(ctx->st, s->cH, tot, ctx->d_flag);
+    scalars_check(ctx->st, s->w, nb, ctx->d_flag);
+    if ((rc = launch_ok(ctx))) break;
+    int bad = 0;
+    if ((rc = flag_read(ctx, &bad))) break;
+    if (bad) rc = BPGPU_E_ARG;
+  } while (0);
+  if (rc) { ipp_free_all(s); return rc; }
+  *out = s;
+  return BPGPU_OK;
+}
 void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s) {
   if (!s) return;
   if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
@@ -972,6 +997,19 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
   hipStream_t st = ctx->st;
   const size_t nb = s->nb, n = s->n, h = n / 2, seg = 2 * h + 1;
   Words8 *a = s->a[s->cur], *b = s->b[s->cur];
+  if (s->gens) {   // resident generators: two table-lookup MSMs over the original generators per proof
+    sc_dot_batched(st, nb, h, a, n, b + h, n, s->cLR, 2);        // c_L = <a_L, b_R>
+    sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
+    ipp_gens_scalars(st, nb, s->n0, n, a, b, s->cG, s->cH, s->cLR, s->w, s->msc);
+    CK(msm_gens_dev(ctx, s->gens, nb * 2, s->n0, (const uint32_t *)s->msc, s->sums, st));
+    jac_to_boundary(st, s->sums, s->out_xy, nb * 2);
+    CK(launch_ok(ctx));
+    std::vector<uint8_t> tmp(nb * 128);
+    CK(d2h(ctx, tmp.data(), s->out_xy, nb * 128));
+    HIPCK(ctx, hipStreamSynchronize(st));
+    for (size_t p = 0; p < nb; p++) { memcpy(L + 64 * p, &tmp[128 * p], 64); memcpy(R + 64 * p, &tmp[128 * p + 64], 64); }
+    return BPGPU_OK;
+  }
   const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
   const bool shared = s->first && s->shared_gens;
   const size_t gouter = shared ? 0 : n;
@@ -1034,6 +1072,16 @@ int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t
   CK(h2d(ctx, du, u, nb * 32));
   CK(h2d(ctx, dui, u_inv, nb * 32));
   scalars_check(st, s->uu, 2 * nb, ctx->d_flag);
+  if (s->gens) {
+    ipp_gens_fold(st, nb, s->n0, n, du, dui, s->cG, s->cH);
+    fold_scalars_batched(st, nb, h, du, dui, s->a[cur], s->b[cur], s->a[nxt], s->b[nxt]);
+    CK(launch_ok(ctx));
+    int bad = 0;
+    CK(flag_read(ctx, &bad));
+    if (bad) return BPGPU_E_ARG;
+    s->cur = nxt; s->n = h; s->first = false;
+    return BPGPU_OK;
+  }
   const AffDev *G = s->G[cur], *H = s->H[cur];
   const bool shared = s->first && s->shared_gens;
   const size_t gouter = shared ? 0 : n;

@@ -107,26 +107,31 @@ void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, siz
   else hipLaunchKernelGGL((k_segmented_sum<128>), dim3(nb), dim3(128), 0, st, in, out, n);
 }
 
-// One block per MSM; lane l walks (generator, window) pairs l, l+TPB, ...; table row index == pair index.
+// Block (chunk, msm): lane l walks the (generator, window) pairs l, l+TPB, ... of its chunk.  The MSM uses the
+// generators [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] of a table built for capacity cap >= n: used generator g lives
+// in table row block g (g < 2 + n) or g + (cap - n) (the H section); scalars are compact (2 + 2n per MSM).
 template <int C, int TPB>
-__global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t ngens, const uint32_t *scalars,
-                                                   size_t sc_stride, JacRaw *out) {
+__global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                   size_t sc_stride, JacRaw *out, size_t pairs_per_chunk) {
   __shared__ int32_t red[27 * (TPB / 2)];
   constexpr int W = num_windows<C>();
   constexpr int HALF = 1 << (C - 1);
   const int tid = threadIdx.x;
-  const uint32_t *sc = scalars + (size_t)blockIdx.x * sc_stride;
-  const size_t total = ngens * W;
+  const uint32_t *sc = scalars + (size_t)blockIdx.y * sc_stride;
+  const size_t total = (2 + 2 * n) * W;
+  const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
+  const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
+  const size_t hshift = cap - n;
   Jac acc = jac_inf();
   // software prefetch of the next table row while the current madd runs.  The scalar words come from
   // L1/L2 (the W lanes of one generator read the same 32 bytes) and are recoded on the fly: staging all
   // recoded scalars in LDS needs 36 B per generator -- 81 KB at capacity 1024, past the 64 KB dynamic limit.
   uint32_t cur[16];
   int dcur = 0;
-  size_t l = tid;
+  size_t l = lo + tid;
   auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
     dg = 0;
-    if (ll < total) {
+    if (ll < hi) {
       size_t g = ll / W;
       int w = (int)(ll - g * W);
       uint32_t s[8], r[9];
@@ -135,14 +140,15 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
       recode_add_k<C>(r, s);
       dg = recode_digit<C>(r, w);
       if (dg != 0) {
-        const AffDev *e = table + ll * HALF + ((dg < 0 ? -dg : dg) - 1);
+        size_t row = (g < 2 + n ? g : g + hshift) * W + w;
+        const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
 #pragma unroll
         for (int t = 0; t < 16; t++) dst[t] = e->w[t];
       }
     }
   };
   fetch(l, cur, dcur);
-  while (l < total) {
+  while (l < hi) {
     uint32_t nxt[16];
     int dnxt;
     fetch(l + TPB, nxt, dnxt);
@@ -159,26 +165,38 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
     l += TPB;
   }
   acc = block_sum<TPB>(acc, red);
-  if (tid == 0) raw_store(&out[blockIdx.x], acc);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+// chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
+size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
+  size_t total = (2 + 2 * n) * (252 / c + 1);
+  size_t by_work = (total + 511) / 512, by_fill = (1024 + nb - 1) / (nb ? nb : 1);
+  size_t ch = by_work < by_fill ? by_work : by_fill;
+  return ch ? ch : 1;
 }
 template <int C>
-static void launch_fixed(hipStream_t st, const AffDev *table, size_t ngens, const uint32_t *scalars, size_t stride,
-                         JacRaw *out, size_t nb) {
+static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t stride,
+                         JacRaw *out, size_t nb, size_t chunks) {
   constexpr int TPB = 128;
-  hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(nb), dim3(TPB), 0, st, table, ngens, scalars, stride, out);
+  size_t total = (2 + 2 * n) * num_windows<C>();
+  size_t per = (total + chunks - 1) / chunks;
+  hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(chunks, nb), dim3(TPB), 0, st, table, n, cap, scalars, stride, out, per);
 }
-void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t ngens, const uint32_t *scalars,
-               size_t stride, JacRaw *out, size_t nb) {
+void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+               size_t stride, JacRaw *out, size_t nb, JacRaw *partials) {
   if (!nb) return;
+  size_t chunks = partials ? fixed_msm_chunks(c, n, nb) : 1;
+  JacRaw *dst = chunks > 1 ? partials : out;
   switch (c) {
-    case 4: launch_fixed<4>(st, table, ngens, scalars, stride, out, nb); break;
-    case 8: launch_fixed<8>(st, table, ngens, scalars, stride, out, nb); break;
-    case 10: launch_fixed<10>(st, table, ngens, scalars, stride, out, nb); break;
-    case 12: launch_fixed<12>(st, table, ngens, scalars, stride, out, nb); break;
-    case 14: launch_fixed<14>(st, table, ngens, scalars, stride, out, nb); break;
-    case 16: launch_fixed<16>(st, table, ngens, scalars, stride, out, nb); break;
-    default: break;   // rejected by the C-ABI before reaching here
+    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    default: return;   // rejected by the C-ABI before reaching here
   }
+  if (chunks > 1) segmented_sum(st, partials, out, nb, chunks);
 }
 
 }  // namespace bpk

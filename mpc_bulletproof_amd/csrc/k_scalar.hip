@@ -4,6 +4,7 @@
 // Hot-path rows: a2 (scalar half of fold_witness), a4 inner_product, a5
 // verification_scalars, a6 batch_inverse, a7 flattened_constraints, a9 verifier scalar assembly.
 #include "fe29.cuh"
+#include <cstdlib>
 #include "kernels.h"
 
 using namespace bp;
@@ -283,6 +284,62 @@ void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, si
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- IPP over RESIDENT generators (no generator folding): after j rounds the folded generator G^(j)_t is
+// sum over the original i == t (mod cur) of cG_i * G_i, so the round's L and R (inner_product_proof.rs:90-114,
+// 159-172) are MSMs over the ORIGINAL generators with scalars a_.. * cG_i / b_.. * cH_i -- table lookups
+// without a single doubling -- and the fold of G, H (:125-146, 202-248) becomes a scalar update of cG, cH.
+// msc layout: [proof][L | R][B, B_blinding, G_0..G_{n0-1}, H_0..H_{n0-1}];  Q = w * B.
+__global__ void __launch_bounds__(256) k_ipp_gens_scalars(size_t n0, size_t cur, const Words8 *a, const Words8 *b,
+                                                          const Words8 *cG, const Words8 *cH, const Words8 *cLR,
+                                                          const Words8 *w, Words8 *msc) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= n0) return;
+  const size_t h = cur / 2, t = i & (cur - 1), tl = t & (h - 1), per = 2 + 2 * n0;
+  const bool hi = t >= h;
+  const Words8 *ap = a + p * cur, *bp = b + p * cur;
+  Words8 *L = msc + (p * 2) * per, *R = L + per;
+  Fn cg = load_plain(&cG[p * n0 + i]), ch = load_plain(&cH[p * n0 + i]);
+  Fn zero = fe_zero<FN>();
+  if (hi) {
+    store_plain(&L[2 + i], mul(load_plain(&ap[tl]), cg));        // <a_L, G_R>
+    store_plain(&L[2 + n0 + i], zero);
+    store_plain(&R[2 + i], zero);
+    store_plain(&R[2 + n0 + i], mul(load_plain(&bp[tl]), ch));   // <b_L, H_R>
+  } else {
+    store_plain(&L[2 + i], zero);
+    store_plain(&L[2 + n0 + i], mul(load_plain(&bp[h + tl]), ch));   // <b_R, H_L>
+    store_plain(&R[2 + i], mul(load_plain(&ap[h + tl]), cg));        // <a_R, G_L>
+    store_plain(&R[2 + n0 + i], zero);
+  }
+  if (i == 0) {
+    Fn ww = load_plain(&w[p]);
+    store_plain(&L[0], mul(load_plain(&cLR[2 * p]), ww));       // c_L * Q
+    store_plain(&L[1], zero);
+    store_plain(&R[0], mul(load_plain(&cLR[2 * p + 1]), ww));   // c_R * Q
+    store_plain(&R[1], zero);
+  }
+}
+void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,
+                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc) {
+  if (!nb || !n0) return;
+  hipLaunchKernelGGL(k_ipp_gens_scalars, dim3((n0 + 255) / 256, nb), dim3(256), 0, st, n0, cur, a, b, cG, cH, cLR, w, msc);
+}
+// G' = u^-1 G_L + u G_R ; H' = u H_L + u^-1 H_R as coefficient updates
+__global__ void __launch_bounds__(256) k_ipp_gens_fold(size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv,
+                                                       Words8 *cG, Words8 *cH) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= n0) return;
+  const bool hi = (i & (cur - 1)) >= cur / 2;
+  Fn uu = load_plain(&u[p]), ui = load_plain(&u_inv[p]);
+  store_plain(&cG[p * n0 + i], mul(load_plain(&cG[p * n0 + i]), hi ? uu : ui));
+  store_plain(&cH[p * n0 + i], mul(load_plain(&cH[p * n0 + i]), hi ? ui : uu));
+}
+void ipp_gens_fold(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv, Words8 *cG,
+                   Words8 *cH) {
+  if (!nb || !n0) return;
+  hipLaunchKernelGGL(k_ipp_gens_fold, dim3((n0 + 255) / 256, nb), dim3(256), 0, st, n0, cur, u, u_inv, cG, cH);
+}
+
 // flattened_constraints: zpow[b][r] = z_b^(r+1); output o = sum over its column of coeff * zpow[row]
 // (w_V and w_c carry the reference's minus sign: prover.rs:367-369, verifier.rs:349-354)
 __global__ void __launch_bounds__(256) k_zpow(const Words8 *z, size_t z_stride, size_t q, int32_t *zpow) {
@@ -545,13 +602,196 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
     }
   }
 }
+// ---- the same assembly for LARGE proofs, split over the grid (one proof of the 2^14-shuffle has padded_n = 2^15,
+// q = 65 533, m = 32 768: a single block per proof would serialise ~10^5 field multiplications per lane).
+// aux per proof (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[32], 34.. u_inv_sq[32], 66.. delta partials[VSL_PARTS],
+// then w_c partials[VSL_PARTS]
+constexpr int VSL_PARTS = 256, VSL_AUX = 66 + 2 * VSL_PARTS, VSL_TPB = 128;
+__global__ void __launch_bounds__(64) k_vsl_prep(VerifyDims d, const Words8 *challenges, int32_t *aux_all) {
+  const size_t p = blockIdx.x, k = d.k;
+  if (threadIdx.x != 0) return;
+  const Words8 *ch = challenges + p * (6 + k);
+  int32_t *aux = aux_all + p * VSL_AUX * NL;
+  Fn pref[33], val[33];
+  Fn acc = fe_one<FN>();
+  val[0] = load_plain(&ch[0]);
+  for (size_t i = 0; i < k; i++) val[1 + i] = load_plain(&ch[6 + i]);
+  for (size_t i = 0; i <= k; i++) { pref[i] = acc; acc = mul(acc, val[i]); }
+  Fn ai = inv_gcd(acc);
+  Fn allinv = fe_one<FN>();
+  for (int i = (int)k; i >= 0; i--) {
+    Fn vi = mul(ai, pref[i]);
+    ai = mul(ai, val[i]);
+    if (i == 0) raw_put(aux, vi);
+    else {
+      allinv = mul(allinv, vi);
+      raw_put(aux + (2 + i - 1) * NL, sqr(val[i]));
+      raw_put(aux + (34 + i - 1) * NL, sqr(vi));
+    }
+  }
+  raw_put(aux + NL, allinv);
+}
+// g_i, h_i (verifier.rs:469-501) + per-block delta partial; blockIdx.y = proof; grid-stride over i
+__global__ void __launch_bounds__(VSL_TPB) k_vsl_gh(CircuitDev c, VerifyDims d, const Words8 *challenges,
+                                                    const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *full_sc,
+                                                    const int32_t *zpow_all, int32_t *aux_all) {
+  __shared__ int32_t s_part[NL * (VSL_TPB / 64)];
+  const size_t p = blockIdx.y;
+  const int tid = threadIdx.x;
+  const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m, n1 = d.n1;
+  const Words8 *ch = challenges + p * (6 + k);
+  const Words8 *ps = proof_scalars + p * 5;
+  const int32_t *zpow = zpow_all + p * c.q * NL;
+  int32_t *aux = aux_all + p * VSL_AUX * NL;
+  const int32_t *s_usq = aux + 2 * NL;
+  Fn u = load_plain(&ch[2]), x = load_plain(&ch[3]);
+  Fn y_inv = raw_get(aux), allinv = raw_get(aux + NL);
+  Fn a = load_plain(&ps[3]), b = load_plain(&ps[4]);
+  const size_t nterms = 13 + m + 2 * np + 2 * k;
+  Words8 *fx = fixed_sc + p * (2 + 2 * np);
+  Words8 *full = full_sc ? full_sc + p * nterms : nullptr;
+  const size_t off_g = 13 + m, off_h = 13 + m + np;
+  Fn dpart = fe_zero<FN>();
+  int dcnt = 0;
+  for (size_t i = (size_t)blockIdx.x * VSL_TPB + tid; i < np; i += (size_t)gridDim.x * VSL_TPB) {
+    if ((++dcnt & 15) == 0) dpart = fn_reduce(dpart);
+    Fn yi = fn_pow_u32(y_inv, (uint32_t)i);
+    Fn si = allinv, sr = allinv;
+    size_t ir = np - 1 - i;
+    for (size_t bb = 0; bb < k; bb++) {
+      Fn us = raw_get(s_usq + (k - 1 - bb) * NL);
+      if ((i >> bb) & 1) si = mul(si, us);
+      if ((ir >> bb) & 1) sr = mul(sr, us);
+    }
+    Fn wLi = fe_zero<FN>(), wRi = fe_zero<FN>(), wOi = fe_zero<FN>();
+    if (i < n) {
+      wLi = flatten_column(c, i, zpow);
+      wRi = flatten_column(c, n + i, zpow);
+      wOi = flatten_column(c, 2 * n + i, zpow);
+    }
+    Fn yneg_wR = mul(wRi, yi);
+    dpart = add(dpart, mul(yneg_wR, wLi));
+    Fn g = sub(mul(x, yneg_wR), mul(a, si));
+    Fn h = sub(mul(yi, sub(add(mul(x, wLi), wOi), mul(b, sr))), fe_one<FN>());
+    if (i >= n1) { g = mul(u, g); h = mul(u, h); }
+    store_plain(&fx[2 + i], g);
+    store_plain(&fx[2 + np + i], h);
+    if (full) { store_plain(&full[off_g + i], g); store_plain(&full[off_h + i], h); }
+  }
+  dpart = wave_sum(fn_reduce(dpart));
+  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, fn_reduce(dpart));
+  __syncthreads();
+  if (tid == 0) {
+    Fn t = raw_get(s_part);
+    for (int w = 1; w < VSL_TPB / 64; w++) t = add(t, raw_get(s_part + w * NL));
+    raw_put(aux + (66 + blockIdx.x) * NL, t);
+  }
+}
+// partial sums of the `One` column (w_c before the sign, verifier.rs:352-354)
+__global__ void __launch_bounds__(VSL_TPB) k_vsl_wc(CircuitDev c, VerifyDims d, const int32_t *zpow_all, int32_t *aux_all) {
+  __shared__ int32_t s_part[NL * (VSL_TPB / 64)];
+  const size_t p = blockIdx.y;
+  const int tid = threadIdx.x;
+  const int32_t *zpow = zpow_all + p * c.q * NL;
+  int32_t *aux = aux_all + p * VSL_AUX * NL;
+  const size_t o = 3 * d.n + d.m;
+  Fn wcp = fe_zero<FN>();
+  int cnt = 0;
+  for (size_t t = (size_t)c.col_ptr[o] + (size_t)blockIdx.x * VSL_TPB + tid; t < c.col_ptr[o + 1]; t += (size_t)gridDim.x * VSL_TPB) {
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = c.coeff[t].w[j];
+    wcp = add(wcp, mul(unpack<FN>(w), raw_get(zpow + (size_t)c.row[t] * NL)));
+    if ((++cnt & 15) == 0) wcp = fn_reduce(wcp);
+  }
+  wcp = wave_sum(fn_reduce(wcp));
+  if ((tid & 63) == 0) raw_put(s_part + (tid >> 6) * NL, fn_reduce(wcp));
+  __syncthreads();
+  if (tid == 0) {
+    Fn t = raw_get(s_part);
+    for (int w = 1; w < VSL_TPB / 64; w++) t = add(t, raw_get(s_part + w * NL));
+    raw_put(aux + (66 + VSL_PARTS + blockIdx.x) * NL, t);
+  }
+}
+// the remaining 11 + m + 2k + 2 scalars (verifier.rs:508-532), one lane each
+__global__ void __launch_bounds__(VSL_TPB) k_vsl_tail(CircuitDev c, VerifyDims d, const Words8 *challenges,
+                                                      const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc,
+                                                      Words8 *full_sc, const int32_t *zpow_all, const int32_t *aux_all,
+                                                      int gh_parts, int wc_parts) {
+  const size_t p = blockIdx.y;
+  const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m;
+  const size_t nvar = 11 + m + 2 * k, nterms = 13 + m + 2 * np + 2 * k;
+  const size_t v = (size_t)blockIdx.x * VSL_TPB + threadIdx.x;
+  if (v >= nvar + 2) return;
+  const Words8 *ch = challenges + p * (6 + k);
+  const Words8 *ps = proof_scalars + p * 5;
+  const int32_t *zpow = zpow_all + p * c.q * NL;
+  const int32_t *aux = aux_all + p * VSL_AUX * NL;
+  Words8 *fx = fixed_sc + p * (2 + 2 * np);
+  Words8 *vs = var_sc + p * nvar;
+  Words8 *full = full_sc ? full_sc + p * nterms : nullptr;
+  Fn u = load_plain(&ch[2]), x = load_plain(&ch[3]), r = load_plain(&ch[5]);
+  Fn xx = sqr(x), rxx = mul(r, xx), xxx = mul(x, xx);
+  Fn val;
+  size_t fpos = v;
+  if (v < 3) val = v == 0 ? x : (v == 1 ? xx : xxx);
+  else if (v < 6) val = mul(u, v == 3 ? x : (v == 4 ? xx : xxx));
+  else if (v < 6 + m) val = mul(flatten_column(c, 3 * n + (v - 6), zpow), rxx);
+  else if (v < 11 + m) {
+    size_t ti = v - 6 - m;
+    val = ti == 0 ? mul(r, x) : ti == 1 ? mul(rxx, x) : ti == 2 ? mul(rxx, xx) : ti == 3 ? mul(rxx, xxx) : mul(mul(rxx, xx), xx);
+  } else if (v < 11 + m + k) { val = raw_get(aux + (2 + v - 11 - m) * NL); fpos = 13 + m + 2 * np + (v - 11 - m); }
+  else if (v < nvar) { val = raw_get(aux + (34 + v - 11 - m - k) * NL); fpos = 13 + m + 2 * np + k + (v - 11 - m - k); }
+  else if (v == nvar) {
+    Fn delta = fe_zero<FN>(), wc = fe_zero<FN>();
+    for (int i = 0; i < gh_parts; i++) { delta = add(delta, raw_get(aux + (66 + i) * NL)); if ((i & 7) == 7) delta = fn_reduce(delta); }
+    for (int i = 0; i < wc_parts; i++) { wc = add(wc, raw_get(aux + (66 + VSL_PARTS + i) * NL)); if ((i & 7) == 7) wc = fn_reduce(wc); }
+    delta = fn_reduce(delta);
+    wc = neg(fn_reduce(wc));
+    Fn w_ch = load_plain(&ch[4]), t_x = load_plain(&ps[0]);
+    Fn a = load_plain(&ps[3]), b = load_plain(&ps[4]);
+    val = add(mul(w_ch, sub(t_x, mul(a, b))), mul(r, sub(mul(xx, add(wc, delta)), t_x)));
+    fpos = 11 + m;
+  } else {
+    val = neg(add(load_plain(&ps[2]), mul(r, load_plain(&ps[1]))));
+    fpos = 12 + m;
+  }
+  if (v < nvar) store_plain(&vs[v], val);
+  else store_plain(&fx[v - nvar], val);
+  if (full) store_plain(&full[fpos], val);
+}
+
+static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
+  const size_t thr = getenv("BPGPU_VS_LARGE_MIN") ? (size_t)atol(getenv("BPGPU_VS_LARGE_MIN")) : 4096;
+  return d.padded_n >= thr || d.m >= thr || c.q >= 4 * thr;
+}
+size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {
+  return d.nb * ((c.q ? c.q : 1) + (vs_large(c, d) ? VSL_AUX : 0)) * NL;
+}
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad) {
   (void)bad;
   if (!d.nb) return;
-  hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
-                     fixed_sc, var_sc, full_sc, zpow_scratch);
+  if (!vs_large(c, d)) {
+    hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
+                       fixed_sc, var_sc, full_sc, zpow_scratch);
+    return;
+  }
+  int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
+  auto parts = [](size_t work) { size_t b = (work + VSL_TPB - 1) / VSL_TPB; return (int)(b < 1 ? 1 : (b > VSL_PARTS ? VSL_PARTS : b)); };
+  const size_t o = 3 * d.n + d.m;
+  (void)o;
+  // number of `One` terms is only known on the device (col_ptr); size its grid from the row count
+  const int gh_parts = parts(d.padded_n), wc_parts = parts(c.q);
+  hipLaunchKernelGGL(k_vsl_prep, dim3(d.nb), dim3(64), 0, st, d, challenges, aux);
+  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, d.nb), dim3(256), 0, st, challenges + 1, (6 + d.k) * 8, c.q, zpow_scratch);
+  hipLaunchKernelGGL(k_vsl_gh, dim3(gh_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, challenges, proof_scalars, fixed_sc,
+                     full_sc, zpow_scratch, aux);
+  hipLaunchKernelGGL(k_vsl_wc, dim3(wc_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, zpow_scratch, aux);
+  const size_t nvar = 11 + d.m + 2 * d.k;
+  hipLaunchKernelGGL(k_vsl_tail, dim3((nvar + 2 + VSL_TPB - 1) / VSL_TPB, d.nb), dim3(VSL_TPB), 0, st, c, d, challenges,
+                     proof_scalars, fixed_sc, var_sc, full_sc, zpow_scratch, aux, gh_parts, wc_parts);
 }
 
 }  // namespace bpk

@@ -59,9 +59,12 @@ void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, siz
 size_t fixed_table_entries(int c, size_t ngens);
 void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, AffDev *table,
                        JacRaw *scratch /* >= ngens*W + entries */);
-// out[b] = sum_g scalars[b*sc_stride + g*8 ..] * P_g  via table lookups (plain canonical scalars)
-void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t ngens_used, const uint32_t *scalars,
-               size_t sc_stride_words, JacRaw *out, size_t nb);
+// out[b] = sum_g scalars[b*sc_stride + g*8 ..] * P_g over the generators [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] of a
+// table built for capacity cap >= n, via table lookups (plain canonical scalars, 2 + 2n per MSM).
+// partials: scratch of nb * fixed_msm_chunks(c, n, nb) points (NULL: one block per MSM).
+size_t fixed_msm_chunks(int c, size_t n, size_t nb);
+void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+               size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials);
 
 // ---- verification tail -------------------------------------------------------------------------
 // per proof: sum of nvar variable-base results + the fixed-base partial; ok = is_identity;
@@ -86,6 +89,12 @@ void sc_mul_strided(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size
 void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size_t x_outer, const Words8 *y,
                     size_t y_outer, Words8 *out, size_t out_stride);
 // a'[p][i] = a[p][i] u_p + u_p^-1 a[p][h+i] ; b'[p][i] = b[p][i] u_p^-1 + u_p b[p][h+i]   (in: nb x 2h, out: nb x h)
+// IPP over resident generators: L/R MSM scalars over the original generators, and the generator fold as a
+// coefficient update (see k_scalar.hip)
+void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,
+                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc);
+void ipp_gens_fold(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv, Words8 *cG,
+                   Words8 *cH);
 void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, const Words8 *u_inv, const Words8 *a,
                           const Words8 *b, Words8 *a_out, Words8 *b_out);
 
@@ -130,6 +139,8 @@ struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]
 //   (A_I1 A_O1 S1 A_I2 A_O2 S2 V.. T_1 T_3 T_4 T_5 T_6 L.. R..), plain canonical words;
 //   full_sc (optional): nb x (13 + m + 2 padded_n + 2k) in verifier.rs:517-532 order.
+//   zpow_scratch: verify_scalars_scratch_ints(c, d) int32 (z powers + the large-proof path's partials)
+size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d);
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad);

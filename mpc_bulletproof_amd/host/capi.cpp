@@ -178,6 +178,57 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
   })
 }
 
+// BASELINE config 4: one k-shuffle proof (tests/r1cs.rs:64-164, benches/shuffle.rs), prove then verify, with the
+// phases timed.  values = x_0..x_{k-1} | y_0..y_{k-1}.  ms[0..6] = generators, fixed-base tables + 2k commitments,
+// prover circuit + phase-1 commit, prove, verifier circuit, verify.  Returns the verify result code.
+int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, uint8_t *proof_out,
+                             size_t *proof_len, uint8_t *commitments_out, double ms[6]) {
+  GUARD({
+    auto T0 = std::chrono::steady_clock::now();
+    int li = 0;
+    auto lap = [&]() {
+      auto t = std::chrono::steady_clock::now();
+      ms[li++] = std::chrono::duration<double, std::milli>(t - T0).count();
+      T0 = t;
+    };
+    const char *label = "ShuffleProofTest";
+    PedersenGens pc_gens;
+    BulletproofGens bp_gens(gens_capacity, 1);
+    lap();
+    Rng rng(seed);
+    std::vector<Scalar> vs, bls;
+    for (size_t i = 0; i < 2 * k; i++) { vs.push_back(Scalar::from(values[i])); bls.push_back(rng.scalar()); }
+    auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
+    lap();
+    R1CSProof proof;
+    {
+      Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+      Prover prover(pc_gens, transcript);
+      std::vector<Variable> vars;
+      for (size_t i = 0; i < 2 * k; i++) vars.push_back(prover.commit_precomputed(vs[i], bls[i], Vs[i]));
+      gadgets::shuffle_gadget(prover, std::vector<Variable>(vars.begin(), vars.begin() + k),
+                              std::vector<Variable>(vars.begin() + k, vars.end()));
+      lap();
+      proof = prover.prove(bp_gens, rng);
+      lap();
+    }
+    auto bytes = proof.to_flat_bytes();
+    memcpy(proof_out, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    for (size_t i = 0; i < 2 * k; i++) memcpy(commitments_out + 64 * i, Vs[i].xy.data(), 64);
+    Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+    Verifier verifier(pc_gens, transcript);
+    std::vector<Variable> vars;
+    for (size_t i = 0; i < 2 * k; i++) vars.push_back(verifier.commit(Vs[i]));
+    gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + k),
+                            std::vector<Variable>(vars.begin() + k, vars.end()));
+    lap();
+    verifier.verify(proof, bp_gens);
+    lap();
+    return 0;
+  })
+}
+
 int bph_gens(int which, uint32_t party, size_t n, uint8_t *out) {
   GUARD({
     BulletproofGens g(n, party + 1);

@@ -1,6 +1,9 @@
 // mpc_bulletproof.cpp -- host-side orchestration of the reference's API over the bpgpu C ABI.
 // Citations are to renegade-fi/mpc-bulletproof (paths relative to its root).
 #include "mpc_bulletproof.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <cstring>
 
@@ -613,6 +616,18 @@ class CsCore {
 
 static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 
+// BPH_TIMING=1: phase timings of prove_batch / verify on stderr
+struct Lap {
+  bool on = getenv("BPH_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  void operator()(const char *what) {
+    if (!on) return;
+    auto t = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[bph]   %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+    t0 = t;
+  }
+};
+
 // ---- Prover ----------------------------------------------------------------------------------------
 Prover::Prover(const PedersenGens &pc, Transcript &t) : c_(new CsCore(true, pc, t, this)) {}
 Prover::~Prover() {}
@@ -678,6 +693,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   }
   if (bp_gens.gens_capacity < n1) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :450-452
   std::vector<R1CSProof> proofs(nb);
+  Lap lap;
   std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
   std::vector<std::vector<Scalar>> s_L(nb), s_R(nb);
   for (size_t p = 0; p < nb; p++) {                                                      // :457-462
@@ -710,6 +726,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     }
   };
   commit3(0, n1, i_b1, o_b1, s_b1, 1);
+  lap("prove: phase-1 commit");
   for (size_t p = 0; p < nb; p++) {
     cs[p]->tr.append_point("A_I1", proofs[p].A_I1);
     cs[p]->tr.append_point("A_O1", proofs[p].A_O1);
@@ -726,6 +743,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     for (size_t i = n1; i < n; i++) s_R[p][i] = rngs[p]->scalar();
   }
   if (n2 > 0) commit3(n1, n, i_b2, o_b2, s_b2, 2);                                        // else identity, :566-576
+  lap("prove: randomize + phase-2 commit");
   std::vector<Scalar> y(nb), z(nb), y_inv(nb);
   for (size_t p = 0; p < nb; p++) {
     cs[p]->tr.append_point("A_I2", proofs[p].A_I2);
@@ -743,7 +761,9 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   // provers: the constraint rows must coincide (checked through their CSR bytes).
   for (size_t p = 1; p < nb; p++)
     if (!cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+  lap("prove: transcript y z, same_rows");
   bpgpu_circuit *circ = cs[0]->upload_circuit(n, m);
+  lap("prove: upload_circuit");
   bpgpu_prover *ps = nullptr;
   std::vector<uint8_t> tco(nb * 6 * 32), wVb(nb * m * 32 + 1);
   {
@@ -763,6 +783,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
                                      n ? psR.data() : &dummy, tco.data(), wVb.data(), &ps);
     if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
   }
+  lap("prove: prover_polys");
   auto t = unpack_scalars(tco.data(), nb * 6);   // per prover: t1 t2 t3 t4 t5 t6
   auto wV = unpack_scalars(wVb.data(), nb * m);
   std::vector<Scalar> tb(nb * 6);                                                         // :621-625 (tb2 filled below)
@@ -808,6 +829,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     tr.append_scalar("e_blinding", proofs[p].e_blinding);
     w[p] = tr.challenge_scalar("w");                                                      // :686
   }
+  lap("prove: T commits, x, blindings");
   std::vector<uint8_t> lv(nb * padded_n * 32), rv(nb * padded_n * 32);
   {
     auto bx = pack_scalars(x);
@@ -816,14 +838,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     bpgpu_circuit_destroy(d.ctx(), circ);
     d.check(rc, "bpgpu_r1cs_prover_eval");
   }
-  // Q_p = w_p * B (:687): nb one-term MSMs over (B, B_blinding) with a zero blinding scalar
-  std::vector<uint8_t> Qb(nb * 64);
-  {
-    std::vector<Scalar> vec(nb * 2);
-    for (size_t p = 0; p < nb; p++) vec[2 * p] = w[p];
-    auto bytes = pack_scalars(vec);
-    d.check(bpgpu_msm_gens(d.ctx(), gens, nb, 0, bytes.data(), Qb.data()), "bpgpu_msm_gens");
-  }
+  lap("prove: prover_eval");
   // InnerProductProof::create for all provers in lock-step (:689-708; inner_product_proof.rs:49-193)
   std::vector<Scalar> Gf(nb * padded_n), Hf(nb * padded_n);
   for (size_t p = 0; p < nb; p++) {
@@ -834,11 +849,25 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     }
     cs[p]->tr.innerproduct_domain_sep(padded_n);                                          // inner_product_proof.rs:72
   }
-  auto pG = pack_points(bp_gens.share(0).G(padded_n)), pH = pack_points(bp_gens.share(0).H(padded_n));
   auto pgf = pack_scalars(Gf), phf = pack_scalars(Hf);
+  lap("prove: factors");
   bpgpu_ipp *ipp = nullptr;
-  d.check(bpgpu_ipp_begin(d.ctx(), nb, padded_n, Qb.data(), pgf.data(), phf.data(), pG.data(), pH.data(), 1, lv.data(), rv.data(), &ipp),
-          "bpgpu_ipp_begin");
+  if (!getenv("BPH_IPP_FOLD_GENERATORS")) {
+    // Q_p = w_p * B (:687) and G, H = bp_gens are resident on the device: session over the generator tables
+    auto wb = pack_scalars(w);
+    d.check(bpgpu_ipp_begin_gens(d.ctx(), gens, nb, padded_n, wb.data(), pgf.data(), phf.data(), lv.data(), rv.data(), &ipp),
+            "bpgpu_ipp_begin_gens");
+  } else {   // the reference's literal schedule (generators folded every round), kept for A/B measurements
+    std::vector<uint8_t> Qb(nb * 64);
+    std::vector<Scalar> vec(nb * 2);
+    for (size_t p = 0; p < nb; p++) vec[2 * p] = w[p];
+    auto bytes = pack_scalars(vec);
+    d.check(bpgpu_msm_gens(d.ctx(), gens, nb, 0, bytes.data(), Qb.data()), "bpgpu_msm_gens");
+    auto pG = pack_points(bp_gens.share(0).G(padded_n)), pH = pack_points(bp_gens.share(0).H(padded_n));
+    d.check(bpgpu_ipp_begin(d.ctx(), nb, padded_n, Qb.data(), pgf.data(), phf.data(), pG.data(), pH.data(), 1, lv.data(), rv.data(), &ipp),
+            "bpgpu_ipp_begin");
+  }
+  lap("prove: ipp_begin");
   try {
     std::vector<uint8_t> L(nb * 64), R(nb * 64), ub(nb * 32), uib(nb * 32);
     while (bpgpu_ipp_len(ipp) > 1) {
@@ -868,6 +897,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     throw;
   }
   bpgpu_ipp_destroy(d.ctx(), ipp);
+  lap("prove: ipp rounds");
   return proofs;
 }
 
@@ -896,6 +926,7 @@ Variable Verifier::commit(const StarkPoint &V) {
 void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
   CsCore &c = *c_;
   Transcript &tr = c.tr;
+  Lap lap;
   try {
     tr.append_u64("m", c.V.size());                                                     // verifier.rs:398
     size_t n1 = c.num_vars;
@@ -903,6 +934,7 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
     tr.validate_and_append_point("A_O1", proof.A_O1);
     tr.validate_and_append_point("S1", proof.S1);
     c.create_randomized_constraints();                                                  // :409
+    lap("verify: randomized constraints");
     size_t n = c.num_vars, padded_n = next_pow2(n), m = c.V.size();
     if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :421-423
     tr.append_point("A_I2", proof.A_I2);                                                // :428-430
@@ -932,8 +964,10 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
     ch[5] = tr.challenge_scalar("r");                                                   // :506
     // device: flatten, inversions, scalar assembly, mega_check MSM, identity test -- :457-553
     Device &d = Device::default_device();
+    lap("verify: transcript");
     bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
     bpgpu_circuit *circ = c.upload_circuit(n, m);
+    lap("verify: upload_circuit");
     std::vector<StarkPoint> pts{proof.A_I1, proof.A_O1, proof.S1, proof.A_I2, proof.A_O2, proof.S2};
     pts.insert(pts.end(), c.V.begin(), c.V.end());
     for (auto *q : {&proof.T_1, &proof.T_3, &proof.T_4, &proof.T_5, &proof.T_6}) pts.push_back(*q);
@@ -943,7 +977,9 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
     auto bs = pack_scalars({proof.t_x, proof.t_x_blinding, proof.e_blinding, proof.ipp_proof.a, proof.ipp_proof.b});
     auto bc = pack_scalars(ch);
     int32_t ok = 0;
+    lap("verify: pack");
     int rc = bpgpu_r1cs_verify_batch(d.ctx(), gens, circ, 1, n1, k, bp.data(), bs.data(), bc.data(), &ok, c.mega.xy.data(), nullptr);
+    lap("verify: bpgpu_r1cs_verify_batch");
     bpgpu_circuit_destroy(d.ctx(), circ);
     if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
     if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);

@@ -10,7 +10,7 @@ SYMBOLS = [
     "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
-    "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
+    "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_prover_destroy",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
@@ -188,6 +188,13 @@ class BpGpu:
         h = C.c_void_p()
         self._ck(_lib.bpgpu_ipp_begin(self.ctx, C.c_size_t(nb), C.c_size_t(n), _buf(Q), _buf(Gf), _buf(Hf), _buf(G),
                                       _buf(H), 1 if shared_gens else 0, _buf(a), _buf(b), C.byref(h)))
+        return h
+
+    def ipp_begin_gens(self, gens, nb, n, w, Gf, Hf, a, b):
+        """Resident-generator session: G, H = gens[:n], Q = w * B (no generator folding on the device)."""
+        h = C.c_void_p()
+        self._ck(_lib.bpgpu_ipp_begin_gens(self.ctx, gens, C.c_size_t(nb), C.c_size_t(n), _buf(w), _buf(Gf), _buf(Hf),
+                                           _buf(a), _buf(b), C.byref(h)))
         return h
 
     def ipp_len(self, s):

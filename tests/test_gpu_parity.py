@@ -203,6 +203,53 @@ def test_range_verify_batch(gpu, n_bits, nb, c):
         gpu.circuit_destroy(circ)
 
 
+def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
+    """The grid-split scalar assembly used for large proofs (padded_n or m >= 4096: the 2^14-shuffle of BASELINE
+    configs[3]) forced onto small circuits: every MSM scalar, mega_check point and accept bit as the oracle's."""
+    monkeypatch.setenv("BPGPU_VS_LARGE_MIN", "1")
+    g = _gens(gpu, 16)
+    try:
+        for rec in golden_r1cs["range"]:
+            _check_record(gpu, g, o.K_RANGE, rec["n_bits"], rec, [])
+        for rec in golden_r1cs["shuffle"]:
+            _check_record(gpu, g, o.K_SHUFFLE, rec["k"], rec, [])
+        for rec in golden_r1cs["example"]:
+            _check_record(gpu, g, o.K_EXAMPLE, 0, rec, [rec["values"][5]])
+    finally:
+        gpu.gens_destroy(g)
+    test_range_verify_batch(gpu, 64, 5, 8)
+    # a shuffle big enough for several blocks per kernel: k = 300 -> n = 598, padded_n = 1024, m = 600, q = 1197
+    k = 300
+    import random
+    rnd = random.Random(5)
+    x = [rnd.getrandbits(64) for _ in range(k)]
+    y = list(x)
+    rnd.shuffle(y)
+    rc, proof, com = o.r1cs_prove(o.K_SHUFFLE, k, b"ShuffleProofTest", x + y, 31, 1024)
+    assert rc == 0
+    s = o.VerifySession(o.K_SHUFFLE, k, b"ShuffleProofTest", [], com, proof, 1024)
+    rp, kind, idx, coeff = s.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s.n1 + s.n2, s.m)
+    g = _gens(gpu, 1024, 4)
+    try:
+        kk, points, scalars = bh.verify_inputs(proof, com)
+        for tam in (False, True):
+            sess = s
+            sc = scalars
+            if tam:
+                bad = bytearray(proof)
+                bad[-1] ^= 1       # ipp b
+                sess = o.VerifySession(o.K_SHUFFLE, k, b"ShuffleProofTest", [], com, bytes(bad), 1024)
+                _, points, sc = bh.verify_inputs(bytes(bad), com)
+            ok, mega, full = gpu.r1cs_verify_batch(g, circ, 1, s.n1, kk, s.m, points, sc, sess.challenges(), True, True)
+            assert ok == [0 if tam else 1]
+            assert mega == sess.mega_check()
+            assert full == sess.msm_terms()[0]
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+
+
 def test_verify_batch_generators_too_short(gpu):
     import mpc_bulletproof_amd as m
     recs, cap = bh.make_range_batch(8, 1)
@@ -221,14 +268,14 @@ def test_verify_batch_generators_too_short(gpu):
 
 
 # ------------------------------------------------------------------ IPP prover (lock-step session)
-def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b):
+def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b, gens=None, w=None):
     """Drive InnerProductProof::create (inner_product_proof.rs:49-193) with the transcript on the host
     (the oracle's Python model of it) and all arithmetic on the GPU."""
     import pymodel as pm
     trs = [pm.Transcript(label) for _ in range(nb)]
     for t in trs:
         t.innerproduct_domain_sep(n)
-    s = gpu.ipp_begin(nb, n, Q, Gf, Hf, G, H, shared, a, b)
+    s = gpu.ipp_begin_gens(gens, nb, n, w, Gf, Hf, a, b) if gens is not None else gpu.ipp_begin(nb, n, Q, Gf, Hf, G, H, shared, a, b)
     Ls, Rs, chs = [b""] * nb, [b""] * nb, [b""] * nb
     try:
         while gpu.ipp_len(s) > 1:
@@ -279,6 +326,28 @@ def test_ipp_create_batched(gpu, shared):
         Hq = Hp if shared else Hh[64 * n * p:64 * n * (p + 1)]
         L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q[64 * p:64 * p + 64], Gf[sl], Hf[sl], Gq, Hq, a[sl], b[sl])
         assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo)
+
+
+@pytest.mark.parametrize("n,cap,c", [(16, 16, 8), (8, 16, 4), (1024, 1024, 4), (1, 4, 8)])
+def test_ipp_create_resident_generators(gpu, n, cap, c):
+    """bpgpu_ipp_begin_gens: the IPP over resident generator tables (L, R as fixed-base MSMs over the ORIGINAL
+    generators, generator folding replaced by coefficient updates) yields the oracle's proof bytes."""
+    sys_path_oracle()
+    nb = 3 if n <= 16 else 2
+    Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
+    g = gpu.gens_create(Gp, Hp, B, B, c)
+    try:
+        a, b = o.random_scalars(41, nb * n), o.random_scalars(42, nb * n)
+        Gf, Hf = o.random_scalars(43, nb * n), o.random_scalars(44, nb * n)
+        w = o.random_scalars(45, nb)
+        Ls, Rs, aa, bb, _ = _ipp_create_gpu(gpu, b"innerproducttest", nb, n, None, Gf, Hf, None, None, True, a, b, gens=g, w=w)
+        for p in range(nb):
+            sl = slice(32 * n * p, 32 * n * (p + 1))
+            Q = o.point_mul(w[32 * p:32 * p + 32], B)
+            L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q, Gf[sl], Hf[sl], Gp[:64 * n], Hp[:64 * n], a[sl], b[sl])
+            assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo)
+    finally:
+        gpu.gens_destroy(g)
 
 
 def sys_path_oracle():
