@@ -663,8 +663,10 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     ProfScope ps(ctx, 2, ctx->st);
     points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
   }
-  // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp))
-  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 2;
+  // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
+  // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
+  // so the identity points of 1-phase proofs (A_I2, A_O2, S2) are skipped wave-uniformly inside k_straus.
+  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 4;
   const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
   const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
   const size_t nres = lanes + rem;
@@ -673,17 +675,17 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     if (lanes) {
       StrausArgs a{};
       for (int j = 0; j < vnp; j++) {
-        a.pts[j] = (AffDev *)dpts + j * lanes; a.pt_stride[j] = 1; a.pt_outer[j] = nvar;
-        a.sc[j] = (uint32_t *)dvar + j * lanes * 8; a.sc_stride[j] = 8; a.sc_outer[j] = nvar * 8;
+        a.pts[j] = (AffDev *)dpts + j * lanes; a.pt_stride[j] = nvar; a.pt_outer[j] = 1;
+        a.sc[j] = (uint32_t *)dvar + j * lanes * 8; a.sc_stride[j] = nvar * 8; a.sc_outer[j] = 8;
       }
-      a.inner = lanes; a.out_outer = nres;
+      a.inner = nb; a.out_outer = 1; a.out_stride = nres;
       straus(ctx->st, vnp, a, (JacRaw *)dvres, nb * lanes, dstr);
     }
     if (rem) {
       StrausArgs a{};
-      a.pts[0] = (AffDev *)dpts + vnp * lanes; a.pt_stride[0] = 1; a.pt_outer[0] = nvar;
-      a.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; a.sc_stride[0] = 8; a.sc_outer[0] = nvar * 8;
-      a.inner = rem; a.out_outer = nres;
+      a.pts[0] = (AffDev *)dpts + vnp * lanes; a.pt_stride[0] = nvar; a.pt_outer[0] = 1;
+      a.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; a.sc_stride[0] = nvar * 8; a.sc_outer[0] = 8;
+      a.inner = nb; a.out_outer = 1; a.out_stride = nres;
       straus(ctx->st, 1, a, (JacRaw *)dvres + lanes, nb * rem, dstr);
     }
   }

@@ -5,6 +5,7 @@
 // Hot-path rows: a1 StarkPoint::msm_iter / msm, a2 fold_witness (point half),
 // a3 first-round generator scaling, a9 mega_check.  All integer work (F_p, 9 x 29-bit limbs); the
 // kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
+#include <cstdlib>
 #include "ec_dev.cuh"
 
 using namespace bp;
@@ -28,6 +29,8 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
   const bool live = i < n;
   if (!live) i = n - 1;               // keep the wave uniform; result discarded
   uint32_t sp[NP][9];
+  unsigned skip = 0;   // bit j, wave-uniform: every lane's j-th point is the identity (A_I2, A_O2, S2 of 1-phase proofs
+                   // when the lanes of a wave share a role) -> no table, no additions for j
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     uint32_t s[8];
@@ -37,6 +40,7 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
     for (int t = 0; t < 8; t++) s[t] = src[t];
     recode_add_k<SW>(sp[j], s);
     Aff P = aff_load(a.pts[j] + pp * a.pt_outer[j] + rr * a.pt_stride[j]);
+    if (__all(aff_is_inf(P))) { skip |= 1u << j; continue; }
     Jac m = jac_from_aff(P);
 #pragma unroll 1
     for (int e = 0; e < SE; e++) {
@@ -57,6 +61,7 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
     }
 #pragma unroll 1
     for (int j = 0; j < NP; j++) {
+      if ((skip >> j) & 1) continue;
       int dg = recode_digit<SW>(sp[j], w);
       if (dg != 0) {
         int e = (dg < 0 ? -dg : dg) - 1;
@@ -71,7 +76,7 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
   }
   if (live) {
     size_t o = i;
-    if (a.inner && a.out_outer) { size_t pp = i / a.inner; o = pp * a.out_outer + (i - pp * a.inner); }
+    if (a.inner && a.out_outer) { size_t pp = i / a.inner; o = pp * a.out_outer + (i - pp * a.inner) * (a.out_stride ? a.out_stride : 1); }
     raw_store(&out[o], acc);
   }
 }
@@ -167,6 +172,73 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
   acc = block_sum<TPB>(acc, red);
   if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
 }
+// Many small MSMs (the 130-generator part of a range-proof verification): LPM lanes per MSM, 64/LPM MSMs per
+// wave, lanes combined with a wave-shuffle butterfly.  Against one 128-lane block per MSM this removes the LDS
+// tree (7 levels of full-wave point additions for ~16 table additions per lane).
+template <int C, int LPM>
+__global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                        size_t sc_stride, JacRaw *out, size_t nb) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const int lane = threadIdx.x & (LPM - 1);
+  size_t b = (size_t)blockIdx.x * (64 / LPM) + (threadIdx.x / LPM);
+  const bool live = b < nb;
+  if (!live) b = nb - 1;
+  const uint32_t *sc = scalars + b * sc_stride;
+  const size_t total = (2 + 2 * n) * W;
+  const size_t hshift = cap - n;
+  Jac acc = jac_inf();
+  uint32_t cur[16];
+  int dcur = 0;
+  size_t l = lane;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < total) {
+      size_t g = ll / W;
+      int w = (int)(ll - g * W);
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t row = (g < 2 + n ? g : g + hshift) * W + w;
+        const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int t = 0; t < 16; t++) dst[t] = e->w[t];
+      }
+    }
+  };
+  fetch(l, cur, dcur);
+  while (l < total) {
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + LPM, nxt, dnxt);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(cur);
+      q.y = unpack<FP>(cur + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
+    dcur = dnxt;
+    l += LPM;
+  }
+#pragma unroll 1
+  for (int off = LPM / 2; off > 0; off >>= 1) {
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
+    }
+    acc = jac_add(acc, q);
+  }
+  if (lane == 0 && live) raw_store(&out[b], acc);
+}
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
 size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
   size_t total = (2 + 2 * n) * (252 / c + 1);
@@ -179,6 +251,12 @@ static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t c
                          JacRaw *out, size_t nb, size_t chunks) {
   constexpr int TPB = 128;
   size_t total = (2 + 2 * n) * num_windows<C>();
+  static const int small_env = getenv("BPGPU_FIXED_SMALL") ? atoi(getenv("BPGPU_FIXED_SMALL")) : 1;
+  if (small_env && chunks == 1 && nb >= 64 && total <= 16384) {
+    if (nb >= 1024) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    else hipLaunchKernelGGL((k_fixed_msm_small<C, 32>), dim3((nb + 1) / 2), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    return;
+  }
   size_t per = (total + chunks - 1) / chunks;
   hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(chunks, nb), dim3(TPB), 0, st, table, n, cap, scalars, stride, out, per);
 }

@@ -473,16 +473,46 @@ void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Wor
 }
 
 // ------------------------------------------------------------------------------------------------
-// Verifier scalar assembly, one block per proof (r1cs/verifier.rs:457-532).
-// Wave 1 / lane 0 performs the (1 + k) inversions with one Fermat exponentiation while wave 0.. fill
-// the z-power table; then every lane produces g_i, h_i for its indices.
-constexpr int VS_TPB = 128;
+// Verifier scalar assembly (r1cs/verifier.rs:457-532) in two kernels.
+// k_vs_prep, one LANE per proof: y^-1 and u_j^-1 (verifier.rs:468, inner_product_proof.rs:283) by Montgomery's
+// trick around one binary-GCD inversion, then u_j^2, u_j^-2, prod u_j^-1.  (Run by one lane of a per-proof block
+// this serial chain cost a full wave's issue slots per proof: a quarter of all instructions of a verification.)
+// aux per proof (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[32], 34.. u_inv_sq[32] (+ partials, large path)
+constexpr int VS_AUX = 66;
+__global__ void __launch_bounds__(64) k_vs_prep(VerifyDims d, const Words8 *challenges, int32_t *aux_all, size_t aux_stride) {
+  const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, k = d.k;
+  if (p >= d.nb) return;
+  const Words8 *ch = challenges + p * (6 + k);
+  int32_t *aux = aux_all + p * aux_stride * NL;
+  Fn acc = fe_one<FN>();
+  // prefix products live in aux (slots 2.. as scratch) to keep the lane's register footprint small
+  raw_put(aux + 2 * NL, acc);
+  acc = load_plain(&ch[0]);
+  for (size_t i = 0; i < k; i++) { raw_put(aux + (3 + i) * NL, acc); acc = mul(acc, load_plain(&ch[6 + i])); }
+  Fn ai = inv_gcd(acc);
+  Fn allinv = fe_one<FN>();
+  for (int i = (int)k; i >= 1; i--) {
+    Fn val = load_plain(&ch[6 + i - 1]);
+    Fn vi = mul(ai, raw_get(aux + (2 + i) * NL));   // (prod_{t<i} val_t)^-1 ... * prefix = val_i^-1
+    ai = mul(ai, val);
+    allinv = mul(allinv, vi);
+    raw_put(aux + (2 + i) * NL, sqr(val));          // slot 2 + i is free again: final home of u_sq[i-1] is 2 + (i-1)
+    raw_put(aux + (34 + i - 1) * NL, sqr(vi));
+  }
+  // shift u_sq down by one slot (slot 2 + i -> 2 + i - 1) and store y_inv, allinv
+  for (size_t i = 1; i <= k; i++) raw_put(aux + (2 + i - 1) * NL, raw_get(aux + (2 + i) * NL));
+  raw_put(aux, ai);   // after the loop ai = val_0^-1 = y^-1
+  raw_put(aux + NL, allinv);
+}
+// k_verify_scalars, one wave per proof: z powers, g_i / h_i, delta, w_c and the remaining scalars.
+constexpr int VS_TPB = 64;
 __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
                                                            const Words8 *proof_scalars, Words8 *fixed_sc,
-                                                           Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all) {
-  __shared__ int32_t sm[(40 + 2 * 32) * NL + 2 * NL * (VS_TPB / 64)];
-  // sm slots (NL ints each): 0 y_inv, 1 allinv, 8.. u_sq[k], 40.. u_inv_sq[k], tail: per-wave partials (delta, wc)
-  int32_t *s_usq = sm + 8 * NL, *s_uinvsq = sm + 40 * NL, *s_part = sm + (40 + 64) * NL;
+                                                           Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all,
+                                                           const int32_t *aux_all) {
+  __shared__ int32_t sm[(VS_AUX + 2) * NL];
+  // sm slots (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[k], 34.. u_inv_sq[k], 66 delta, 67 wc
+  int32_t *s_usq = sm + 2 * NL, *s_uinvsq = sm + 34 * NL, *s_part = sm + VS_AUX * NL;
   const size_t p = blockIdx.x;
   const int tid = threadIdx.x;
   const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m, n1 = d.n1;
@@ -490,28 +520,12 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   const Words8 *ps = proof_scalars + p * 5;
   int32_t *zpow = zpow_all + p * c.q * NL;
   Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
-
-  if (tid == 64) {   // inversions: y^-1 and u_j^-1 (verifier.rs:468, inner_product_proof.rs:283)
-    Fn pref[33], val[33];   // Montgomery's trick: one (binary-GCD) inversion for the 1 + k values
-    Fn acc = fe_one<FN>();
-    val[0] = y;
-    for (size_t i = 0; i < k; i++) val[1 + i] = load_plain(&ch[6 + i]);
-    for (size_t i = 0; i <= k; i++) { pref[i] = acc; acc = mul(acc, val[i]); }
-    Fn ai = inv_gcd(acc);
-    Fn allinv = fe_one<FN>();
-    for (int i = (int)k; i >= 0; i--) {
-      Fn vi = mul(ai, pref[i]);
-      ai = mul(ai, val[i]);
-      if (i == 0) raw_put(sm + 0 * NL, vi);
-      else {
-        allinv = mul(allinv, vi);
-        raw_put(s_usq + (i - 1) * NL, sqr(val[i]));
-        raw_put(s_uinvsq + (i - 1) * NL, sqr(vi));
-      }
-    }
-    raw_put(sm + 1 * NL, allinv);
-  } else if (tid < 64) {   // z^(r+1) table (verifier.rs:336,358)
-    for (size_t r = tid; r < c.q; r += 64) raw_put(zpow + r * NL, fn_pow_u32(z, (uint32_t)r + 1));
+  (void)y;
+  for (int t = tid; t < VS_AUX * NL; t += VS_TPB) sm[t] = aux_all[p * VS_AUX * NL + t];
+  {   // z^(r+1) table (verifier.rs:336,358): lane r starts at z^(r+1) and steps by z^64
+    Fn cur = fn_pow_u32(z, (uint32_t)tid + 1), z64 = z;
+    for (int t = 0; t < 6; t++) z64 = sqr(z64);
+    for (size_t r = tid; r < c.q; r += VS_TPB) { raw_put(zpow + r * NL, cur); cur = mul(cur, z64); }
   }
   __syncthreads();
   Fn y_inv = raw_get(sm + 0 * NL), allinv = raw_get(sm + 1 * NL);
@@ -565,15 +579,14 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   }
   dpart = wave_sum(fn_reduce(dpart));
   wcp = wave_sum(fn_reduce(wcp));
-  if ((tid & 63) == 0) {
-    raw_put(s_part + (tid >> 6) * 2 * NL, fn_reduce(dpart));
-    raw_put(s_part + ((tid >> 6) * 2 + 1) * NL, fn_reduce(wcp));
+  if (tid == 0) {
+    raw_put(s_part, fn_reduce(dpart));
+    raw_put(s_part + NL, fn_reduce(wcp));
   }
   __syncthreads();
   // one lane per remaining output scalar (verifier.rs:508-532)
   if ((size_t)tid < nvar + 2 || m > (size_t)VS_TPB) {
     Fn delta = raw_get(s_part), wc = raw_get(s_part + NL);
-    for (int w = 1; w < VS_TPB / 64; w++) { delta = add(delta, raw_get(s_part + w * 2 * NL)); wc = add(wc, raw_get(s_part + (w * 2 + 1) * NL)); }
     wc = neg(wc);
     Fn r = load_plain(&ch[5]);
     Fn xx = sqr(x), rxx = mul(r, xx), xxx = mul(x, xx);
@@ -606,31 +619,7 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
 // q = 65 533, m = 32 768: a single block per proof would serialise ~10^5 field multiplications per lane).
 // aux per proof (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[32], 34.. u_inv_sq[32], 66.. delta partials[VSL_PARTS],
 // then w_c partials[VSL_PARTS]
-constexpr int VSL_PARTS = 256, VSL_AUX = 66 + 2 * VSL_PARTS, VSL_TPB = 128;
-__global__ void __launch_bounds__(64) k_vsl_prep(VerifyDims d, const Words8 *challenges, int32_t *aux_all) {
-  const size_t p = blockIdx.x, k = d.k;
-  if (threadIdx.x != 0) return;
-  const Words8 *ch = challenges + p * (6 + k);
-  int32_t *aux = aux_all + p * VSL_AUX * NL;
-  Fn pref[33], val[33];
-  Fn acc = fe_one<FN>();
-  val[0] = load_plain(&ch[0]);
-  for (size_t i = 0; i < k; i++) val[1 + i] = load_plain(&ch[6 + i]);
-  for (size_t i = 0; i <= k; i++) { pref[i] = acc; acc = mul(acc, val[i]); }
-  Fn ai = inv_gcd(acc);
-  Fn allinv = fe_one<FN>();
-  for (int i = (int)k; i >= 0; i--) {
-    Fn vi = mul(ai, pref[i]);
-    ai = mul(ai, val[i]);
-    if (i == 0) raw_put(aux, vi);
-    else {
-      allinv = mul(allinv, vi);
-      raw_put(aux + (2 + i - 1) * NL, sqr(val[i]));
-      raw_put(aux + (34 + i - 1) * NL, sqr(vi));
-    }
-  }
-  raw_put(aux + NL, allinv);
-}
+constexpr int VSL_PARTS = 256, VSL_AUX = VS_AUX + 2 * VSL_PARTS, VSL_TPB = 128;
 // g_i, h_i (verifier.rs:469-501) + per-block delta partial; blockIdx.y = proof; grid-stride over i
 __global__ void __launch_bounds__(VSL_TPB) k_vsl_gh(CircuitDev c, VerifyDims d, const Words8 *challenges,
                                                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *full_sc,
@@ -766,25 +755,26 @@ static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
   return d.padded_n >= thr || d.m >= thr || c.q >= 4 * thr;
 }
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {
-  return d.nb * ((c.q ? c.q : 1) + (vs_large(c, d) ? VSL_AUX : 0)) * NL;
+  return d.nb * ((c.q ? c.q : 1) + (vs_large(c, d) ? VSL_AUX : VS_AUX)) * NL;
 }
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad) {
   (void)bad;
   if (!d.nb) return;
+  int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
   if (!vs_large(c, d)) {
+    hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, d, challenges, aux, (size_t)VS_AUX);
     hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
-                       fixed_sc, var_sc, full_sc, zpow_scratch);
+                       fixed_sc, var_sc, full_sc, zpow_scratch, aux);
     return;
   }
-  int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
   auto parts = [](size_t work) { size_t b = (work + VSL_TPB - 1) / VSL_TPB; return (int)(b < 1 ? 1 : (b > VSL_PARTS ? VSL_PARTS : b)); };
   const size_t o = 3 * d.n + d.m;
   (void)o;
   // number of `One` terms is only known on the device (col_ptr); size its grid from the row count
   const int gh_parts = parts(d.padded_n), wc_parts = parts(c.q);
-  hipLaunchKernelGGL(k_vsl_prep, dim3(d.nb), dim3(64), 0, st, d, challenges, aux);
+  hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, d, challenges, aux, (size_t)VSL_AUX);
   if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, d.nb), dim3(256), 0, st, challenges + 1, (6 + d.k) * 8, c.q, zpow_scratch);
   hipLaunchKernelGGL(k_vsl_gh, dim3(gh_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, challenges, proof_scalars, fixed_sc,
                      full_sc, zpow_scratch, aux);

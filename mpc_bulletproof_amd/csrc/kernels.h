@@ -33,7 +33,8 @@ struct StrausArgs {
   size_t inner;
   size_t pt_outer[4];
   size_t sc_outer[4];
-  size_t out_outer;   // with inner != 0: out[p * out_outer + r]; 0 = dense (out[i])
+  size_t out_outer;   // with inner != 0: out[p * out_outer + r * out_stride]; 0 = dense (out[i])
+  size_t out_stride;  // 0 = 1
 };
 // scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
 size_t straus_scratch_bytes(int np, size_t n);
