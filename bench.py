@@ -27,10 +27,12 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 2 points per lane; k_straus: 12 174 / 22 032 KB --
-    # the writes are the per-lane window tables (21 MB) that live in L2/HBM scratch instead of LDS
-    "straus": int((2 * 12174.1 + 22032.0) * 1024),
-    "verify_scalars": int((2 * 12571.6 + 13653.2) * 1024),
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 16 tables (profiles/r01_pmc2_*.csv).
+    # k_straus: the writes are the per-lane window tables that live in L2/HBM scratch instead of LDS;
+    # k_fixed_msm_small: 1024 x 2080 random 64-byte table rows out of the 4.5 GB c = 16 table
+    "straus": int((2 * 11202.9 + 19665.3) * 1024),
+    "verify_scalars": int((2 * 5383.4 + 9601.7) * 1024),
+    "fixed_msm": int((2 * 134669.9 + 112.0) * 1024),
 }
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
@@ -260,11 +262,14 @@ def main():
         alg_bytes = nb * (terms * 96 if dom != "verify_scalars" else (6 + k + 5) * 32 + nterms * 32)
         achieved = alg_bytes / avg_s / 1e9
         # integer roofline: algorithmic F_p multiplications x 94 v_mad_u64_u32 each (csrc/fe29.cuh), per step
-        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "2"))))
+        # (Straus: one 252-doubling chain per lane + table build and 63 window additions per non-identity point --
+        # A_I2, A_O2, S2 are the identity in 1-phase proofs and are skipped; fixed-base: one mixed addition per
+        # (generator, window) + the 16-lane butterfly)
+        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
         lanes = nvar // vnp + nvar % vnp
         W = 252 // a.window_bits + 1
-        fp_straus = nb * lanes * (252 * 9 + vnp * (63 * 16 + 7 * 11))
-        fp_fixed = nb * ((nterms - nvar) * W * 11 + 127 * 16)
+        fp_straus = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
+        fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
         fpmul = {"straus": fp_straus, "fixed_msm": fp_fixed, "verify_scalars": 0}[dom]
         step_s = dt / a.steps
         out = {
@@ -275,7 +280,7 @@ def main():
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
-            "roofline": {"bound": "hbm", "kernel": {"straus": f"k_straus<{vnp},64>", "fixed_msm": f"k_fixed_msm<{a.window_bits},128>", "verify_scalars": "k_verify_scalars"}[dom],
+            "roofline": {"bound": "hbm", "kernel": {"straus": f"k_straus<{vnp},64>", "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "avg_launch_ms": avg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
