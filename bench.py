@@ -255,22 +255,22 @@ def main():
         nvar = 11 + m + 2 * k
         nterms = 13 + m + 2 * (1 << k) + 2 * k
         # dominant kernel = variable-base Straus over nb * nvar (scalar, point) pairs, 96 B per term
-        dom = max(("straus", "fixed_msm", "verify_scalars"), key=lambda n_: prof[n_][0])
+        dom = max(("verify_msm", "straus", "fixed_msm", "verify_scalars"), key=lambda n_: prof.get(n_, (0.0, 0))[0])
         ms, cnt = prof[dom]
         avg_s = ms / max(cnt, 1) / 1e3
-        terms = {"straus": nvar, "fixed_msm": nterms - nvar, "verify_scalars": 0}[dom]
+        terms = {"verify_msm": nterms, "straus": nvar, "fixed_msm": nterms - nvar, "verify_scalars": 0}[dom]
         alg_bytes = nb * (terms * 96 if dom != "verify_scalars" else (6 + k + 5) * 32 + nterms * 32)
         achieved = alg_bytes / avg_s / 1e9
         # integer roofline: algorithmic F_p multiplications x 94 v_mad_u64_u32 each (csrc/fe29.cuh), per step
         # (Straus: one 252-doubling chain per lane + table build and 63 window additions per non-identity point --
         # A_I2, A_O2, S2 are the identity in 1-phase proofs and are skipped; fixed-base: one mixed addition per
         # (generator, window) + the 16-lane butterfly)
-        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
+        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "3"))))
         lanes = nvar // vnp + nvar % vnp
         W = 252 // a.window_bits + 1
         fp_straus = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
         fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
-        fpmul = {"straus": fp_straus, "fixed_msm": fp_fixed, "verify_scalars": 0}[dom]
+        fpmul = {"verify_msm": fp_straus + fp_fixed, "straus": fp_straus, "fixed_msm": fp_fixed, "verify_scalars": 0}[dom]
         step_s = dt / a.steps
         out = {
             "metric": "range-proof verifications/sec (64-bit, m=1)",
@@ -280,13 +280,13 @@ def main():
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
-            "roofline": {"bound": "hbm", "kernel": {"straus": f"k_straus<{vnp},64>", "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}[dom],
+            "roofline": {"bound": "hbm", "kernel": {"verify_msm": f"k_verify_msm<{vnp},{a.window_bits},16>", "straus": f"k_straus<{vnp},64>", "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "avg_launch_ms": avg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
                          "note": "avg launch duration is measured with steps overlapping on the GPU (steps_in_flight); "
                                  "solo launch times are in DESIGN.md.  The path is VALU-integer bound: see roofline_int"},
-            "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "k_straus + k_fixed_msm of one step / wall time per step",
+            "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "Straus + fixed-base halves of one step's mega_check MSMs / wall time per step",
                              "achieved": (fp_straus + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
                              "frac": (fp_straus + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS,
                              "dominant_kernel_frac_at_its_avg_launch": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},

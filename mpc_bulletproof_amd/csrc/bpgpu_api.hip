@@ -645,51 +645,66 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   VerifyDims d{nb, n1, n, np, k, m};
   CK(flag_reset(ctx));
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
-  scalars_check(ctx->st, (const Words8 *)scalars, nb * 5, ctx->d_flag);
-  scalars_check(ctx->st, (const Words8 *)challenges, nb * (6 + k), ctx->d_flag);
+  // (canonicity of the scalars and challenges is checked inside verify_scalars)
   {
     ProfScope ps(ctx, 0, ctx->st);
     verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
                    (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag);
   }
-  HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
-  HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
-  {
-    ProfScope ps(ctx, 1, ctx->st2);
-    CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2));
-  }
-  HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
-  {
-    ProfScope ps(ctx, 2, ctx->st);
-    points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
-  }
   // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
   // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
   // so the identity points of 1-phase proofs (A_I2, A_O2, S2) are skipped wave-uniformly inside k_straus.
-  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 4;
+  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 3;
+  static const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
   const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
   const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
   const size_t nres = lanes + rem;
-  {
-    ProfScope ps(ctx, 3, ctx->st);
-    if (lanes) {
-      StrausArgs a{};
-      for (int j = 0; j < vnp; j++) {
-        a.pts[j] = (AffDev *)dpts + j * lanes; a.pt_stride[j] = nvar; a.pt_outer[j] = 1;
-        a.sc[j] = (uint32_t *)dvar + j * lanes * 8; a.sc_stride[j] = nvar * 8; a.sc_outer[j] = 8;
-      }
-      a.inner = nb; a.out_outer = 1; a.out_stride = nres;
-      straus(ctx->st, vnp, a, (JacRaw *)dvres, nb * lanes, dstr);
-    }
-    if (rem) {
-      StrausArgs a{};
-      a.pts[0] = (AffDev *)dpts + vnp * lanes; a.pt_stride[0] = nvar; a.pt_outer[0] = 1;
-      a.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; a.sc_stride[0] = nvar * 8; a.sc_outer[0] = 8;
-      a.inner = nb; a.out_outer = 1; a.out_stride = nres;
-      straus(ctx->st, 1, a, (JacRaw *)dvres + lanes, nb * rem, dstr);
+  StrausArgs am{}, ar{};
+  for (int j = 0; j < vnp; j++) {
+    am.pts[j] = (AffDev *)dpts + j * lanes; am.pt_stride[j] = nvar; am.pt_outer[j] = 1;
+    am.sc[j] = (uint32_t *)dvar + j * lanes * 8; am.sc_stride[j] = nvar * 8; am.sc_outer[j] = 8;
+  }
+  am.inner = nb; am.out_outer = 1; am.out_stride = nres;
+  ar.pts[0] = (AffDev *)dpts + vnp * lanes; ar.pt_stride[0] = nvar; ar.pt_outer[0] = 1;
+  ar.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; ar.sc_stride[0] = nvar * 8; ar.sc_outer[0] = 8;
+  ar.inner = nb; ar.out_outer = 1; ar.out_stride = nres;
+  bool fused = false;
+  if (!no_fuse && lanes && fixed_msm_chunks(g->c, np, nb) == 1) {
+    // one launch for both halves of the MSM, reading the proof points straight from the ABI bytes
+    StrausArgs af = am;
+    for (int j = 0; j < vnp; j++) af.pts[j] = (const AffDev *)points + j * lanes;
+    af.from_boundary = 1; af.bad = ctx->d_flag;
+    ProfScope ps(ctx, 6, ctx->st);
+    fused = verify_msm_fused(ctx->st, vnp, af, (JacRaw *)dvres, nb * lanes, dstr, g->c, g->table, np, g->cap,
+                             (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres, nb);
+    if (fused && rem) {
+      StrausArgs bf = ar;
+      bf.pts[0] = (const AffDev *)points + vnp * lanes;
+      bf.from_boundary = 1; bf.bad = ctx->d_flag;
+      void *dstr2;
+      CK(ws_get(ctx, 12, straus_scratch_bytes(1, nb * rem), &dstr2));
+      straus(ctx->st, 1, bf, (JacRaw *)dvres + lanes, nb * rem, dstr2);
     }
   }
-  HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
+  if (!fused) {
+    HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
+    HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
+    {
+      ProfScope ps(ctx, 1, ctx->st2);
+      CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2));
+    }
+    HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
+    {
+      ProfScope ps(ctx, 2, ctx->st);
+      points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
+    }
+    {
+      ProfScope ps(ctx, 3, ctx->st);
+      if (lanes) straus(ctx->st, vnp, am, (JacRaw *)dvres, nb * lanes, dstr);
+      if (rem) straus(ctx->st, 1, ar, (JacRaw *)dvres + lanes, nb * rem, dstr);
+    }
+    HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
+  }
   {
     ProfScope ps(ctx, 4, ctx->st);
     verify_finalize(ctx->st, (JacRaw *)dvres, nres, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
@@ -828,8 +843,7 @@ static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(ws_get(ctx, 14, pippenger_scratch_bytes(tot, cw), &dpip));
   VerifyDims d{nb, n1, n, np, k, m};
   CK(flag_reset(ctx));
-  scalars_check(ctx->st, (const Words8 *)scalars, nb * 5, ctx->d_flag);
-  scalars_check(ctx->st, (const Words8 *)challenges, nb * (6 + k), ctx->d_flag);
+  // (canonicity of the scalars and challenges is checked inside verify_scalars)
   scalars_check(ctx->st, (const Words8 *)rho, nb, ctx->d_flag);
   verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
                  (Words8 *)dvar, nullptr, (int32_t *)dzp, ctx->d_flag);

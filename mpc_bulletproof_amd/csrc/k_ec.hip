@@ -22,10 +22,10 @@ namespace bpk {
 constexpr int SW = 4;                 // window bits
 constexpr int SE = 1 << (SW - 1);     // 8 table entries
 template <int NP, int TPB>
-__global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all) {
+__device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, size_t n, int32_t *tab_all, size_t blk) {
   const int tid = threadIdx.x;
-  int32_t *tab = tab_all + (size_t)blockIdx.x * (NP * SE * 27 * TPB);
-  size_t i = (size_t)blockIdx.x * TPB + tid;
+  int32_t *tab = tab_all + blk * (NP * SE * 27 * TPB);
+  size_t i = blk * TPB + tid;
   const bool live = i < n;
   if (!live) i = n - 1;               // keep the wave uniform; result discarded
   uint32_t sp[NP][9];
@@ -39,7 +39,20 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
 #pragma unroll
     for (int t = 0; t < 8; t++) s[t] = src[t];
     recode_add_k<SW>(sp[j], s);
-    Aff P = aff_load(a.pts[j] + pp * a.pt_outer[j] + rr * a.pt_stride[j]);
+    const AffDev *psrc = a.pts[j] + pp * a.pt_outer[j] + rr * a.pt_stride[j];
+    Aff P;
+    if (a.from_boundary) {   // points straight from the ABI bytes: canonical + on-curve checks here (k_points_from_boundary)
+      uint32_t w[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
+      if (!aff_from_boundary(P, w)) {
+        if (live) atomicOr(a.bad, 1);
+        P.x = fe_zero<FP>();
+        P.y = fe_zero<FP>();
+      }
+    } else {
+      P = aff_load(psrc);
+    }
     if (__all(aff_is_inf(P))) { skip |= 1u << j; continue; }
     Jac m = jac_from_aff(P);
 #pragma unroll 1
@@ -79,6 +92,10 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
     if (a.inner && a.out_outer) { size_t pp = i / a.inner; o = pp * a.out_outer + (i - pp * a.inner) * (a.out_stride ? a.out_stride : 1); }
     raw_store(&out[o], acc);
   }
+}
+template <int NP, int TPB>
+__global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all) {
+  straus_body<NP, TPB>(a, out, n, tab_all, blockIdx.x);
 }
 size_t straus_scratch_bytes(int np, size_t n) {
   const size_t tpb = 64;
@@ -176,12 +193,12 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
 // wave, lanes combined with a wave-shuffle butterfly.  Against one 128-lane block per MSM this removes the LDS
 // tree (7 levels of full-wave point additions for ~16 table additions per lane).
 template <int C, int LPM>
-__global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
-                                                        size_t sc_stride, JacRaw *out, size_t nb) {
+__device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                 size_t sc_stride, JacRaw *out, size_t nb, size_t blk) {
   constexpr int W = num_windows<C>();
   constexpr int HALF = 1 << (C - 1);
   const int lane = threadIdx.x & (LPM - 1);
-  size_t b = (size_t)blockIdx.x * (64 / LPM) + (threadIdx.x / LPM);
+  size_t b = blk * (64 / LPM) + (threadIdx.x / LPM);
   const bool live = b < nb;
   if (!live) b = nb - 1;
   const uint32_t *sc = scalars + b * sc_stride;
@@ -238,6 +255,42 @@ __global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, siz
     acc = jac_add(acc, q);
   }
   if (lane == 0 && live) raw_store(&out[b], acc);
+}
+template <int C, int LPM>
+__global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                        size_t sc_stride, JacRaw *out, size_t nb) {
+  fixed_small_body<C, LPM>(table, n, cap, scalars, sc_stride, out, nb, blockIdx.x);
+}
+// Both halves of a batch's mega_check MSM in ONE launch: blocks [0, straus_blocks) run the per-lane Straus over the
+// proof points, the rest the table-lookup MSMs over the generators.  A single 1024-proof batch gives either part
+// only 100-250 waves for 1024 SIMDs and a stream runs one kernel at a time, so launching them together doubles the
+// waves each in-flight batch keeps on the chip.
+struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
+template <int NP, int C, int LPM>
+__global__ void __launch_bounds__(64) k_verify_msm(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all,
+                                                   unsigned straus_blocks, FixedSmallArgs f) {
+  if (blockIdx.x < straus_blocks) straus_body<NP, 64>(a, out, n, tab_all, blockIdx.x);
+  else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - straus_blocks);
+}
+template <int NP, int C>
+static void launch_verify_msm(hipStream_t st, const StrausArgs &a, JacRaw *out, size_t n, void *scratch, const FixedSmallArgs &f) {
+  unsigned sb = (unsigned)((n + 63) / 64);
+  if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_msm<NP, C, 16>), dim3(sb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, a, out, n, (int32_t *)scratch, sb, f);
+  else hipLaunchKernelGGL((k_verify_msm<NP, C, 32>), dim3(sb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, a, out, n, (int32_t *)scratch, sb, f);
+}
+bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_var, size_t n_lanes, void *scratch, int c,
+                      const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride,
+                      JacRaw *out_fixed, size_t nb) {
+  const size_t total = (2 + 2 * n) * (252 / c + 1);
+  if (!n_lanes || nb < 64 || total > 16384) return false;
+  FixedSmallArgs f{table, n, cap, scalars, sc_stride, out_fixed, nb};
+  if (c == 16 && np == 2) launch_verify_msm<2, 16>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 16 && np == 3) launch_verify_msm<3, 16>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 16 && np == 4) launch_verify_msm<4, 16>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 8 && np == 2) launch_verify_msm<2, 8>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 8 && np == 4) launch_verify_msm<4, 8>(st, a, out_var, n_lanes, scratch, f);
+  else return false;
+  return true;
 }
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
 size_t fixed_msm_chunks(int c, size_t n, size_t nb) {

@@ -489,7 +489,9 @@ __global__ void __launch_bounds__(64) k_vs_prep(VerifyDims d, const Words8 *chal
   raw_put(aux + 2 * NL, acc);
   acc = load_plain(&ch[0]);
   for (size_t i = 0; i < k; i++) { raw_put(aux + (3 + i) * NL, acc); acc = mul(acc, load_plain(&ch[6 + i])); }
-  Fn ai = inv_gcd(acc);
+  // Fermat here: with a different proof in every lane the binary GCD's data-dependent branches diverge (measured
+  // 315 k wave instructions, 1 ms of latency per launch) while the fixed exponent keeps the wave uniform (~125 k)
+  Fn ai = inv(acc);
   Fn allinv = fe_one<FN>();
   for (int i = (int)k; i >= 1; i--) {
     Fn val = load_plain(&ch[6 + i - 1]);
@@ -509,7 +511,7 @@ constexpr int VS_TPB = 64;
 __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
                                                            const Words8 *proof_scalars, Words8 *fixed_sc,
                                                            Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all,
-                                                           const int32_t *aux_all) {
+                                                           const int32_t *aux_all, int *bad) {
   __shared__ int32_t sm[(VS_AUX + 2) * NL];
   // sm slots (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[k], 34.. u_inv_sq[k], 66 delta, 67 wc
   int32_t *s_usq = sm + 2 * NL, *s_uinvsq = sm + 34 * NL, *s_part = sm + VS_AUX * NL;
@@ -522,6 +524,15 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
   (void)y;
   for (int t = tid; t < VS_AUX * NL; t += VS_TPB) sm[t] = aux_all[p * VS_AUX * NL + t];
+  if (bad) {   // canonical-encoding check of this proof's 6 + k challenges and 5 scalars (k_scalars_check)
+    for (size_t t = tid; t < 11 + k; t += VS_TPB) {
+      const Words8 *src = t < 6 + k ? &ch[t] : &ps[t - 6 - k];
+      uint32_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = src->w[j];
+      if (!words_lt_mod<FN>(w)) atomicOr(bad, 1);
+    }
+  }
   {   // z^(r+1) table (verifier.rs:336,358): lane r starts at z^(r+1) and steps by z^64
     Fn cur = fn_pow_u32(z, (uint32_t)tid + 1), z64 = z;
     for (int t = 0; t < 6; t++) z64 = sqr(z64);
@@ -760,15 +771,15 @@ size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad) {
-  (void)bad;
   if (!d.nb) return;
   int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
   if (!vs_large(c, d)) {
     hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, d, challenges, aux, (size_t)VS_AUX);
     hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
-                       fixed_sc, var_sc, full_sc, zpow_scratch, aux);
+                       fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad);
     return;
   }
+  if (bad) { scalars_check(st, challenges, d.nb * (6 + d.k), bad); scalars_check(st, proof_scalars, d.nb * 5, bad); }
   auto parts = [](size_t work) { size_t b = (work + VSL_TPB - 1) / VSL_TPB; return (int)(b < 1 ? 1 : (b > VSL_PARTS ? VSL_PARTS : b)); };
   const size_t o = 3 * d.n + d.m;
   (void)o;

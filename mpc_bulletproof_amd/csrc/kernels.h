@@ -35,10 +35,18 @@ struct StrausArgs {
   size_t sc_outer[4];
   size_t out_outer;   // with inner != 0: out[p * out_outer + r * out_stride]; 0 = dense (out[i])
   size_t out_stride;  // 0 = 1
+  int from_boundary;  // pts are ABI bytes (x || y canonical LE words): validate + convert in the kernel, *bad |= 1 on failure
+  int *bad;
 };
 // scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
 size_t straus_scratch_bytes(int np, size_t n);
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch);
+
+// Straus over the proof points (n_lanes lanes) and the small fixed-base MSMs (nb of them) in one launch; false =
+// this (np, c, size) combination has no fused kernel, launch the two parts separately
+bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_var, size_t n_lanes, void *scratch, int c,
+                      const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride_words,
+                      JacRaw *out_fixed, size_t nb);
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
 int pippenger_window(size_t n);
@@ -140,6 +148,7 @@ struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]
 //   (A_I1 A_O1 S1 A_I2 A_O2 S2 V.. T_1 T_3 T_4 T_5 T_6 L.. R..), plain canonical words;
 //   full_sc (optional): nb x (13 + m + 2 padded_n + 2k) in verifier.rs:517-532 order.
+//   bad (optional): set to 1 when a challenge or proof scalar is not canonical (< n)
 //   zpow_scratch: verify_scalars_scratch_ints(c, d) int32 (z powers + the large-proof path's partials)
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d);
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
