@@ -27,13 +27,16 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 16 tables (profiles/r01_pmc2_*.csv).
-    # k_straus: the writes are the per-lane window tables that live in L2/HBM scratch instead of LDS;
-    # k_fixed_msm_small: 1024 x 2080 random 64-byte table rows out of the 4.5 GB c = 16 table
-    "straus": int((2 * 11202.9 + 19665.3) * 1024),
-    "verify_scalars": int((2 * 5383.4 + 9601.7) * 1024),
-    "fixed_msm": int((2 * 134669.9 + 112.0) * 1024),
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 3 points per lane, c = 16 tables (profiles/r01_pmc3_*.csv).
+    # k_verify_msm: fetches = 1024 x 2080 random 64-byte rows of the 4.5 GB c = 16 generator table (136 MB of
+    # gathers that replace 16 doublings each) + the proof points; writes = the per-lane Straus window tables
+    "verify_msm": int((2 * 187530.9 + 20031.0) * 1024),
+    "verify_scalars": int((2 * 5457.9 + 9601.7) * 1024),
 }
+# VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
+# k_verify_msm<3,16,16> 2.45e8 + k_verify_scalars 2.08e7 + k_verify_finalize 6.3e6 + k_vs_prep 1.6e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 2.45e8 + 2.08e7 + 6.33e6 + 1.59e6
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
 
@@ -290,6 +293,10 @@ def main():
                              "achieved": (fp_straus + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
                              "frac": (fp_straus + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS,
                              "dominant_kernel_frac_at_its_avg_launch": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
+            "roofline_valu_issue": ({"bound": "VALU issue slots", "achieved": VALU_WAVE_INSTR_PER_STEP_1024 / step_s,
+                                     "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s", "frac": VALU_WAVE_INSTR_PER_STEP_1024 / step_s / VALU_ISSUE_PEAK,
+                                     "note": "instructions per step from the PMC pass of the default configuration (profiles/r01_pmc_sq_summary.txt)"}
+                                    if nb == 1024 and vnp == 3 and a.window_bits == 16 and not os.environ.get("BPGPU_NO_FUSE") else None),
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
             "with_device_transcript": fs,
