@@ -81,6 +81,13 @@ int bpgpu_msm(bpgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, siz
 /* nb independent MSMs of n terms each (term-major within an MSM); out = nb points */
 int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
                     uint8_t *out);
+/* nsets MSMs over ONE point vector: out[s] = sum_i scalars[s*n + i] * points[i].  This is the local work of
+ * StarkPoint::msm_authenticated_iter in the two-party prover -- one MSM each over the secret shares, the MACs and
+ * the public modifiers of the same authenticated scalars against the same points (r1cs_mpc/mpc_prover.rs:621-657,
+ * 717-750; r1cs_mpc/mpc_inner_product.rs:104-126,172-186): the points are validated and converted
+ * once.  scalars: nsets x n x 32 B; points: n x 64 B; out: nsets x 64 B. */
+int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scalars, const uint8_t *points,
+                     uint8_t *out);
 
 /* ---- resident generators ---------------------------------------------------------------------
  * BulletproofGens::share(0).G(n) / .H(n) and PedersenGens{B, B_blinding}

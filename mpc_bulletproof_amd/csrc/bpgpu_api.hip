@@ -329,9 +329,13 @@ static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *
   if (n >= pip_min) {   // bucket method per instance
     int c = pippenger_window(n);
     void *dpip;
-    CK(ws_get(ctx, 14, pippenger_scratch_bytes(n, c), &dpip));
-    for (size_t b = 0; b < nb; b++)
-      pippenger(ctx->st, (AffDev *)dpts + b * n, (uint32_t *)dsc + b * n * 8, n, c, (JacRaw *)dsum + b, dpip);
+    if (nb == 1) {
+      CK(ws_get(ctx, 14, pippenger_scratch_bytes(n, c), &dpip));
+      pippenger(ctx->st, (AffDev *)dpts, (uint32_t *)dsc, n, c, (JacRaw *)dsum, dpip);
+    } else {
+      CK(ws_get(ctx, 14, pippenger_scratch_bytes_batch(nb, n, c), &dpip));
+      pippenger_batch(ctx->st, (AffDev *)dpts, (const uint32_t *)dsc, nb, n, c, (JacRaw *)dsum, 1, dpip);
+    }
   } else {
     StrausArgs a{};
     a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
@@ -360,6 +364,56 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
   if (!ctx || (nb && !out) || (nb && n && (!scalars || !points))) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return msm_batch_locked(ctx, nb, n, scalars, points, out);
+}
+
+/* nsets MSMs over ONE point vector (the share / MAC / public-modifier MSMs of msm_authenticated_iter) */
+int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scalars, const uint8_t *points,
+                     uint8_t *out) {
+  if (!ctx || (nsets && !out) || (nsets && n && (!scalars || !points))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (!nsets) return BPGPU_OK;
+  if (!n) { memset(out, 0, nsets * 64); return BPGPU_OK; }
+  const size_t tot = nsets * n;
+  void *dsc, *dxy, *dpts, *dres, *dsum, *dout;
+  CK(ws_get(ctx, 0, tot * 32, &dsc));
+  CK(ws_get(ctx, 1, n * 64, &dxy));
+  CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
+  CK(ws_get(ctx, 4, nsets * sizeof(JacRaw), &dsum));
+  CK(ws_get(ctx, 5, nsets * 64, &dout));
+  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  const bool bucket = n >= pip_min;
+  CK(ws_get(ctx, 2, (bucket ? tot + n : n) * sizeof(AffDev), &dpts));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dsc, scalars, tot * 32));
+  CK(h2d(ctx, dxy, points, n * 64));
+  scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
+  points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, n, ctx->d_flag);   // validated and converted once
+  if (bucket) {   // one batched bucket-method launch; the instances read replicas of the converted points
+    AffDev *rep = (AffDev *)dpts + n;
+    gather_points(ctx->st, (AffDev *)dpts, 0, n, nsets, rep, n);
+    int c = pippenger_window(n);
+    void *dpip;
+    CK(ws_get(ctx, 14, pippenger_scratch_bytes_batch(nsets, n, c), &dpip));
+    pippenger_batch(ctx->st, rep, (const uint32_t *)dsc, nsets, n, c, (JacRaw *)dsum, 1, dpip);
+  } else {        // one Straus lane per (set, term), the sets share the point array
+    StrausArgs a{};
+    a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1; a.pt_outer[0] = 0;
+    a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8; a.sc_outer[0] = n * 8;
+    a.inner = n;
+    void *dstr;
+    CK(straus_ws(ctx, 1, tot, &dstr));
+    straus(ctx->st, 1, a, (JacRaw *)dres, tot, dstr);
+    segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nsets, n);
+  }
+  jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nsets);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, nsets * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
 }
 
 /* ---------------------------------------------------------------- resident generators */

@@ -60,3 +60,15 @@ def combine_partial_points(local_point: bytes, point_add, group=None) -> bytes:
     for p in allgather_bytes(local_point, group):
         acc = point_add(acc, p)
     return acc
+
+
+def sharded_msm(scalars: bytes, points: bytes, msm_fn, point_add, group=None) -> bytes:
+    """One LARGE multi-scalar multiplication split by term range (the 98 347-term mega_check of
+    the 2^14-shuffle): rank r computes sum over its contiguous slice with `msm_fn(scalars, points) -> 64 B`
+    (BpGpu.msm on the GPU box), the <= 8 partial points are all-gathered and added locally.  Every rank
+    returns the same full result."""
+    n = len(scalars) // 32
+    assert len(points) == 64 * n
+    lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
+    part = msm_fn(scalars[32 * lo:32 * hi], points[64 * lo:64 * hi]) if hi > lo else bytes(64)
+    return combine_partial_points(part, point_add, group)

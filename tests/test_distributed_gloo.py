@@ -43,7 +43,10 @@ def _worker(rank, world, port, n_bits, nb, q):
             s.close()
         total_pt = sh.combine_partial_points(local_pt, o.point_add)
         tmax = sh.max_over_ranks(float(rank + 1))
-        q.put((rank, lo, hi, full, total_pt, tmax))
+        # one large MSM split by term range; 37 terms -> uneven slices
+        sc, pts = o.random_scalars(91, 37), (o.gens("G", 32) + o.gens("H", 32))[:64 * 37]
+        big = sh.sharded_msm(sc, pts, o.msm, o.point_add)
+        q.put((rank, lo, hi, full, total_pt, tmax, big))
     finally:
         dist.destroy_process_group()
 
@@ -80,6 +83,8 @@ def test_sharded_verification_gloo_world2():
         s.close()
     assert res[0][4] == res[1][4] == acc and acc != bytes(64)
     assert res[0][5] == res[1][5] == 2.0
+    sc, pts = o.random_scalars(91, 37), (o.gens("G", 32) + o.gens("H", 32))[:64 * 37]
+    assert res[0][6] == res[1][6] == o.msm(sc, pts)
 
 
 def test_shard_bounds_cover_everything():

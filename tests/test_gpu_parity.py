@@ -75,6 +75,25 @@ def test_msm_batch(gpu):
     assert gpu.msm_batch(nb, n, sc, pts) == o.msm_batch(sc, pts, nb, n)
 
 
+@pytest.mark.parametrize("n", [3, 29, 700])
+def test_msm_shared_points(gpu, n):
+    """The three local MSMs of msm_authenticated_iter (shares, MACs, public modifiers) over one point vector:
+    SimpleCircuit-sized (n <= 3), k=8 shuffle-sized (29) and a bucket-method size."""
+    nsets = 3
+    sc = o.random_scalars(600 + n, nsets * n)
+    k = o.random_scalars(700 + n, n)
+    pts = b"".join(o.point_mul(k[32 * i:32 * i + 32], G) for i in range(n)) if n < 100 else \
+        (o.gens("G", 512) + o.gens("H", 512))[:64 * n]
+    want = o.msm_batch(sc, pts * nsets, nsets, n)
+    assert gpu.msm_shared(nsets, n, sc, pts) == want
+    import mpc_bulletproof_amd as m
+    bad = bytearray(pts)
+    bad[5] ^= 1
+    with pytest.raises(m.BpGpuError) as e:
+        gpu.msm_shared(nsets, n, sc, bytes(bad))
+    assert e.value.code == m.lib.E_ARG
+
+
 def test_msm_rejects_bad_input(gpu):
     import mpc_bulletproof_amd as m
     G = o.generator()
