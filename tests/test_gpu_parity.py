@@ -80,6 +80,7 @@ def test_msm_shared_points(gpu, n):
     """The three local MSMs of msm_authenticated_iter (shares, MACs, public modifiers) over one point vector:
     SimpleCircuit-sized (n <= 3), k=8 shuffle-sized (29) and a bucket-method size."""
     nsets = 3
+    G = o.generator()
     sc = o.random_scalars(600 + n, nsets * n)
     k = o.random_scalars(700 + n, n)
     pts = b"".join(o.point_mul(k[32 * i:32 * i + 32], G) for i in range(n)) if n < 100 else \
