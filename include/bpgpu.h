@@ -172,6 +172,13 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
                             uint8_t *wV, bpgpu_prover **out);
 int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, const uint8_t *x,
                            uint8_t *l_vec, uint8_t *r_vec);
+/* prover.rs:659-708 in one call with everything staying in HBM: evaluates l(x), r(x) (with the padding), forms
+ * G_factors = [1; n1] ++ [u; padded_n - n1] and H_factors = y^-i * G_factors (prover.rs:689-697) and opens the
+ * resident-generator IPP session (bpgpu_ipp_begin_gens) on them with Q = w * B.  x, u, y_inv, w: nb x 32 B.
+ * Continue with bpgpu_ipp_round / fold / finish. */
+int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_gens *g, size_t padded_n, size_t n1,
+                                const uint8_t *x, const uint8_t *u, const uint8_t *y_inv, const uint8_t *w,
+                                bpgpu_ipp **out);
 void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s);
 /* out[i] = scalars[i] * (curve generator) -- GeneratorsChain::next (generators.rs:112-124),
  * Q = w * B (prover.rs:687), PedersenGens::commit with B = B_blinding (generators.rs:41-43,61-70) */

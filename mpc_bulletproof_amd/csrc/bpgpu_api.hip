@@ -1274,6 +1274,51 @@ int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, con
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
 }
+/* prover.rs:659-708 without leaving the device: l(x), r(x) with their padding, the G/H factors and the
+ * resident-generator IPP session that consumes them */
+int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_gens *g, size_t padded_n, size_t n1,
+                                const uint8_t *x, const uint8_t *u, const uint8_t *y_inv, const uint8_t *w,
+                                bpgpu_ipp **out) {
+  if (!ctx || !ps || !g || !x || !u || !y_inv || !w || !out) return BPGPU_E_ARG;
+  if (!padded_n || padded_n < ps->n || (padded_n & (padded_n - 1)) || n1 > ps->n) return BPGPU_E_LEN;
+  if (padded_n > g->cap) return BPGPU_E_GENS;
+  *out = nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = ps->nb, n = padded_n;
+  bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
+  if (!s) return BPGPU_E_OOM;
+  s->nb = nb; s->n0 = s->n = n; s->gens = g;
+  size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
+  bool okk = true;
+  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
+  M((void **)&s->cG, tot * 32); M((void **)&s->cH, tot * 32); M((void **)&s->w, nb * 32);
+  M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
+  M((void **)&s->sums, nb * 2 * sizeof(JacRaw)); M((void **)&s->out_xy, nb * 2 * 64);
+  M((void **)&s->msc, nb * 2 * (2 + 2 * n) * 32);
+  if (!okk) { ipp_free_all(s); return BPGPU_E_OOM; }
+  int rc = BPGPU_OK;
+  do {
+    void *din;
+    if ((rc = ws_get(ctx, 0, 3 * nb * 32, &din))) break;
+    Words8 *dx = (Words8 *)din, *du = dx + nb, *dyi = du + nb;
+    if ((rc = flag_reset(ctx))) break;
+    if ((rc = h2d(ctx, dx, x, nb * 32)) || (rc = h2d(ctx, du, u, nb * 32)) || (rc = h2d(ctx, dyi, y_inv, nb * 32)) ||
+        (rc = h2d(ctx, s->w, w, nb * 32))) break;
+    scalars_check(ctx->st, dx, 3 * nb, ctx->d_flag);
+    scalars_check(ctx->st, s->w, nb, ctx->d_flag);
+    prover_eval(ctx->st, nb, ps->n, n, dx, ps->y, ps->polys, s->a[0], s->b[0]);
+    ipp_r1cs_factors(ctx->st, nb, n, n1, du, dyi, s->cG, s->cH);
+    if ((rc = launch_ok(ctx))) break;
+    int bad = 0;
+    if ((rc = flag_read(ctx, &bad))) break;
+    if (bad) rc = BPGPU_E_ARG;
+  } while (0);
+  if (rc) { ipp_free_all(s); return rc; }
+  *out = s;
+  return BPGPU_OK;
+}
 void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s) {
   if (!s) return;
   if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); }

@@ -324,6 +324,21 @@ void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Wo
   if (!nb || !n0) return;
   hipLaunchKernelGGL(k_ipp_gens_scalars, dim3((n0 + 255) / 256, nb), dim3(256), 0, st, n0, cur, a, b, cG, cH, cLR, w, msc);
 }
+// G_factors / H_factors of the R1CS proof's inner-product argument (prover.rs:689-697): G_i factor 1 for the
+// phase-1 multipliers and u for the rest, H_i factor y^-i times that
+__global__ void __launch_bounds__(256) k_ipp_r1cs_factors(size_t np, size_t n1, const Words8 *u, const Words8 *y_inv,
+                                                          Words8 *cG, Words8 *cH) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
+  if (i >= np) return;
+  Fn gf = i < n1 ? fe_one<FN>() : load_plain(&u[p]);
+  store_plain(&cG[p * np + i], gf);
+  store_plain(&cH[p * np + i], mul(fn_pow_u32(load_plain(&y_inv[p]), (uint32_t)i), gf));
+}
+void ipp_r1cs_factors(hipStream_t st, size_t nb, size_t np, size_t n1, const Words8 *u, const Words8 *y_inv, Words8 *cG,
+                      Words8 *cH) {
+  if (!nb || !np) return;
+  hipLaunchKernelGGL(k_ipp_r1cs_factors, dim3((np + 255) / 256, nb), dim3(256), 0, st, np, n1, u, y_inv, cG, cH);
+}
 // G' = u^-1 G_L + u G_R ; H' = u H_L + u^-1 H_R as coefficient updates
 __global__ void __launch_bounds__(256) k_ipp_gens_fold(size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv,
                                                        Words8 *cG, Words8 *cH) {

@@ -102,6 +102,8 @@ void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size
 // coefficient update (see k_scalar.hip)
 void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,
                       const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc);
+void ipp_r1cs_factors(hipStream_t st, size_t nb, size_t np, size_t n1, const Words8 *u, const Words8 *y_inv, Words8 *cG,
+                      Words8 *cH);
 void ipp_gens_fold(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv, Words8 *cG,
                    Words8 *cH);
 void fold_scalars_batched(hipStream_t st, size_t nb, size_t h, const Words8 *u, const Words8 *u_inv, const Words8 *a,

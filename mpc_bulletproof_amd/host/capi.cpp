@@ -147,25 +147,28 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
     // all nb * nvals Pedersen commitments in one device call (the blinding factors are drawn first, in
     // the order tests/r1cs.rs:684 draws them)
     std::vector<Scalar> vs, bls;
-    for (size_t p = 0; p < nb; p++) {
-      rngs.emplace_back(new Rng(seed0 + p));
-      for (size_t j = 0; j < nvals; j++) { vs.push_back(Scalar::from(values[p * nvals + j])); bls.push_back(rngs.back()->scalar()); }
-    }
+    vs.resize(nb * nvals); bls.resize(nb * nvals);
+    for (size_t p = 0; p < nb; p++) rngs.emplace_back(new Rng(seed0 + p));
+    parallel_for(nb, [&](size_t p) {
+      for (size_t j = 0; j < nvals; j++) { vs[p * nvals + j] = Scalar::from(values[p * nvals + j]); bls[p * nvals + j] = rngs[p]->scalar(); }
+    });
     auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
     lap("tables + commitments");
     for (size_t p = 0; p < nb; p++) {
       trs.emplace_back(new Transcript(std::string((const char *)label, label_len)));
       provers.emplace_back(new Prover(pc_gens, *trs.back()));
+      pp.push_back(provers.back().get());
+      rr.push_back(rngs[p].get());
+    }
+    parallel_for(nb, [&](size_t p) {   // the provers build their constraint systems independently
       for (size_t j = 0; j < nvals; j++) {
         uint64_t v = values[p * nvals + j];
         size_t ix = p * nvals + j;
         memcpy(commitments_out + ix * 64, Vs[ix].xy.data(), 64);
-        Variable var = provers.back()->commit_precomputed(vs[ix], bls[ix], Vs[ix]);
-        gadgets::range_proof(*provers.back(), LinearCombination(var), &v, n_bits);
+        Variable var = provers[p]->commit_precomputed(vs[ix], bls[ix], Vs[ix]);
+        gadgets::range_proof(*provers[p], LinearCombination(var), &v, n_bits);
       }
-      pp.push_back(provers.back().get());
-      rr.push_back(rngs[p].get());
-    }
+    });
     lap("circuit building");
     auto proofs = Prover::prove_batch(pp, bp_gens, rr);
     lap("prove_batch");
@@ -174,6 +177,9 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
       *proof_len = bytes.size();
       memcpy(proofs_out + p * bytes.size(), bytes.data(), bytes.size());
     }
+    lap("serialise");
+    parallel_for(nb, [&](size_t p) { provers[p].reset(); trs[p].reset(); });   // constraint systems: many small allocations
+    lap("teardown");
     return 0;
   })
 }

@@ -2,6 +2,8 @@
 // Citations are to renegade-fi/mpc-bulletproof (paths relative to its root).
 #include "mpc_bulletproof.hpp"
 #include <chrono>
+#include <exception>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -126,16 +128,55 @@ StarkPoint StarkPoint::generator() {
   return p;
 }
 
+// ================================================================ host parallelism ================
+void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t min_n) {
+  static const unsigned nthreads = [] {
+    unsigned hw = std::thread::hardware_concurrency();
+    unsigned t = hw ? (hw < 16 ? hw : 16) : 4;
+    if (const char *e = getenv("BPH_THREADS")) { int v = atoi(e); if (v > 0) t = (unsigned)v; }
+    return t;
+  }();
+  if (n < min_n || nthreads <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
+  const size_t nt = n < nthreads ? n : nthreads;
+  std::vector<std::thread> th;
+  std::vector<std::exception_ptr> err(nt);
+  for (size_t t = 0; t < nt; t++)
+    th.emplace_back([&, t] {
+      try { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); } catch (...) { err[t] = std::current_exception(); }
+    });
+  for (auto &x : th) x.join();
+  for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
 // ================================================================ byte packing helpers ============
 namespace {
+// grow-only uninitialised byte buffers for the big scalar uploads (a zero-initialised std::vector costs a
+// single-threaded memset + page faults of tens of MB per call)
+struct RawBuf {
+  uint8_t *p = nullptr;
+  size_t cap = 0;
+  ~RawBuf() { free(p); }
+  uint8_t *ensure(size_t n) {
+    if (n > cap) { free(p); p = (uint8_t *)malloc(n ? n : 1); cap = p ? n : 0; if (!p) throw std::bad_alloc(); }
+    return p;
+  }
+};
+inline void pack_range(uint8_t *dst, const Scalar *src, size_t n) { for (size_t i = 0; i < n; i++) src[i].to_bytes_le(dst + 32 * i); }
+constexpr size_t PACK_CHUNK = 4096;   // scalars per parallel work item
 std::vector<uint8_t> pack_scalars(const std::vector<Scalar> &v) {
   std::vector<uint8_t> o(v.size() * 32);
-  for (size_t i = 0; i < v.size(); i++) v[i].to_bytes_le(&o[32 * i]);
+  const size_t n = v.size(), chunks = (n + PACK_CHUNK - 1) / PACK_CHUNK;
+  parallel_for(chunks, [&](size_t c) {
+    for (size_t i = c * PACK_CHUNK; i < n && i < (c + 1) * PACK_CHUNK; i++) v[i].to_bytes_le(&o[32 * i]);
+  }, 4);
   return o;
 }
 std::vector<Scalar> unpack_scalars(const uint8_t *b, size_t n) {
   std::vector<Scalar> o(n);
-  for (size_t i = 0; i < n; i++) o[i] = Scalar::from_bytes_le(b + 32 * i);
+  const size_t chunks = (n + PACK_CHUNK - 1) / PACK_CHUNK;
+  parallel_for(chunks, [&](size_t c) {
+    for (size_t i = c * PACK_CHUNK; i < n && i < (c + 1) * PACK_CHUNK; i++) o[i] = Scalar::from_bytes_le(b + 32 * i);
+  }, 4);
   return o;
 }
 std::vector<uint8_t> pack_points(const std::vector<StarkPoint> &v) {
@@ -696,29 +737,35 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   Lap lap;
   std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
   std::vector<std::vector<Scalar>> s_L(nb), s_R(nb);
-  for (size_t p = 0; p < nb; p++) {                                                      // :457-462
+  parallel_for(nb, [&](size_t p) {                                                       // :457-462
     i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
     s_L[p].resize(n1); s_R[p].resize(n1);
     for (auto &x : s_L[p]) x = rngs[p]->scalar();
     for (auto &x : s_R[p]) x = rngs[p]->scalar();
-  }
+  });
   // three commitments per prover over [B, B_blinding, G_0.., H_0..] -- :465-494 / :532-565
   auto commit3 = [&](size_t lo, size_t hi, const std::vector<Scalar> &ib, const std::vector<Scalar> &ob,
                      const std::vector<Scalar> &sb, int which_phase) {
     const size_t n = hi, per = 2 + 2 * n;
-    std::vector<Scalar> vec(nb * 3 * per);
-    for (size_t p = 0; p < nb; p++) {
-      auto at = [&](size_t w, size_t j) -> Scalar & { return vec[(p * 3 + w) * per + j]; };
-      at(0, 1) = ib[p]; at(1, 1) = ob[p]; at(2, 1) = sb[p];
-      for (size_t i = lo; i < hi; i++) {
-        at(0, 2 + i) = cs[p]->a_L[i]; at(0, 2 + n + i) = cs[p]->a_R[i];
-        at(1, 2 + i) = cs[p]->a_O[i];
-        at(2, 2 + i) = s_L[p][i]; at(2, 2 + n + i) = s_R[p][i];
+    static thread_local RawBuf buf;
+    uint8_t *bytes = buf.ensure(nb * 3 * per * 32);
+    parallel_for(nb, [&](size_t p) {   // rows [B, B_blinding, G_0.., H_0..] of A_I, A_O, S packed straight to bytes
+      auto row = [&](size_t w) { return bytes + (p * 3 + w) * per * 32; };
+      for (size_t w = 0; w < 3; w++) {
+        memset(row(w), 0, 32);                                       // B scalar
+        memset(row(w) + 64, 0, lo * 32);                             // G_0..G_{lo-1}
+        memset(row(w) + (2 + n) * 32, 0, lo * 32);                   // H_0..H_{lo-1}
       }
-    }
-    auto bytes = pack_scalars(vec);
+      ib[p].to_bytes_le(row(0) + 32); ob[p].to_bytes_le(row(1) + 32); sb[p].to_bytes_le(row(2) + 32);
+      pack_range(row(0) + (2 + lo) * 32, cs[p]->a_L.data() + lo, hi - lo);
+      pack_range(row(0) + (2 + n + lo) * 32, cs[p]->a_R.data() + lo, hi - lo);
+      pack_range(row(1) + (2 + lo) * 32, cs[p]->a_O.data() + lo, hi - lo);
+      memset(row(1) + (2 + n + lo) * 32, 0, (hi - lo) * 32);
+      pack_range(row(2) + (2 + lo) * 32, s_L[p].data() + lo, hi - lo);
+      pack_range(row(2) + (2 + n + lo) * 32, s_R[p].data() + lo, hi - lo);
+    });
     std::vector<uint8_t> o(nb * 3 * 64);
-    d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 3, n, bytes.data(), o.data()), "bpgpu_msm_gens");
+    d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 3, n, bytes, o.data()), "bpgpu_msm_gens");
     for (size_t p = 0; p < nb; p++) {
       StarkPoint *dst[3] = {which_phase == 1 ? &proofs[p].A_I1 : &proofs[p].A_I2, which_phase == 1 ? &proofs[p].A_O1 : &proofs[p].A_O2,
                             which_phase == 1 ? &proofs[p].S1 : &proofs[p].S2};
@@ -727,31 +774,31 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   };
   commit3(0, n1, i_b1, o_b1, s_b1, 1);
   lap("prove: phase-1 commit");
-  for (size_t p = 0; p < nb; p++) {
+  parallel_for(nb, [&](size_t p) {
     cs[p]->tr.append_point("A_I1", proofs[p].A_I1);
     cs[p]->tr.append_point("A_O1", proofs[p].A_O1);
     cs[p]->tr.append_point("S1", proofs[p].S1);
     cs[p]->create_randomized_constraints();                                              // :501
-  }
+  });
   const size_t n = cs[0]->a_L.size(), n2 = n - n1, padded_n = next_pow2(n);
   for (auto *c : cs) if (c->a_L.size() != n) throw std::invalid_argument("prove_batch: circuits differ after randomization");
   if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :511-513
-  for (size_t p = 0; p < nb; p++) {
+  parallel_for(nb, [&](size_t p) {
     if (n2 > 0) { i_b2[p] = rngs[p]->scalar(); o_b2[p] = rngs[p]->scalar(); s_b2[p] = rngs[p]->scalar(); }   // :519-527
     s_L[p].resize(n); s_R[p].resize(n);
     for (size_t i = n1; i < n; i++) s_L[p][i] = rngs[p]->scalar();
     for (size_t i = n1; i < n; i++) s_R[p][i] = rngs[p]->scalar();
-  }
+  });
   if (n2 > 0) commit3(n1, n, i_b2, o_b2, s_b2, 2);                                        // else identity, :566-576
   lap("prove: randomize + phase-2 commit");
   std::vector<Scalar> y(nb), z(nb), y_inv(nb);
-  for (size_t p = 0; p < nb; p++) {
+  parallel_for(nb, [&](size_t p) {
     cs[p]->tr.append_point("A_I2", proofs[p].A_I2);
     cs[p]->tr.append_point("A_O2", proofs[p].A_O2);
     cs[p]->tr.append_point("S2", proofs[p].S2);
     y[p] = cs[p]->tr.challenge_scalar("y");                                               // :584-585
     z[p] = cs[p]->tr.challenge_scalar("z");
-  }
+  });
   {   // y^-1 for all provers: Scalar::inverse (prover.rs:593) as one batched device inversion
     auto by = pack_scalars(y);
     d.check(bpgpu_batch_inverse(d.ctx(), by.data(), nb), "bpgpu_batch_inverse");
@@ -759,28 +806,29 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   }
   // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619.  One circuit for all
   // provers: the constraint rows must coincide (checked through their CSR bytes).
-  for (size_t p = 1; p < nb; p++)
-    if (!cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+  parallel_for(nb, [&](size_t p) {
+    if (p && !cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+  });
   lap("prove: transcript y z, same_rows");
   bpgpu_circuit *circ = cs[0]->upload_circuit(n, m);
   lap("prove: upload_circuit");
   bpgpu_prover *ps = nullptr;
   std::vector<uint8_t> tco(nb * 6 * 32), wVb(nb * m * 32 + 1);
   {
-    std::vector<Scalar> aL, aR, aO, sl, sr;
-    for (size_t p = 0; p < nb; p++) {
-      aL.insert(aL.end(), cs[p]->a_L.begin(), cs[p]->a_L.end());
-      aR.insert(aR.end(), cs[p]->a_R.begin(), cs[p]->a_R.end());
-      aO.insert(aO.end(), cs[p]->a_O.begin(), cs[p]->a_O.end());
-      sl.insert(sl.end(), s_L[p].begin(), s_L[p].end());
-      sr.insert(sr.end(), s_R[p].begin(), s_R[p].end());
-    }
+    static thread_local RawBuf buf;
+    const size_t plane = nb * n * 32;
+    uint8_t *wit = buf.ensure(5 * plane + 1);
+    uint8_t *paL = wit, *paR = wit + plane, *paO = wit + 2 * plane, *psL = wit + 3 * plane, *psR = wit + 4 * plane;
+    parallel_for(nb, [&](size_t p) {
+      pack_range(paL + p * n * 32, cs[p]->a_L.data(), n);
+      pack_range(paR + p * n * 32, cs[p]->a_R.data(), n);
+      pack_range(paO + p * n * 32, cs[p]->a_O.data(), n);
+      pack_range(psL + p * n * 32, s_L[p].data(), n);
+      pack_range(psR + p * n * 32, s_R[p].data(), n);
+    });
     auto by = pack_scalars(y), byi = pack_scalars(y_inv), bz = pack_scalars(z);
-    auto paL = pack_scalars(aL), paR = pack_scalars(aR), paO = pack_scalars(aO), psL = pack_scalars(sl), psR = pack_scalars(sr);
-    uint8_t dummy = 0;
-    int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), n ? paL.data() : &dummy,
-                                     n ? paR.data() : &dummy, n ? paO.data() : &dummy, n ? psL.data() : &dummy,
-                                     n ? psR.data() : &dummy, tco.data(), wVb.data(), &ps);
+    int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), paL, paR, paO, psL, psR,
+                                     tco.data(), wVb.data(), &ps);
     if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
   }
   lap("prove: prover_polys");
@@ -790,12 +838,13 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   {   // T_1, T_3, T_4, T_5, T_6 = commit(t_i, tb_i): 5 nb two-term MSMs over (B, B_blinding) -- :627-631
     std::vector<Scalar> vec(nb * 5 * 2);
     const int idx[5] = {0, 2, 3, 4, 5};
-    for (size_t p = 0; p < nb; p++)
+    parallel_for(nb, [&](size_t p) {
       for (int k = 0; k < 5; k++) {
         tb[p * 6 + idx[k]] = rngs[p]->scalar();
         vec[(p * 5 + k) * 2] = t[p * 6 + idx[k]];
         vec[(p * 5 + k) * 2 + 1] = tb[p * 6 + idx[k]];
       }
+    }, 32);
     auto bytes = pack_scalars(vec);
     std::vector<uint8_t> o(nb * 5 * 64);
     d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 5, 0, bytes.data(), o.data()), "bpgpu_msm_gens");
@@ -805,7 +854,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     }
   }
   std::vector<Scalar> u(nb), x(nb), w(nb);
-  for (size_t p = 0; p < nb; p++) {
+  parallel_for(nb, [&](size_t p) {
     Transcript &tr = cs[p]->tr;
     tr.append_point("T_1", proofs[p].T_1);
     tr.append_point("T_3", proofs[p].T_3);
@@ -828,36 +877,36 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     tr.append_scalar("t_x_blinding", proofs[p].t_x_blinding);
     tr.append_scalar("e_blinding", proofs[p].e_blinding);
     w[p] = tr.challenge_scalar("w");                                                      // :686
-  }
+  }, 8);
   lap("prove: T commits, x, blindings");
-  std::vector<uint8_t> lv(nb * padded_n * 32), rv(nb * padded_n * 32);
-  {
-    auto bx = pack_scalars(x);
-    int rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
+  bpgpu_ipp *ipp = nullptr;
+  for (size_t p = 0; p < nb; p++) cs[p]->tr.innerproduct_domain_sep(padded_n);              // inner_product_proof.rs:72
+  if (!getenv("BPH_IPP_FOLD_GENERATORS")) {
+    // l(x), r(x), the G/H factors (:661-672, 689-697) and the IPP operands never leave the device; Q_p = w_p * B
+    // (:687) and G, H = bp_gens are resident: the session runs over the generator tables
+    auto bx = pack_scalars(x), bu = pack_scalars(u), byi = pack_scalars(y_inv), bw = pack_scalars(w);
+    int rc = bpgpu_r1cs_prover_ipp_begin(d.ctx(), ps, gens, padded_n, n1, bx.data(), bu.data(), byi.data(), bw.data(), &ipp);
     bpgpu_prover_destroy(d.ctx(), ps);
     bpgpu_circuit_destroy(d.ctx(), circ);
-    d.check(rc, "bpgpu_r1cs_prover_eval");
-  }
-  lap("prove: prover_eval");
-  // InnerProductProof::create for all provers in lock-step (:689-708; inner_product_proof.rs:49-193)
-  std::vector<Scalar> Gf(nb * padded_n), Hf(nb * padded_n);
-  for (size_t p = 0; p < nb; p++) {
-    auto exp_y_inv = util::exp_iter(y_inv[p], padded_n);
-    for (size_t i = 0; i < padded_n; i++) {
-      Gf[p * padded_n + i] = i < n1 ? Scalar::one() : u[p];
-      Hf[p * padded_n + i] = exp_y_inv[i] * Gf[p * padded_n + i];
+    d.check(rc, "bpgpu_r1cs_prover_ipp_begin");
+  } else {   // the reference's literal schedule (operands through the host, generators folded every round), for A/B runs
+    std::vector<uint8_t> lv(nb * padded_n * 32), rv(nb * padded_n * 32);
+    {
+      auto bx = pack_scalars(x);
+      int rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
+      bpgpu_prover_destroy(d.ctx(), ps);
+      bpgpu_circuit_destroy(d.ctx(), circ);
+      d.check(rc, "bpgpu_r1cs_prover_eval");
     }
-    cs[p]->tr.innerproduct_domain_sep(padded_n);                                          // inner_product_proof.rs:72
-  }
-  auto pgf = pack_scalars(Gf), phf = pack_scalars(Hf);
-  lap("prove: factors");
-  bpgpu_ipp *ipp = nullptr;
-  if (!getenv("BPH_IPP_FOLD_GENERATORS")) {
-    // Q_p = w_p * B (:687) and G, H = bp_gens are resident on the device: session over the generator tables
-    auto wb = pack_scalars(w);
-    d.check(bpgpu_ipp_begin_gens(d.ctx(), gens, nb, padded_n, wb.data(), pgf.data(), phf.data(), lv.data(), rv.data(), &ipp),
-            "bpgpu_ipp_begin_gens");
-  } else {   // the reference's literal schedule (generators folded every round), kept for A/B measurements
+    std::vector<Scalar> Gf(nb * padded_n), Hf(nb * padded_n);
+    parallel_for(nb, [&](size_t p) {
+      auto exp_y_inv = util::exp_iter(y_inv[p], padded_n);
+      for (size_t i = 0; i < padded_n; i++) {
+        Gf[p * padded_n + i] = i < n1 ? Scalar::one() : u[p];
+        Hf[p * padded_n + i] = exp_y_inv[i] * Gf[p * padded_n + i];
+      }
+    });
+    auto pgf = pack_scalars(Gf), phf = pack_scalars(Hf);
     std::vector<uint8_t> Qb(nb * 64);
     std::vector<Scalar> vec(nb * 2);
     for (size_t p = 0; p < nb; p++) vec[2 * p] = w[p];
@@ -872,7 +921,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     std::vector<uint8_t> L(nb * 64), R(nb * 64), ub(nb * 32), uib(nb * 32);
     while (bpgpu_ipp_len(ipp) > 1) {
       d.check(bpgpu_ipp_round(d.ctx(), ipp, L.data(), R.data()), "bpgpu_ipp_round");
-      for (size_t p = 0; p < nb; p++) {
+      parallel_for(nb, [&](size_t p) {
         StarkPoint Lp, Rp;
         memcpy(Lp.xy.data(), &L[64 * p], 64);
         memcpy(Rp.xy.data(), &R[64 * p], 64);
@@ -881,7 +930,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
         cs[p]->tr.append_point("L", Lp);                                                  // :119-123 / :177-181
         cs[p]->tr.append_point("R", Rp);
         cs[p]->tr.challenge_scalar("u").to_bytes_le(&ub[32 * p]);
-      }
+      }, 64);
       uib = ub;
       d.check(bpgpu_batch_inverse(d.ctx(), uib.data(), nb), "bpgpu_batch_inverse");
       d.check(bpgpu_ipp_fold(d.ctx(), ipp, ub.data(), uib.data()), "bpgpu_ipp_fold");

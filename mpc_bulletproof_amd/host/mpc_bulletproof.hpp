@@ -65,6 +65,10 @@ class Rng {
   uint64_t s_;
 };
 
+// Host-side data parallelism (the reference uses rayon): f(i) for i in [0, n) on up to BPH_THREADS threads
+// (default min(16, hardware threads)); exceptions are rethrown on the caller's thread.  Serial when n < min_n.
+void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t min_n = 2);
+
 // ---- StarkPoint: canonical affine bytes; arithmetic happens on the device ------------------------
 struct StarkPoint {
   std::array<uint8_t, 64> xy{};   // x || y little-endian; zeros = identity (src/util.rs:274-289)
