@@ -40,20 +40,43 @@ VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instru
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
 
-def _gen_one(args):
-    """worker (CPU oracle): prove one instance, replay the verifier transcript for the challenges."""
-    import oracle_lib as o
-    import bp_helpers as bh
-    i, seed0 = args
-    v = (0x9E3779B97F4A7C15 * (i + 1) + seed0) & ((1 << N_BITS) - 1)
-    rc, proof, com = o.r1cs_prove(o.K_RANGE, N_BITS, LABEL, [v], seed0 + i, N_BITS)
-    assert rc == 0
-    s = o.VerifySession(o.K_RANGE, N_BITS, LABEL, [], com, proof, N_BITS)
-    assert s.rc == 0
-    k, pts, sc = bh.verify_inputs(proof, com)
-    out = (proof, com, pts, sc, s.challenges(), (s.n1, s.n2, s.k, s.m), s.csr() if i == 0 else None)
-    s.close()
-    return out
+def _gen_workload(path, nb, seed0):
+    """child process (forked before the parent touches the GPU): prove nb single-value 64-bit range proofs with the
+    product path itself (C++ host mirror over the C ABI, provers in lock-step on the GPU), replay the verifier
+    transcripts on the host and write the operands of bpgpu_r1cs_verify_batch to `path`."""
+    import ctypes as C
+    import pickle
+    host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+    vals = [(0x9E3779B97F4A7C15 * (i + 1) + seed0) & ((1 << N_BITS) - 1) for i in range(nb)]
+    arr = (C.c_uint64 * nb)(*vals)
+    lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
+    proofs, coms, plen = (C.c_uint8 * (nb * 4096))(), (C.c_uint8 * (nb * 64))(), C.c_size_t(0)
+    rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(1), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr,
+                                    C.c_uint64(seed0), C.c_size_t(N_BITS), proofs, C.byref(plen), coms)
+    assert rc == 0, f"bph_range_prove_batch rc={rc}"
+    pl = plen.value
+    k = N_BITS.bit_length() - 1
+    nvar = 11 + 1 + 2 * k
+    pts, sc, ch = (C.c_uint8 * (nb * nvar * 64))(), (C.c_uint8 * (nb * 5 * 32))(), (C.c_uint8 * (nb * (6 + k) * 32))()
+    init, dims = (C.c_uint8 * 32)(), (C.c_size_t * 6)()
+    cap = 8 * N_BITS + 8
+    rp, kind, idx, coeff = (C.c_uint32 * (2 * N_BITS + 2))(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint8 * (32 * cap))()
+    rc = host.bph_range_verify_inputs(C.c_size_t(nb), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), coms, proofs,
+                                      C.c_size_t(pl), C.c_size_t(N_BITS), pts, sc, ch, init, dims, rp, kind, idx, coeff)
+    assert rc == 0, f"bph_range_verify_inputs rc={rc}"
+    n1, n, kk, m, q, nnz = list(dims)
+    assert kk == k and m == 1
+    G, H, B = (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * 64)()
+    assert host.bph_gens(ord("G"), 0, C.c_size_t(N_BITS), G) == 0 and host.bph_gens(ord("H"), 0, C.c_size_t(N_BITS), H) == 0
+    host.bph_generator(B)
+    wl = {"proofs": bytes(proofs)[:nb * pl], "proof_len": pl, "commitments": bytes(coms), "points": bytes(pts),
+          "scalars": bytes(sc), "challenges": bytes(ch), "init_state": bytes(init), "dims": (n1, n - n1, k, m),
+          "csr": (list(rp)[:q + 1], list(kind)[:nnz], list(idx)[:nnz], bytes(coeff)[:32 * nnz]),
+          "G": bytes(G), "H": bytes(H), "B": bytes(B)}
+    tmp = path + f".tmp{os.getpid()}"
+    with open(tmp, "wb") as f:
+        pickle.dump(wl, f)
+    os.replace(tmp, path)
 
 
 def _cpu_verify_chunk(args):
@@ -80,6 +103,7 @@ def main():
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-combined", action="store_true", help="skip the secondary combined-batch-check measurement")
+    ap.add_argument("--no-prover", action="store_true", help="skip the secondary R1CS prover measurement (N = 1 only)")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
     a = ap.parse_args()
@@ -89,9 +113,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     nb = a.batch
 
-    # ---- synthetic workload from the CPU oracle (setup, untimed; forked before any GPU init).
-    # Every rank verifies the same synthetic batch (weak scaling): local rank 0 generates it once
-    # with the host's cores and publishes it through a file, the other ranks wait for the file.
+    # ---- synthetic workload (setup, untimed), generated by the product path itself in a child process forked before
+    # this process touches the GPU.  Every rank verifies the same batch (weak scaling): local rank 0 generates it
+    # once and publishes it through a file, the other ranks wait for the file.  The CPU baseline (the oracle's
+    # restatement, timed on all host cores) runs in a fork pool, also before any GPU initialisation here.
     import pickle
     import tempfile
     ncpu = max(1, min(os.cpu_count() or 1, 32))
@@ -99,56 +124,53 @@ def main():
     cache = f"{a.workload_cache}.{nb}" if a.workload_cache else os.path.join(
         tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}.pkl")
     cpu = None
-    if os.path.exists(cache) and (a.workload_cache or local_rank != 0):
-        pass
-    elif local_rank == 0:
-        with mp.get_context("fork").Pool(ncpu) as pool:
-            recs = pool.map(_gen_one, [(i, seed0) for i in range(nb)], chunksize=max(1, nb // (4 * ncpu)))
-            if rank == 0 and world == 1 and not a.no_cpu_baseline:
-                # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
-                plen = len(recs[0][0])
-                per = (nb + ncpu - 1) // ncpu
-                chunks = []
-                for c in range(ncpu):
-                    sub = recs[c * per:(c + 1) * per]
-                    if sub:
-                        chunks.append((b"".join(r[0] for r in sub), b"".join(r[1] for r in sub), plen))
-                t0 = time.perf_counter()
-                res = pool.map(_cpu_verify_chunk, chunks)
-                wall = time.perf_counter() - t0
-                assert sum(r[0] for r in res) == nb
-                cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
-                       "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
-                                 f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
-        tmp = cache + f".tmp{os.getpid()}"
-        with open(tmp, "wb") as f:
-            pickle.dump(recs, f)
-        os.replace(tmp, cache)
+    if not os.path.exists(cache) and local_rank == 0:
+        child = mp.get_context("fork").Process(target=_gen_workload, args=(cache, nb, seed0))
+        child.start()
+        child.join()
+        if child.exitcode != 0:
+            raise RuntimeError(f"workload generation failed (exit code {child.exitcode}): the HIP path is required, "
+                               "there is no CPU fallback")
     deadline = time.time() + 1200
     while not os.path.exists(cache):
         if time.time() > deadline:
             raise RuntimeError("workload file never appeared")
         time.sleep(0.5)
     with open(cache, "rb") as f:
-        recs = pickle.load(f)
-    n1, n2, k, m = recs[0][5]
-    rp, kind, idx, coeff = recs[0][6]
-    pts = b"".join(r[2] for r in recs)
-    sc = b"".join(r[3] for r in recs)
-    ch = b"".join(r[4] for r in recs)
+        wl = pickle.load(f)
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
+        plen = wl["proof_len"]
+        per = (nb + ncpu - 1) // ncpu
+        chunks = []
+        for c in range(ncpu):
+            lo, hi = c * per, min(nb, (c + 1) * per)
+            if hi > lo:
+                chunks.append((wl["proofs"][lo * plen:hi * plen], wl["commitments"][64 * lo:64 * hi], plen))
+        with mp.get_context("fork").Pool(len(chunks)) as pool:
+            pool.map(_cpu_verify_chunk, [(b"", b"", plen)] * len(chunks))     # start the workers, load the library
+            t0 = time.perf_counter()
+            res = pool.map(_cpu_verify_chunk, chunks, chunksize=1)
+            wall = time.perf_counter() - t0
+        assert sum(r[0] for r in res) == nb, "the CPU oracle rejects proofs made by the GPU prover"
+        cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
+               "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
+                         f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
+    n1, n2, k, m = wl["dims"]
+    rp, kind, idx, coeff = wl["csr"]
+    pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
 
     # ---- GPU
     import torch
     import torch.distributed as dist
     import mpc_bulletproof_amd as mb
-    import oracle_lib as o
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ctxs = [mb.BpGpu(local_rank) for _ in range(max(1, a.inflight))]
     gpu = ctxs[0]
     circ = gpu.circuit_create(rp, kind, idx, coeff, n1 + n2, m)
-    gens = gpu.gens_create(o.gens("G", N_BITS), o.gens("H", N_BITS), o.generator(), o.generator(), a.window_bits)
+    gens = gpu.gens_create(wl["G"], wl["H"], wl["B"], wl["B"], a.window_bits)
     d_pts, d_sc, d_ch = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch)
     d_oks = [gpu.malloc(4 * nb) for _ in ctxs]
     counter = [0]
@@ -196,9 +218,7 @@ def main():
     # (SURVEY 8f N1): inputs are the proofs + one 32-byte initial chain state per proof, no host challenges
     fs = None
     if not a.no_combined:
-        sys.path.insert(0, os.path.join(ROOT, "oracle"))
-        import pymodel as pm
-        d_init = gpu.to_device(pm.Transcript(LABEL).state * nb)
+        d_init = gpu.to_device(wl["init_state"] * nb)
 
         def fstep(i):
             j = i % len(ctxs)
@@ -227,7 +247,9 @@ def main():
     # the 64-byte partials + local add).  Not the headline (the reference verifies proof by proof).
     comb = None
     if not a.no_combined:
-        d_rho = gpu.to_device(o.random_scalars(0xC0B1 + rank, nb))
+        import random
+        rnd = random.Random(0xC0B1 + rank)   # verifier-chosen weights: any scalars < 2^250 < n
+        d_rho = gpu.to_device(b"".join(rnd.getrandbits(250).to_bytes(32, "little") for _ in range(nb)))
         d_parts = [gpu.malloc(64) for _ in ctxs]
 
         def cstep(i):
@@ -247,12 +269,38 @@ def main():
         if world > 1:
             from mpc_bulletproof_amd import sharding
             cdt = sharding.max_over_ranks(cdt)
-            ones = o.s2b(1)
+            ones = (1).to_bytes(32, "little")
             part = sharding.combine_partial_points(part, lambda x, y: gpu.msm(ones + ones, x + y))
         assert part == bytes(64), "combined batch check must be the identity for valid proofs"
         comb = {"value": world * nb * a.steps / cdt, "unit": "verifications/s", "ms_per_step": cdt / a.steps * 1e3,
                 "note": "sum_p rho_p*mega_check_p == identity (single accept bit per batch; one fixed-base MSM + one "
                         f"{nb * (11 + m + 2 * k)}-term bucket-method MSM per GPU; partial points all-gathered over RCCL when n_gpus > 1)"}
+
+    # ---- secondary: the other half of BASELINE.json's metric, R1CS constraints/s of the prover, on configs[2]'s
+    # shape: 256 provers in lock-step, each range-proving 16 x 64-bit values in one constraint system (n = 1024
+    # multipliers, q = 2064 constraints), through the C++ host mirror (wall clock incl. circuit building,
+    # transcripts and packing on the host).  tools/bench_prove.py checks the proof bytes against the oracle.
+    prove = None
+    if world == 1 and not a.no_prover:
+        import ctypes as C
+        host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+        pnb, nvals = 256, 16
+        pq, pn = nvals * (2 * N_BITS + 1), nvals * N_BITS
+        vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(pnb) for i in range(nvals)]
+        arr = (C.c_uint64 * len(vals))(*vals)
+        lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
+        pout, pcom, plen_ = (C.c_uint8 * (pnb * 4096))(), (C.c_uint8 * (pnb * nvals * 64))(), C.c_size_t(0)
+        best = None
+        for rep in range(3):
+            t0 = time.perf_counter()
+            rc = host.bph_range_prove_batch(C.c_size_t(pnb), C.c_size_t(nvals), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)),
+                                            arr, C.c_uint64(900), C.c_size_t(pn), pout, C.byref(plen_), pcom)
+            pdt = time.perf_counter() - t0
+            assert rc == 0, f"bph_range_prove_batch rc={rc}"
+            best = pdt if best is None or (rep and pdt < best) else best
+        prove = {"value": pnb * pq / best, "unit": "R1CS constraints/s", "proofs_per_s": pnb / best, "ms_per_batch": best * 1e3,
+                 "workload": f"{pnb} provers x ({nvals} x 64-bit range gadgets in one constraint system: n = {pn}, q = {pq}, m = {nvals})",
+                 "note": "wall clock of Prover::prove_batch incl. host circuit building, transcripts, packing and generator tables"}
 
     if rank == 0:
         nvar = 11 + m + 2 * k
@@ -301,6 +349,7 @@ def main():
             "cpu_baseline": cpu,
             "with_device_transcript": fs,
             "combined_batch_check": comb,
+            "r1cs_prove": prove,
         }
         print(json.dumps(out))
     if world > 1:

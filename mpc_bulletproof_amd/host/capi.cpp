@@ -235,6 +235,55 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
   })
 }
 
+// Operands of bpgpu_r1cs_verify_batch for nb proofs of the n_bits range gadget (m = 1), produced by the host mirror:
+// transcript replay per proof (parallel over proofs), the circuit's CSR rows (buffers sized by the caller:
+// row_ptr 2 n_bits + 2, kind/idx 8 n_bits + 8 entries, coeff 32 x that), dims = n1, n, k, m, q, nnz, and the
+// 32-byte transcript state after Transcript::new(label) (input of bpgpu_r1cs_verify_batch_fs).
+int bph_range_verify_inputs(size_t nb, size_t n_bits, const uint8_t *label, size_t label_len, const uint8_t *commitments,
+                            const uint8_t *proofs, size_t proof_len, size_t gens_capacity, uint8_t *points_out,
+                            uint8_t *scalars_out, uint8_t *challenges_out, uint8_t init_state_out[32], size_t dims_out[6],
+                            uint32_t *row_ptr, uint32_t *kind, uint32_t *idx, uint8_t *coeff) {
+  GUARD({
+    PedersenGens pc_gens;
+    BulletproofGens bp_gens(gens_capacity, 1);
+    std::vector<Verifier::BatchInputs> ins(nb);
+    std::vector<uint32_t> rp, kd, ix;
+    std::vector<uint8_t> co;
+    parallel_for(nb, [&](size_t p) {
+      Transcript transcript(std::string((const char *)label, label_len));
+      Verifier verifier(pc_gens, transcript);
+      StarkPoint V;
+      memcpy(V.xy.data(), commitments + 64 * p, 64);
+      Variable var = verifier.commit(V);
+      gadgets::range_proof(verifier, LinearCombination(var), nullptr, n_bits);
+      R1CSProof pr = R1CSProof::from_flat_bytes(std::vector<uint8_t>(proofs + p * proof_len, proofs + (p + 1) * proof_len));
+      ins[p] = verifier.transcript_replay(pr, bp_gens);
+      if (p == 0) verifier.circuit_csr(rp, kd, ix, co);
+    });
+    const auto &a = ins[0];
+    for (size_t p = 0; p < nb; p++) {
+      if (ins[p].k != a.k || ins[p].n != a.n || ins[p].m != a.m) return -3;
+      memcpy(points_out + p * a.points.size(), ins[p].points.data(), a.points.size());
+      memcpy(scalars_out + p * a.scalars.size(), ins[p].scalars.data(), a.scalars.size());
+      memcpy(challenges_out + p * a.challenges.size(), ins[p].challenges.data(), a.challenges.size());
+    }
+    Transcript t0(std::string((const char *)label, label_len));
+    memcpy(init_state_out, t0.state(), 32);
+    dims_out[0] = a.n1; dims_out[1] = a.n; dims_out[2] = a.k; dims_out[3] = a.m; dims_out[4] = rp.size() - 1; dims_out[5] = kd.size();
+    memcpy(row_ptr, rp.data(), rp.size() * 4);
+    memcpy(kind, kd.data(), kd.size() * 4);
+    memcpy(idx, ix.data(), ix.size() * 4);
+    memcpy(coeff, co.data(), co.size());
+    return 0;
+  })
+}
+
+int bph_generator(uint8_t out[64]) {
+  StarkPoint g = StarkPoint::generator();
+  memcpy(out, g.xy.data(), 64);
+  return 0;
+}
+
 int bph_gens(int which, uint32_t party, size_t n, uint8_t *out) {
   GUARD({
     BulletproofGens g(n, party + 1);

@@ -632,9 +632,8 @@ class CsCore {
     return true;
   }
   // constraint rows -> CSR arrays of the C ABI (the reference's Vec<LinearCombination>)
-  bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
-    std::vector<uint32_t> rp{0}, kind, idx;
-    std::vector<uint8_t> coeff;
+  void csr(std::vector<uint32_t> &rp, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx, std::vector<uint8_t> &coeff) const {
+    rp.assign(1, 0); kind.clear(); idx.clear(); coeff.clear();
     for (auto &lc : constraints) {
       for (auto &kv : lc.terms) {
         if (kv.first.kind == Variable::Zero) continue;
@@ -645,6 +644,11 @@ class CsCore {
       }
       rp.push_back((uint32_t)kind.size());
     }
+  }
+  bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
+    std::vector<uint32_t> rp, kind, idx;
+    std::vector<uint8_t> coeff;
+    csr(rp, kind, idx, coeff);
     Device &d = Device::default_device();
     bpgpu_circuit *c = nullptr;
     uint32_t z32 = 0; uint8_t z8 = 0;
@@ -972,20 +976,24 @@ Variable Verifier::commit(const StarkPoint &V) {
   return Variable{Variable::Committed, i};
 }
 
-void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
+void Verifier::circuit_csr(std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx,
+                           std::vector<uint8_t> &coeff) const {
+  c_->csr(row_ptr, kind, idx, coeff);
+}
+
+Verifier::BatchInputs Verifier::transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens) {
   CsCore &c = *c_;
   Transcript &tr = c.tr;
-  Lap lap;
+  BatchInputs in;
   try {
     tr.append_u64("m", c.V.size());                                                     // verifier.rs:398
-    size_t n1 = c.num_vars;
+    in.n1 = c.num_vars;
     tr.validate_and_append_point("A_I1", proof.A_I1);                                   // :401-406
     tr.validate_and_append_point("A_O1", proof.A_O1);
     tr.validate_and_append_point("S1", proof.S1);
     c.create_randomized_constraints();                                                  // :409
-    lap("verify: randomized constraints");
-    size_t n = c.num_vars, padded_n = next_pow2(n), m = c.V.size();
-    if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :421-423
+    in.n = c.num_vars; in.padded_n = next_pow2(in.n); in.m = c.V.size();
+    if (bp_gens.gens_capacity < in.padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :421-423
     tr.append_point("A_I2", proof.A_I2);                                                // :428-430
     tr.append_point("A_O2", proof.A_O2);
     tr.append_point("S2", proof.S2);
@@ -1002,8 +1010,9 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
     Scalar w = tr.challenge_scalar("w");
     // transcript half of verification_scalars (inner_product_proof.rs:259-278)
     size_t k = proof.ipp_proof.L_vec.size();
-    if (k >= 32 || padded_n != ((size_t)1 << k) || proof.ipp_proof.R_vec.size() != k) throw ProofException(ProofError::VerificationError);
-    tr.innerproduct_domain_sep(padded_n);
+    if (k >= 32 || in.padded_n != ((size_t)1 << k) || proof.ipp_proof.R_vec.size() != k) throw ProofException(ProofError::VerificationError);
+    in.k = k;
+    tr.innerproduct_domain_sep(in.padded_n);
     std::vector<Scalar> ch{y, z, u, x, w, Scalar()};
     for (size_t i = 0; i < k; i++) {
       tr.validate_and_append_point("L", proof.ipp_proof.L_vec[i]);
@@ -1011,32 +1020,39 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
       ch.push_back(tr.challenge_scalar("u"));
     }
     ch[5] = tr.challenge_scalar("r");                                                   // :506
-    // device: flatten, inversions, scalar assembly, mega_check MSM, identity test -- :457-553
-    Device &d = Device::default_device();
-    lap("verify: transcript");
-    bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
-    bpgpu_circuit *circ = c.upload_circuit(n, m);
-    lap("verify: upload_circuit");
     std::vector<StarkPoint> pts{proof.A_I1, proof.A_O1, proof.S1, proof.A_I2, proof.A_O2, proof.S2};
     pts.insert(pts.end(), c.V.begin(), c.V.end());
     for (auto *q : {&proof.T_1, &proof.T_3, &proof.T_4, &proof.T_5, &proof.T_6}) pts.push_back(*q);
     pts.insert(pts.end(), proof.ipp_proof.L_vec.begin(), proof.ipp_proof.L_vec.end());
     pts.insert(pts.end(), proof.ipp_proof.R_vec.begin(), proof.ipp_proof.R_vec.end());
-    auto bp = pack_points(pts);
-    auto bs = pack_scalars({proof.t_x, proof.t_x_blinding, proof.e_blinding, proof.ipp_proof.a, proof.ipp_proof.b});
-    auto bc = pack_scalars(ch);
-    int32_t ok = 0;
-    lap("verify: pack");
-    int rc = bpgpu_r1cs_verify_batch(d.ctx(), gens, circ, 1, n1, k, bp.data(), bs.data(), bc.data(), &ok, c.mega.xy.data(), nullptr);
-    lap("verify: bpgpu_r1cs_verify_batch");
-    bpgpu_circuit_destroy(d.ctx(), circ);
-    if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
-    if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
-    d.check(rc, "bpgpu_r1cs_verify_batch");
-    if (!ok) throw R1CSException(R1CSError::VerificationError);                         // :549-551
+    in.points = pack_points(pts);
+    in.scalars = pack_scalars({proof.t_x, proof.t_x_blinding, proof.e_blinding, proof.ipp_proof.a, proof.ipp_proof.b});
+    in.challenges = pack_scalars(ch);
   } catch (const ProofException &) {
     throw R1CSException(R1CSError::VerificationError);                                  // From<ProofError>, errors.rs:179-189
   }
+  return in;
+}
+
+void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
+  CsCore &c = *c_;
+  Lap lap;
+  BatchInputs in = transcript_replay(proof, bp_gens);
+  lap("verify: transcript replay");
+  // device: flatten, inversions, scalar assembly, mega_check MSM, identity test -- :457-553
+  Device &d = Device::default_device();
+  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+  bpgpu_circuit *circ = c.upload_circuit(in.n, in.m);
+  lap("verify: upload_circuit");
+  int32_t ok = 0;
+  int rc = bpgpu_r1cs_verify_batch(d.ctx(), gens, circ, 1, in.n1, in.k, in.points.data(), in.scalars.data(),
+                                   in.challenges.data(), &ok, c.mega.xy.data(), nullptr);
+  lap("verify: bpgpu_r1cs_verify_batch");
+  bpgpu_circuit_destroy(d.ctx(), circ);
+  if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+  if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+  d.check(rc, "bpgpu_r1cs_verify_batch");
+  if (!ok) throw R1CSException(R1CSError::VerificationError);                           // :549-551
 }
 
 }  // namespace r1cs

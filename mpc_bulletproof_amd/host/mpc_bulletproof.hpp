@@ -113,6 +113,7 @@ class Transcript {
   void append_point(const std::string &label, const StarkPoint &p);
   void validate_and_append_point(const std::string &label, const StarkPoint &p);   // throws ProofException(VerificationError)
   Scalar challenge_scalar(const std::string &label);
+  const uint8_t *state() const { return state_; }   // the 32-byte hash-chain state (input of the device transcript)
  private:
   uint8_t state_[32];
 };
@@ -259,6 +260,19 @@ class Verifier : public RandomizedConstraintSystem {
   ~Verifier();
   Variable commit(const StarkPoint &commitment);                   // :298-306
   void verify(const R1CSProof &proof, const BulletproofGens &bp_gens);   // :393-554; throws R1CSException
+  // The host half of verify(): the transcript replay (verifier.rs:398-455,506; inner_product_proof.rs:259-278) and
+  // the operand layout of bpgpu_r1cs_verify_batch -- what a service that batches many proofs of one circuit
+  // collects per proof.  Throws like verify() on identity points / bad lengths.
+  struct BatchInputs {
+    size_t n1 = 0, n = 0, padded_n = 0, m = 0, k = 0;
+    std::vector<uint8_t> points;       // (11 + m + 2k) x 64
+    std::vector<uint8_t> scalars;      // 5 x 32: t_x t_x_blinding e_blinding a b
+    std::vector<uint8_t> challenges;   // (6 + k) x 32: y z u x w r u_1..u_k
+  };
+  BatchInputs transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens);
+  // the constraint rows as the CSR arrays of bpgpu_circuit_create (valid after transcript_replay / verify)
+  void circuit_csr(std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx,
+                   std::vector<uint8_t> &coeff) const;
   // the mega_check point of the last verify() (identity <=> accepted); parity hook
   StarkPoint last_mega_check() const;
   Transcript &transcript() override;
