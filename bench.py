@@ -27,15 +27,15 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 3 points per lane, c = 16 tables (profiles/r01_pmc3_*.csv).
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 16 tables (profiles/r01_pmc_*.csv).
     # k_verify_msm: fetches = 1024 x 2080 random 64-byte rows of the 4.5 GB c = 16 generator table (136 MB of
     # gathers that replace 16 doublings each) + the proof points; writes = the per-lane Straus window tables
-    "verify_msm": int((2 * 187530.9 + 20031.0) * 1024),
-    "verify_scalars": int((2 * 5457.9 + 9601.7) * 1024),
+    "verify_msm": int((2 * 199621.2 + 19778.2) * 1024),
+    "verify_scalars": int((2 * 5402.1 + 9601.4) * 1024),
 }
 # VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_msm<3,16,16> 2.45e8 + k_verify_scalars 2.08e7 + k_verify_finalize 6.3e6 + k_vs_prep 1.6e6
-VALU_WAVE_INSTR_PER_STEP_1024 = 2.45e8 + 2.08e7 + 6.33e6 + 1.59e6
+# k_verify_msm<4,16,16> 2.28e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 2.28e8 + 2.08e7 + 4.64e6 + 1.59e6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
@@ -94,8 +94,8 @@ def main():
     os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=1024)
+    ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "16")))
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
@@ -316,7 +316,7 @@ def main():
         # (Straus: one 252-doubling chain per lane + table build and 63 window additions per non-identity point --
         # A_I2, A_O2, S2 are the identity in 1-phase proofs and are skipped; fixed-base: one mixed addition per
         # (generator, window) + the 16-lane butterfly)
-        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "3"))))
+        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
         lanes = nvar // vnp + nvar % vnp
         W = 252 // a.window_bits + 1
         fp_straus = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
@@ -344,7 +344,7 @@ def main():
             "roofline_valu_issue": ({"bound": "VALU issue slots", "achieved": VALU_WAVE_INSTR_PER_STEP_1024 / step_s,
                                      "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s", "frac": VALU_WAVE_INSTR_PER_STEP_1024 / step_s / VALU_ISSUE_PEAK,
                                      "note": "instructions per step from the PMC pass of the default configuration (profiles/r01_pmc_sq_summary.txt)"}
-                                    if nb == 1024 and vnp == 3 and a.window_bits == 16 and not os.environ.get("BPGPU_NO_FUSE") else None),
+                                    if nb == 1024 and vnp == 4 and a.window_bits == 16 and not os.environ.get("BPGPU_NO_FUSE") else None),
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
             "with_device_transcript": fs,

@@ -708,7 +708,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
   // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
   // so the identity points of 1-phase proofs (A_I2, A_O2, S2) are skipped wave-uniformly inside k_straus.
-  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 3;
+  static const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 4;
   static const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
   const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
   const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
@@ -728,6 +728,8 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     StrausArgs af = am;
     for (int j = 0; j < vnp; j++) af.pts[j] = (const AffDev *)points + j * lanes;
     af.from_boundary = 1; af.bad = ctx->d_flag;
+    static const int sprio = getenv("BPGPU_STRAUS_PRIO") ? atoi(getenv("BPGPU_STRAUS_PRIO")) : 0;
+    af.prio = sprio;
     ProfScope ps(ctx, 6, ctx->st);
     fused = verify_msm_fused(ctx->st, vnp, af, (JacRaw *)dvres, nb * lanes, dstr, g->c, g->table, np, g->cap,
                              (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres, nb);

@@ -269,7 +269,12 @@ struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scal
 template <int NP, int C, int LPM>
 __global__ void __launch_bounds__(64) k_verify_msm(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all,
                                                    unsigned straus_blocks, FixedSmallArgs f) {
-  if (blockIdx.x < straus_blocks) straus_body<NP, 64>(a, out, n, tab_all, blockIdx.x);
+  if (blockIdx.x < straus_blocks) {
+    // the Straus lanes carry the launch's longest dependency chain (252 doublings + 63 NP additions against ~130
+    // table additions per fixed-base lane): let them win the issue arbitration, the fixed-base waves fill the gaps
+    if (a.prio) __builtin_amdgcn_s_setprio(1);
+    straus_body<NP, 64>(a, out, n, tab_all, blockIdx.x);
+  }
   else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - straus_blocks);
 }
 template <int NP, int C>

@@ -141,6 +141,7 @@ void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, 
 // 32 lanes per proof (two proofs per wave): gather, butterfly-reduce with wave shuffles, test identity.
 __global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_t nvar, const JacRaw *fixed,
                                                         size_t nb, int32_t *ok, Words8 *mega) {
+  __builtin_amdgcn_s_setprio(2);   // last link of the per-batch chain: finish ahead of other batches' bulk MSM waves
   const int lane = threadIdx.x & 31;
   size_t p = (size_t)blockIdx.x * 2 + (threadIdx.x >> 5);
   const bool live = p < nb;

@@ -37,6 +37,7 @@ struct StrausArgs {
   size_t out_stride;  // 0 = 1
   int from_boundary;  // pts are ABI bytes (x || y canonical LE words): validate + convert in the kernel, *bad |= 1 on failure
   int *bad;
+  int prio;           // fused launch: raise the Straus waves' issue priority
 };
 // scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
 size_t straus_scratch_bytes(int np, size_t n);

@@ -1,7 +1,7 @@
 #!/bin/bash
 # sweep hardware queues x steps in flight x Straus points per lane (one line per config)
 for q in ${QS:-16 32}; do for s in ${INFL:-16 32}; do for np in ${NPS:-4}; do
-  GPU_MAX_HW_QUEUES=$q BPGPU_STRAUS_NP=$np python bench.py --steps 64 --warmup 16 --no-cpu-baseline --no-combined --workload-cache gpurun_out/wl2 --inflight $s ${EXTRA} 2>&1 | tail -1 > /tmp/o.json
+  GPU_MAX_HW_QUEUES=$q BPGPU_STRAUS_NP=$np python bench.py --steps ${STEPS:-64} --warmup 16 --no-cpu-baseline --no-combined --no-prover --workload-cache gpurun_out/wl2 --inflight $s ${EXTRA} 2>&1 | tail -1 > /tmp/o.json
   python3 - "$q" "$s" "$np" <<'PY'
 import json,sys
 try:
