@@ -184,6 +184,16 @@ void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s);
  * Q = w * B (prover.rs:687), PedersenGens::commit with B = B_blinding (generators.rs:41-43,61-70) */
 int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out);
 
+/* Point wire codec: StarkPoint::from_bytes / to_bytes at r1cs/proof.rs:90-108,150-155 and
+ * inner_product_proof.rs:391-392,440-445.  The 32-byte form lives in the absent crate mpc-stark; restated as
+ * arkworks' compressed short-Weierstrass encoding: x little-endian, bit 7 of byte 31 = "y is the larger of (y, -y)",
+ * bit 6 = point at infinity (parity unpinned).  Decompression takes a square root in F_p
+ * (2-adicity 192) per point on the device.  ok[i] = 1 iff encoding i is valid (canonical x on the curve, not both
+ * flags); invalid ones decode to 64 zero bytes -- the caller maps them to FormatError.  xy: n x 64 B boundary form. */
+int bpgpu_points_decompress(bpgpu_ctx *ctx, const uint8_t *compressed, size_t n, uint8_t *xy, int32_t *ok);
+/* BPGPU_E_ARG when a point is not canonical / not on the curve */
+int bpgpu_points_compress(bpgpu_ctx *ctx, const uint8_t *xy, size_t n, uint8_t *compressed);
+
 /* Batched Verifier::verify arithmetic -- r1cs/verifier.rs:457-553 for nb proofs of ONE circuit.
  * Per proof p (all arrays proof-major):
  *   points     : (11 + m + 2k) x 64 B : A_I1 A_O1 S1 A_I2 A_O2 S2 | V_0..V_{m-1} | T_1 T_3 T_4 T_5 T_6 | L_0..L_{k-1} | R_0..R_{k-1}

@@ -28,6 +28,7 @@ struct bpgpu_ctx {
   std::mutex mu;
   std::string err;
   int *d_flag = nullptr;          // device int: bad-input flag
+  void *sqrt_tab = nullptr;       // F_p square-root tables of the point codec (built on first use)
   Slot ws[20];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
@@ -187,6 +188,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   hipStreamSynchronize(ctx->st2);
   for (auto &s : ctx->ws) if (s.p) hipFree(s.p);
   hipFree(ctx->d_flag);
+  hipFree(ctx->sqrt_tab);
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev2);
   if (ctx->st2 != ctx->st) hipStreamDestroy(ctx->st2);
@@ -412,6 +414,52 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
   CK(flag_read(ctx, &bad));
   if (bad) return BPGPU_E_ARG;
   CK(d2h(ctx, out, dout, nsets * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* ---------------------------------------------------------------- point wire codec */
+int bpgpu_points_decompress(bpgpu_ctx *ctx, const uint8_t *compressed, size_t n, uint8_t *xy, int32_t *ok) {
+  if (!ctx || (n && (!compressed || !xy || !ok))) return BPGPU_E_ARG;
+  if (!n) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->sqrt_tab) {
+    void *t = nullptr;
+    if (hipMalloc(&t, sqrt_table_bytes()) != hipSuccess) return BPGPU_E_OOM;
+    sqrt_tables_build(ctx->st, t);
+    ctx->sqrt_tab = t;
+  }
+  void *din, *dxy, *dok;
+  CK(ws_get(ctx, 0, n * 32, &din));
+  CK(ws_get(ctx, 1, n * 64, &dxy));
+  CK(ws_get(ctx, 5, n * 4, &dok));
+  CK(h2d(ctx, din, compressed, n * 32));
+  points_decompress(ctx->st, (const Words8 *)din, (Words8 *)dxy, (int32_t *)dok, n, ctx->sqrt_tab);
+  CK(launch_ok(ctx));
+  CK(d2h(ctx, xy, dxy, n * 64));
+  CK(d2h(ctx, ok, dok, n * 4));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_points_compress(bpgpu_ctx *ctx, const uint8_t *xy, size_t n, uint8_t *compressed) {
+  if (!ctx || (n && (!xy || !compressed))) return BPGPU_E_ARG;
+  if (!n) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *dxy, *dpts, *dout;
+  CK(ws_get(ctx, 1, n * 64, &dxy));
+  CK(ws_get(ctx, 2, n * sizeof(AffDev), &dpts));
+  CK(ws_get(ctx, 0, n * 32, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dxy, xy, n * 64));
+  points_from_boundary(ctx->st, (const Words8 *)dxy, (AffDev *)dpts, n, ctx->d_flag);   // canonical + on-curve checks
+  points_compress(ctx->st, (const Words8 *)dxy, (Words8 *)dout, n);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, compressed, dout, n * 32));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
 }

@@ -158,4 +158,10 @@ void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, co
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad);
 
+// ---- wire codec of points (k_codec.hip): 32-byte compressed <-> 64-byte affine boundary form ------
+size_t sqrt_table_bytes();
+void sqrt_tables_build(hipStream_t st, void *tab /* sqrt_table_bytes() */);
+void points_decompress(hipStream_t st, const Words8 *in, Words8 *out_xy, int32_t *ok, size_t n, const void *tab);
+void points_compress(hipStream_t st, const Words8 *xy, Words8 *out, size_t n);
+
 }  // namespace bpk

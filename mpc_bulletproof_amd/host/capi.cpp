@@ -278,6 +278,27 @@ int bph_range_verify_inputs(size_t nb, size_t n_bits, const uint8_t *label, size
   })
 }
 
+// wire codec (proof.rs:82-207): "flat v0" <-> reference wire bytes; out buffers sized by the caller (<= flat size)
+int bph_proof_flat_to_wire(const uint8_t *flat, size_t flat_len, uint8_t *wire_out, size_t *wire_len) {
+  GUARD({
+    R1CSProof p = R1CSProof::from_flat_bytes(std::vector<uint8_t>(flat, flat + flat_len));
+    auto w = p.to_bytes();
+    if (w.size() != p.serialized_size()) return -5;
+    memcpy(wire_out, w.data(), w.size());
+    *wire_len = w.size();
+    return 0;
+  })
+}
+int bph_proof_wire_to_flat(const uint8_t *wire, size_t wire_len, uint8_t *flat_out, size_t *flat_len) {
+  GUARD({
+    R1CSProof p = R1CSProof::from_bytes(wire, wire_len);
+    auto f = p.to_flat_bytes();
+    memcpy(flat_out, f.data(), f.size());
+    *flat_len = f.size();
+    return 0;
+  })
+}
+
 int bph_generator(uint8_t out[64]) {
   StarkPoint g = StarkPoint::generator();
   memcpy(out, g.xy.data(), 64);

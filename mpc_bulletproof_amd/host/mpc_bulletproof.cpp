@@ -81,6 +81,16 @@ void Scalar::to_bytes_le(uint8_t out[32]) const {
   mont_mul(t, v_, one);
   for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(t[i] >> (8 * j));
 }
+void Scalar::to_bytes_be(uint8_t out[32]) const {
+  uint8_t le[32];
+  to_bytes_le(le);
+  for (int i = 0; i < 32; i++) out[i] = le[31 - i];
+}
+Scalar Scalar::from_be_bytes_mod_order(const uint8_t b[32]) {
+  uint8_t wide[64] = {0};
+  for (int i = 0; i < 32; i++) wide[i] = b[31 - i];
+  return from_le_bytes_mod_order_wide(wide);
+}
 Scalar Scalar::operator+(const Scalar &o) const {
   Scalar r;
   u128 c = 0;
@@ -381,6 +391,105 @@ bpgpu_gens *BulletproofGens::device_tables(const PedersenGens &pc, int window_bi
   tables_pc_ = key;
   return tables_;
 }
+
+// ================================================================ wire codec =========
+std::vector<uint8_t> compress_points(const std::vector<StarkPoint> &pts) {
+  std::vector<uint8_t> out(pts.size() * 32);
+  if (pts.empty()) return out;
+  Device &d = Device::default_device();
+  auto xy = pack_points(pts);
+  d.check(bpgpu_points_compress(d.ctx(), xy.data(), pts.size(), out.data()), "bpgpu_points_compress");
+  return out;
+}
+std::vector<StarkPoint> decompress_points(const uint8_t *b, size_t n) {
+  std::vector<StarkPoint> pts(n);
+  if (!n) return pts;
+  Device &d = Device::default_device();
+  std::vector<uint8_t> xy(n * 64);
+  std::vector<int32_t> ok(n);
+  d.check(bpgpu_points_decompress(d.ctx(), b, n, xy.data(), ok.data()), "bpgpu_points_decompress");
+  for (size_t i = 0; i < n; i++) {
+    if (!ok[i]) throw ProofException(ProofError::FormatError);
+    memcpy(pts[i].xy.data(), &xy[64 * i], 64);
+  }
+  return pts;
+}
+std::vector<uint8_t> InnerProductProof::to_bytes() const {                                // :387-398
+  std::vector<StarkPoint> pts;
+  for (size_t i = 0; i < L_vec.size(); i++) { pts.push_back(L_vec[i]); pts.push_back(R_vec[i]); }
+  std::vector<uint8_t> out = compress_points(pts);
+  out.resize(out.size() + 64);
+  a.to_bytes_be(&out[out.size() - 64]);
+  b.to_bytes_be(&out[out.size() - 32]);
+  return out;
+}
+InnerProductProof InnerProductProof::from_bytes(const uint8_t *s, size_t len) {           // :419-455
+  if (len < 64 || len % 32) throw ProofException(ProofError::FormatError);
+  size_t num_points = (len - 64) / 32;
+  if (num_points % 2) throw ProofException(ProofError::FormatError);
+  size_t lg_n = num_points / 2;
+  if (lg_n >= 32) throw ProofException(ProofError::FormatError);
+  auto pts = decompress_points(s, num_points);
+  InnerProductProof p;
+  for (size_t i = 0; i < lg_n; i++) { p.L_vec.push_back(pts[2 * i]); p.R_vec.push_back(pts[2 * i + 1]); }
+  p.a = Scalar::from_be_bytes_mod_order(s + 64 * lg_n);
+  p.b = Scalar::from_be_bytes_mod_order(s + 64 * lg_n + 32);
+  return p;
+}
+namespace r1cs {
+static bool missing_phase2(const R1CSProof &p) { return p.A_I2.is_identity() && p.A_O2.is_identity() && p.S2.is_identity(); }   // proof.rs:121-123
+size_t R1CSProof::serialized_size() const { return 1 + (missing_phase2(*this) ? 11 : 14) * 32 + ipp_proof.serialized_size(); }
+std::vector<uint8_t> R1CSProof::to_bytes() const {
+  const bool one = missing_phase2(*this);
+  std::vector<StarkPoint> pts{A_I1, A_O1, S1};
+  if (!one) { pts.push_back(A_I2); pts.push_back(A_O2); pts.push_back(S2); }
+  for (auto *q : {&T_1, &T_3, &T_4, &T_5, &T_6}) pts.push_back(*q);
+  const size_t head = pts.size();
+  for (size_t i = 0; i < ipp_proof.L_vec.size(); i++) { pts.push_back(ipp_proof.L_vec[i]); pts.push_back(ipp_proof.R_vec[i]); }
+  auto cp = compress_points(pts);     // all points of the proof in one device call
+  std::vector<uint8_t> out;
+  out.reserve(serialized_size());
+  out.push_back(one ? 0 : 1);         // ONE_PHASE_COMMITMENTS / TWO_PHASE_COMMITMENTS
+  out.insert(out.end(), cp.begin(), cp.begin() + head * 32);
+  uint8_t sb[32];
+  for (const Scalar *x : {&t_x, &t_x_blinding, &e_blinding}) { x->to_bytes_be(sb); out.insert(out.end(), sb, sb + 32); }
+  out.insert(out.end(), cp.begin() + head * 32, cp.end());
+  ipp_proof.a.to_bytes_be(sb); out.insert(out.end(), sb, sb + 32);
+  ipp_proof.b.to_bytes_be(sb); out.insert(out.end(), sb, sb + 32);
+  return out;
+}
+R1CSProof R1CSProof::from_bytes(const uint8_t *s, size_t len) {
+  if (!len) throw R1CSException(R1CSError::FormatError);
+  const uint8_t version = s[0];
+  s++; len--;
+  if (len % 32) throw R1CSException(R1CSError::FormatError);
+  if (version > 1) throw R1CSException(R1CSError::FormatError);
+  const size_t head = version == 0 ? 8 : 11;
+  if (len < (head + 3) * 32) throw R1CSException(R1CSError::FormatError);
+  const size_t ipp_len = len - (head + 3) * 32;
+  // InnerProductProof::from_bytes' own length checks (inner_product_proof.rs:419-436)
+  if (ipp_len < 64 || ((ipp_len - 64) / 32) % 2 || (ipp_len - 64) / 64 >= 32) throw R1CSException(R1CSError::FormatError);
+  const size_t npts_ipp = (ipp_len - 64) / 32;
+  // gather every compressed point of the proof for one device decompression
+  std::vector<uint8_t> cp(s, s + head * 32);
+  const uint8_t *ipp = s + (head + 3) * 32;
+  cp.insert(cp.end(), ipp, ipp + npts_ipp * 32);
+  std::vector<StarkPoint> pts;
+  try { pts = decompress_points(cp.data(), head + npts_ipp); } catch (const ProofException &) { throw R1CSException(R1CSError::FormatError); }
+  R1CSProof p;
+  size_t k = 0;
+  p.A_I1 = pts[k++]; p.A_O1 = pts[k++]; p.S1 = pts[k++];
+  if (version == 1) { p.A_I2 = pts[k++]; p.A_O2 = pts[k++]; p.S2 = pts[k++]; }
+  p.T_1 = pts[k++]; p.T_3 = pts[k++]; p.T_4 = pts[k++]; p.T_5 = pts[k++]; p.T_6 = pts[k++];
+  p.t_x = Scalar::from_be_bytes_mod_order(s + head * 32);
+  p.t_x_blinding = Scalar::from_be_bytes_mod_order(s + head * 32 + 32);
+  p.e_blinding = Scalar::from_be_bytes_mod_order(s + head * 32 + 64);
+  for (size_t i = 0; i < npts_ipp / 2; i++) { p.ipp_proof.L_vec.push_back(pts[k++]); p.ipp_proof.R_vec.push_back(pts[k++]); }
+  p.ipp_proof.a = Scalar::from_be_bytes_mod_order(ipp + npts_ipp * 32);
+  p.ipp_proof.b = Scalar::from_be_bytes_mod_order(ipp + npts_ipp * 32 + 32);
+  return p;
+}
+}  // namespace r1cs
 
 // ================================================================ util / inner product =============
 namespace util {

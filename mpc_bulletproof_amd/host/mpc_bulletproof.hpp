@@ -40,6 +40,8 @@ class Scalar {
   static Scalar from_bytes_le(const uint8_t b[32]);        // canonical; throws ProofException(FormatError)
   static Scalar from_le_bytes_mod_order_wide(const uint8_t b[64]);
   void to_bytes_le(uint8_t out[32]) const;
+  void to_bytes_be(uint8_t out[32]) const;                 // Scalar::to_bytes_be (proof wire format)
+  static Scalar from_be_bytes_mod_order(const uint8_t b[32]);
   std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; to_bytes_le(o.data()); return o; }
   Scalar operator+(const Scalar &o) const;
   Scalar operator-(const Scalar &o) const;
@@ -164,7 +166,14 @@ struct InnerProductProof {
   void verify(size_t n, Transcript &transcript, const std::vector<Scalar> &G_factors, const std::vector<Scalar> &H_factors,
               const StarkPoint &P, const StarkPoint &Q, const std::vector<StarkPoint> &G, const std::vector<StarkPoint> &H) const;
   bool operator==(const InnerProductProof &o) const { return L_vec == o.L_vec && R_vec == o.R_vec && a == o.a && b == o.b; }
+  // wire format (:379-455): L_0 R_0 .. L_{k-1} R_{k-1} as 32-byte compressed points, then a, b big-endian
+  size_t serialized_size() const { return L_vec.size() * 2 * 32 + 64; }
+  std::vector<uint8_t> to_bytes() const;
+  static InnerProductProof from_bytes(const uint8_t *b, size_t len);   // throws ProofException(FormatError)
 };
+// StarkPoint::to_bytes / from_bytes for many points in one device call (bpgpu_points_compress / _decompress)
+std::vector<uint8_t> compress_points(const std::vector<StarkPoint> &pts);
+std::vector<StarkPoint> decompress_points(const uint8_t *b, size_t n);   // throws ProofException(FormatError)
 
 namespace util {
 std::vector<Scalar> exp_iter(const Scalar &x, size_t n);          // src/util.rs:73-76
@@ -203,6 +212,10 @@ struct R1CSProof {                                                 // proof.rs:3
   // compression lives in the absent mpc-stark crate -- proof.rs:82-109)
   std::vector<uint8_t> to_flat_bytes() const;
   static R1CSProof from_flat_bytes(const std::vector<uint8_t> &b);   // throws R1CSException(FormatError)
+  // the reference wire format (proof.rs:82-207): version byte, 8 or 11 compressed points, 3 scalars, the IPP
+  size_t serialized_size() const;                                     // proof.rs:111-119
+  std::vector<uint8_t> to_bytes() const;                              // proof.rs:82-109
+  static R1CSProof from_bytes(const uint8_t *b, size_t len);          // proof.rs:128-207; throws R1CSException(FormatError)
 };
 
 class RandomizedConstraintSystem;

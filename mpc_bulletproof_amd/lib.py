@@ -8,7 +8,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
     "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
-    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_shared", "bpgpu_gens_create",
+    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
@@ -134,6 +134,19 @@ class BpGpu:
         out = _out(64 * nsets)
         self._ck(_lib.bpgpu_msm_shared(self.ctx, C.c_size_t(nsets), C.c_size_t(n), _buf(scalars), _buf(points), out))
         return bytes(out)[:64 * nsets]
+
+    def points_decompress(self, compressed):
+        """-> (xy bytes n x 64, ok list) for n x 32-byte compressed points"""
+        n = len(compressed) // 32
+        xy, ok = _out(64 * n), (C.c_int32 * max(n, 1))()
+        self._ck(_lib.bpgpu_points_decompress(self.ctx, _buf(compressed), C.c_size_t(n), xy, ok))
+        return bytes(xy)[:64 * n], list(ok)[:n]
+
+    def points_compress(self, xy):
+        n = len(xy) // 64
+        out = _out(32 * n)
+        self._ck(_lib.bpgpu_points_compress(self.ctx, _buf(xy), C.c_size_t(n), out))
+        return bytes(out)[:32 * n]
 
     def inner_product(self, a, b):
         if len(a) != len(b):

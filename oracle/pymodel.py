@@ -930,3 +930,141 @@ def example_gadget(cs, a1, a2, b1, b2, c1, c2):
     """tests/r1cs.rs:217-228."""
     _, _, c_var = cs.multiply(lc_add(a1, a2), lc_add(b1, b2))
     cs.constrain(lc_sub(lc_add(c1, c2), lc_var(c_var)))
+
+
+# --------------------------------------------------------------------------- wire codec (SURVEY.md 8f N3)
+# R1CSProof::{to,from}_bytes (src/r1cs/proof.rs:82-207), InnerProductProof::{to,from}_bytes
+# (src/inner_product_proof.rs:379-455).  Scalars: 32 bytes big-endian, read back mod n
+# (`from_be_bytes_mod_order`).  Points: StarkPoint::to_bytes() is defined in the absent crate mpc-stark = "0.2";
+# restated here as arkworks' compressed short-Weierstrass encoding (ark-serialize 0.4, which mpc-stark builds
+# on): x as 32 little-endian bytes with two flag bits in the top of the last byte -- bit 7: y is the
+# lexicographically larger of (y, -y); bit 6: point at infinity.  PARITY UNPINNED for the point bytes (no file
+# or test of the reference fixes them); everything else follows the reference line by line.
+ONE_PHASE_COMMITMENTS = 0
+TWO_PHASE_COMMITMENTS = 1
+
+
+class FormatError(Exception):
+    """ProofError::FormatError / R1CSError::FormatError"""
+
+
+def fp_sqrt(a: int):
+    """Tonelli-Shanks in F_p (p - 1 = 2^192 * (2^59 + 17)); None for a non-residue."""
+    a %= P
+    if a == 0:
+        return 0
+    if pow(a, (P - 1) // 2, P) != 1:
+        return None
+    s, t = 192, (P - 1) >> 192
+    z = pow(3, t, P)                      # 3 is the smallest quadratic non-residue
+    x, b, m = pow(a, (t + 1) // 2, P), pow(a, t, P), s
+    while b != 1:
+        i, bb = 0, b
+        while bb != 1:
+            bb = bb * bb % P
+            i += 1
+        g = pow(z, 1 << (m - i - 1), P)
+        x, z, b, m = x * g % P, g * g % P, b * g * g % P, i
+    assert x * x % P == a
+    return x
+
+
+def point_compress(Pt) -> bytes:
+    if Pt is INF:
+        return bytes(31) + b"\x40"
+    x, y = Pt
+    b = bytearray(x.to_bytes(32, "little"))
+    if y > P - y:
+        b[31] |= 0x80
+    return bytes(b)
+
+
+def point_decompress(b: bytes):
+    if len(b) != 32:
+        raise FormatError("length")
+    flags = b[31] >> 6
+    x = int.from_bytes(b[:31] + bytes([b[31] & 0x3F]), "little")
+    if flags == 3 or x >= P:
+        raise FormatError("flags / non-canonical x")
+    if flags == 1:
+        return INF
+    y = fp_sqrt((x * x * x + CURVE_A * x + CURVE_B) % P)
+    if y is None:
+        raise FormatError("x is not on the curve")
+    if (y > P - y) != (flags == 2):
+        y = P - y
+    return (x, y)
+
+
+def scalar_to_bytes_be(s: int) -> bytes:
+    return (s % N).to_bytes(32, "big")
+
+
+def ipp_to_bytes(L_vec, R_vec, a, b) -> bytes:
+    out = b""
+    for l, r in zip(L_vec, R_vec):
+        out += point_compress(l) + point_compress(r)
+    return out + scalar_to_bytes_be(a) + scalar_to_bytes_be(b)
+
+
+def ipp_from_bytes(s: bytes):
+    """inner_product_proof.rs:419-455"""
+    if len(s) < 64 or len(s) % 32:
+        raise FormatError("length")
+    num_points = (len(s) - 64) // 32
+    if num_points % 2:
+        raise FormatError("odd number of points")
+    lg_n = num_points // 2
+    if lg_n >= 32:
+        raise FormatError("too big")
+    L = [point_decompress(s[64 * i:64 * i + 32]) for i in range(lg_n)]
+    R = [point_decompress(s[64 * i + 32:64 * i + 64]) for i in range(lg_n)]
+    pos = 64 * lg_n
+    return L, R, int.from_bytes(s[pos:pos + 32], "big") % N, int.from_bytes(s[pos + 32:pos + 64], "big") % N
+
+
+_PROOF_POINTS_1 = ("A_I1", "A_O1", "S1")
+_PROOF_POINTS_2 = ("A_I2", "A_O2", "S2")
+_PROOF_POINTS_T = ("T_1", "T_3", "T_4", "T_5", "T_6")
+
+
+def r1cs_proof_to_bytes(p: dict) -> bytes:
+    """r1cs/proof.rs:82-123; p has the keys of Prover.prove()'s result"""
+    one_phase = all(p[k] is INF for k in _PROOF_POINTS_2)
+    out = bytes([ONE_PHASE_COMMITMENTS if one_phase else TWO_PHASE_COMMITMENTS])
+    for k in _PROOF_POINTS_1 + (() if one_phase else _PROOF_POINTS_2) + _PROOF_POINTS_T:
+        out += point_compress(p[k])
+    for k in ("t_x", "t_x_blinding", "e_blinding"):
+        out += scalar_to_bytes_be(p[k])
+    return out + ipp_to_bytes(p["L_vec"], p["R_vec"], p["a"], p["b"])
+
+
+def r1cs_proof_from_bytes(s: bytes) -> dict:
+    """r1cs/proof.rs:128-207"""
+    if not s:
+        raise FormatError("empty")
+    version, s = s[0], s[1:]
+    if len(s) % 32:
+        raise FormatError("length")
+    if version not in (ONE_PHASE_COMMITMENTS, TWO_PHASE_COMMITMENTS):
+        raise FormatError("version")
+    if len(s) < (11 if version == ONE_PHASE_COMMITMENTS else 14) * 32:
+        raise FormatError("short")
+    p, pos = {}, 0
+
+    def rd_point():
+        nonlocal pos
+        v = point_decompress(s[pos:pos + 32])
+        pos += 32
+        return v
+    for k in _PROOF_POINTS_1:
+        p[k] = rd_point()
+    for k in _PROOF_POINTS_2:
+        p[k] = INF if version == ONE_PHASE_COMMITMENTS else rd_point()
+    for k in _PROOF_POINTS_T:
+        p[k] = rd_point()
+    for k in ("t_x", "t_x_blinding", "e_blinding"):
+        p[k] = int.from_bytes(s[pos:pos + 32], "big") % N
+        pos += 32
+    p["L_vec"], p["R_vec"], p["a"], p["b"] = ipp_from_bytes(s[pos:])
+    return p

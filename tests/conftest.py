@@ -37,3 +37,8 @@ def golden_ipp():
 @pytest.fixture(scope="session")
 def golden_r1cs():
     return load_golden("r1cs.json")
+
+
+@pytest.fixture(scope="session")
+def golden_codec():
+    return load_golden("codec.json")

@@ -103,3 +103,33 @@ int h29_recode(int c, const uint8_t *s, int *digits) {
   return n;
 }
 }
+
+// ---- square roots (fe29_sqrt.cuh): tables built once on the CPU
+#include "../../mpc_bulletproof_amd/csrc/fe29_sqrt.cuh"
+static int32_t g_sqrt_T[SQ_DIG * 256 * NL];
+static uint8_t g_sqrt_hash[65536];
+static bool g_sqrt_ready = false;
+extern "C" {
+// -> 1: root written (canonical bytes), 0: non-residue, -1: malformed; -2: the hash table collides
+int h29_sqrt(const uint8_t *a, uint8_t *out) {
+  if (!g_sqrt_ready) {
+    memset(g_sqrt_hash, 0xff, sizeof g_sqrt_hash);
+    for (int j = 0; j < SQ_DIG; j++)
+      for (int d = 0; d < 256; d++) {
+        Fp e = sqrt_table_entry(j, d);
+        for (int t = 0; t < NL; t++) g_sqrt_T[((size_t)j * 256 + d) * NL + t] = e.v[t];
+        if (j == SQ_DIG - 1) {
+          uint32_t h = sqrt_hash(e);
+          if (g_sqrt_hash[h] != 0xff) return -2;
+          g_sqrt_hash[h] = (uint8_t)((256 - d) & 255);
+        }
+      }
+    g_sqrt_ready = true;
+  }
+  Fp x, r;
+  if (!load_fe(x, a)) return -1;
+  if (!fp_sqrt(r, x, g_sqrt_T, g_sqrt_hash)) return 0;
+  store_fe(out, r);
+  return 1;
+}
+}

@@ -570,3 +570,63 @@ def test_verify_with_device_transcript(gpu):
         finally:
             gpu.gens_destroy(g)
             gpu.circuit_destroy(circ)
+
+
+# ------------------------------------------------------------------ wire codec
+def test_points_codec_golden(gpu, golden_codec):
+    """32-byte compressed points <-> affine: the model's vectors (signs, identity) both ways, and the rejected
+    encodings (x off the curve with either sign flag, x >= p, both flags)."""
+    xy = b"".join(H(r["xy"]) for r in golden_codec["points"])
+    comp = b"".join(H(r["compressed"]) for r in golden_codec["points"])
+    assert gpu.points_compress(xy) == comp
+    got, ok = gpu.points_decompress(comp)
+    assert got == xy and ok == [1] * len(golden_codec["points"])
+    bad = b"".join(H(b) for b in golden_codec["invalid"])
+    got, ok = gpu.points_decompress(bad + comp[:32])
+    assert ok == [0] * len(golden_codec["invalid"]) + [1]
+    assert got[:64 * len(golden_codec["invalid"])] == bytes(64 * len(golden_codec["invalid"]))
+    import mpc_bulletproof_amd as m
+    off = bytearray(xy[:64])
+    off[0] ^= 1
+    with pytest.raises(m.BpGpuError) as e:
+        gpu.points_compress(bytes(off))
+    assert e.value.code == m.lib.E_ARG
+
+
+def test_points_codec_roundtrip_many(gpu):
+    """decompress(compress(P)) == P for 4096 generator-chain points and their negatives (size-independent property;
+    every decompression is a square root in F_p through the 24-digit discrete logarithm)."""
+    sys_path_oracle()
+    import pymodel as pm
+    n = 2048
+    pts = o.gens("G", n // 2) + o.gens("H", n // 2)
+    neg = b"".join(pts[64 * i:64 * i + 32] + ((pm.P - int.from_bytes(pts[64 * i + 32:64 * i + 64], "little")) % pm.P).to_bytes(32, "little")
+                   for i in range(n))
+    allp = pts + neg
+    comp = gpu.points_compress(allp)
+    # a point and its negative share x and differ in the sign flag only
+    for i in range(0, n, 97):
+        a, b = comp[32 * i:32 * i + 32], comp[32 * (n + i):32 * (n + i) + 32]
+        assert a[:31] == b[:31] and (a[31] ^ b[31]) == 0x80
+    got, ok = gpu.points_decompress(comp)
+    assert ok == [1] * (2 * n) and got == allp
+
+
+def test_proof_wire_format_golden(golden_codec):
+    """R1CSProof::to_bytes / from_bytes through the host mirror (device point codec underneath) against the model's
+    wire bytes of the committed golden proofs (1-phase and 2-phase), and the reference's length / version errors."""
+    import ctypes as C
+    import os
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_bulletproof_amd", "libbphost.so"))
+    out, ln = (C.c_uint8 * 8192)(), C.c_size_t(0)
+    for rec in golden_codec["proofs"]:
+        flat, wire = H(rec["flat"]), H(rec["wire"])
+        assert host.bph_proof_flat_to_wire(o._buf(flat), C.c_size_t(len(flat)), out, C.byref(ln)) == 0
+        assert bytes(out)[:ln.value] == wire
+        assert host.bph_proof_wire_to_flat(o._buf(wire), C.c_size_t(len(wire)), out, C.byref(ln)) == 0
+        assert bytes(out)[:ln.value] == flat
+    wire = H(golden_codec["proofs"][0]["wire"])
+    bad_cases = [b"", bytes([2]) + wire[1:], wire[:-1], wire[:1 + 10 * 32], wire + bytes(32),
+                 wire[:1] + H(golden_codec["invalid"][0]) + wire[33:]]
+    for bad in bad_cases:
+        assert host.bph_proof_wire_to_flat(o._buf(bad if bad else b"\0"), C.c_size_t(len(bad)), out, C.byref(ln)) == -3, bad[:4]
