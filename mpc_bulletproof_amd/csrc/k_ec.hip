@@ -293,6 +293,7 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
   else if (c == 16 && np == 3) launch_verify_msm<3, 16>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 16 && np == 4) launch_verify_msm<4, 16>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 8 && np == 2) launch_verify_msm<2, 8>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 8 && np == 3) launch_verify_msm<3, 8>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 8 && np == 4) launch_verify_msm<4, 8>(st, a, out_var, n_lanes, scratch, f);
   else return false;
   return true;

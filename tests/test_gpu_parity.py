@@ -270,6 +270,59 @@ def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
         gpu.circuit_destroy(circ)
 
 
+@pytest.mark.parametrize("np_,fuse", [(4, True), (3, True), (2, True), (4, False), (1, False)])
+def test_verify_batch_fused_and_split_launches(gpu, monkeypatch, np_, fuse):
+    """Batches of >= 64 proofs take the fused mega_check launch (role-major Straus lanes + small fixed-base MSMs in
+    one kernel, points validated in-kernel); 18 proof points with 4 per lane leave a remainder launch.  Accept
+    bits, mega_check points (tampered proofs included) and all MSM scalars must equal the oracle's for every
+    points-per-lane setting, fused or not."""
+    monkeypatch.setenv("BPGPU_STRAUS_NP", str(np_))
+    if not fuse:
+        monkeypatch.setenv("BPGPU_NO_FUSE", "1")
+    test_range_verify_batch(gpu, 8, 70, 8)
+
+
+def test_verify_batch_rejects_malformed_inputs_in_fused_launch(gpu):
+    """An off-curve proof point or a non-canonical scalar anywhere in a 70-proof batch -> BPGPU_E_ARG (the fused
+    kernel validates points itself; the scalar assembly checks canonicity)."""
+    import mpc_bulletproof_amd as m
+    recs, cap = bh.make_range_batch(8, 70)
+    s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
+    rp, kind, idx, coeff = s0.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        pts = sc = ch = b""
+        for proof, com in recs:
+            s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap)
+            k, p, q = bh.verify_inputs(proof, com)
+            pts += p
+            sc += q
+            ch += s.challenges()
+            s.close()
+        ok, _, _ = gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, ch)
+        assert ok == [1] * 70
+        nvar = 11 + s0.m + 2 * s0.k
+        bad_pts = bytearray(pts)
+        bad_pts[64 * (nvar * 37 + 9) + 3] ^= 4          # proof 37, point 9: off the curve
+        with pytest.raises(m.BpGpuError) as e:
+            gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, bytes(bad_pts), sc, ch)
+        assert e.value.code == m.lib.E_ARG
+        bad_sc = bytearray(sc)
+        bad_sc[32 * (5 * 51 + 2):32 * (5 * 51 + 3)] = N.to_bytes(32, "little")      # proof 51: e_blinding = n
+        with pytest.raises(m.BpGpuError) as e:
+            gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, bytes(bad_sc), ch)
+        assert e.value.code == m.lib.E_ARG
+        bad_ch = bytearray(ch)
+        bad_ch[32 * ((6 + s0.k) * 3 + 7):32 * ((6 + s0.k) * 3 + 8)] = b"\xff" * 32  # proof 3: u_2 >= n
+        with pytest.raises(m.BpGpuError) as e:
+            gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, bytes(bad_ch))
+        assert e.value.code == m.lib.E_ARG
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+
+
 def test_verify_batch_generators_too_short(gpu):
     import mpc_bulletproof_amd as m
     recs, cap = bh.make_range_batch(8, 1)
