@@ -81,6 +81,11 @@ int bpgpu_msm(bpgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, siz
 /* nb independent MSMs of n terms each (term-major within an MSM); out = nb points */
 int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
                     uint8_t *out);
+/* bpgpu_msm_batch with device-resident operands and result (boundary encodings in HBM, e.g. from bpgpu_upload):
+ * asynchronous on the context's stream; malformed operands raise the context's input flag (bpgpu_input_flag)
+ * instead of an error code.  For callers that keep points resident between MSMs. */
+int bpgpu_msm_batch_dev(bpgpu_ctx *ctx, size_t nb, size_t n, const void *scalars_dev, const void *points_dev,
+                        void *out_dev);
 /* nsets MSMs over ONE point vector: out[s] = sum_i scalars[s*n + i] * points[i].  This is the local work of
  * StarkPoint::msm_authenticated_iter in the two-party prover -- one MSM each over the secret shares, the MACs and
  * the public modifiers of the same authenticated scalars against the same points (r1cs_mpc/mpc_prover.rs:621-657,

@@ -309,31 +309,22 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
 }
 
 /* ---------------------------------------------------------------- MSM (general points) */
-static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
-                            uint8_t *out) {
-  HIPCK(ctx, hipSetDevice(ctx->device));
+// device-resident core: dsc / dxy hold the boundary encodings in HBM, dout receives nb x 64 B; asynchronous on ctx->st
+static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *dxy, void *dout) {
   size_t tot = nb * n;
-  if (!nb) return BPGPU_OK;
-  if (!n) { memset(out, 0, nb * 64); return BPGPU_OK; }
-  void *dsc, *dxy, *dpts, *dres, *dsum, *dout;
-  CK(ws_get(ctx, 0, tot * 32, &dsc));
-  CK(ws_get(ctx, 1, tot * 64, &dxy));
+  void *dpts, *dres, *dsum;
   CK(ws_get(ctx, 2, tot * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
   CK(ws_get(ctx, 4, nb * sizeof(JacRaw), &dsum));
-  CK(ws_get(ctx, 5, nb * 64, &dout));
-  CK(flag_reset(ctx));
-  CK(h2d(ctx, dsc, scalars, tot * 32));
-  CK(h2d(ctx, dxy, points, tot * 64));
-  scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
-  points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, tot, ctx->d_flag);
+  scalars_check(ctx->st, (const Words8 *)dsc, tot, ctx->d_flag);
+  points_from_boundary(ctx->st, (const Words8 *)dxy, (AffDev *)dpts, tot, ctx->d_flag);
   static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
-  if (n >= pip_min) {   // bucket method per instance
+  if (n >= pip_min) {   // bucket method
     int c = pippenger_window(n);
     void *dpip;
     if (nb == 1) {
       CK(ws_get(ctx, 14, pippenger_scratch_bytes(n, c), &dpip));
-      pippenger(ctx->st, (AffDev *)dpts, (uint32_t *)dsc, n, c, (JacRaw *)dsum, dpip);
+      pippenger(ctx->st, (AffDev *)dpts, (const uint32_t *)dsc, n, c, (JacRaw *)dsum, dpip);
     } else {
       CK(ws_get(ctx, 14, pippenger_scratch_bytes_batch(nb, n, c), &dpip));
       pippenger_batch(ctx->st, (AffDev *)dpts, (const uint32_t *)dsc, nb, n, c, (JacRaw *)dsum, 1, dpip);
@@ -341,20 +332,44 @@ static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *
   } else {
     StrausArgs a{};
     a.pts[0] = (AffDev *)dpts; a.pt_stride[0] = 1;
-    a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
+    a.sc[0] = (const uint32_t *)dsc; a.sc_stride[0] = 8;
     void *dstr;
     CK(straus_ws(ctx, 1, tot, &dstr));
     straus(ctx->st, 1, a, (JacRaw *)dres, tot, dstr);
     segmented_sum(ctx->st, (JacRaw *)dres, (JacRaw *)dsum, nb, n);
   }
   jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nb);
-  CK(launch_ok(ctx));
+  return launch_ok(ctx);
+}
+static int msm_batch_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars, const uint8_t *points,
+                            uint8_t *out) {
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t tot = nb * n;
+  if (!nb) return BPGPU_OK;
+  if (!n) { memset(out, 0, nb * 64); return BPGPU_OK; }
+  void *dsc, *dxy, *dout;
+  CK(ws_get(ctx, 0, tot * 32, &dsc));
+  CK(ws_get(ctx, 1, tot * 64, &dxy));
+  CK(ws_get(ctx, 5, nb * 64, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dsc, scalars, tot * 32));
+  CK(h2d(ctx, dxy, points, tot * 64));
+  CK(msm_batch_dev_locked(ctx, nb, n, dsc, dxy, dout));
   int bad = 0;
   CK(flag_read(ctx, &bad));
   if (bad) return BPGPU_E_ARG;
   CK(d2h(ctx, out, dout, nb * 64));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
+}
+int bpgpu_msm_batch_dev(bpgpu_ctx *ctx, size_t nb, size_t n, const void *scalars_dev, const void *points_dev, void *out_dev) {
+  if (!ctx || (nb && !out_dev) || (nb && n && (!scalars_dev || !points_dev))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (!nb) return BPGPU_OK;
+  if (!n) { HIPCK(ctx, hipMemsetAsync(out_dev, 0, nb * 64, ctx->st)); return BPGPU_OK; }
+  CK(flag_reset(ctx));   // the flag reports on the most recent *_dev call
+  return msm_batch_dev_locked(ctx, nb, n, scalars_dev, points_dev, out_dev);
 }
 int bpgpu_msm(bpgpu_ctx *ctx, const uint8_t *scalars, const uint8_t *points, size_t n, uint8_t out[64]) {
   if (!ctx || !out || (n && (!scalars || !points))) return BPGPU_E_ARG;

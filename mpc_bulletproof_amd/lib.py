@@ -8,7 +8,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
     "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download",
-    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
+    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
@@ -128,6 +128,9 @@ class BpGpu:
         b = _buf(scalars)
         self._ck(_lib.bpgpu_batch_inverse(self.ctx, b, C.c_size_t(n)))
         return bytes(b)[:32 * n]
+
+    def msm_batch_dev(self, nb, n, d_scalars, d_points, d_out):
+        self._ck(_lib.bpgpu_msm_batch_dev(self.ctx, C.c_size_t(nb), C.c_size_t(n), d_scalars, d_points, d_out))
 
     def msm_shared(self, nsets, n, scalars, points):
         """nsets MSMs over one point vector (msm_authenticated_iter's share / MAC / modifier MSMs)."""

@@ -95,6 +95,26 @@ def test_msm_shared_points(gpu, n):
     assert e.value.code == m.lib.E_ARG
 
 
+def test_msm_batch_device_resident(gpu):
+    """bpgpu_msm_batch_dev: operands and result stay in HBM; same bytes as the host-buffer call; a malformed
+    operand raises the input flag."""
+    nb, n = 3, 40
+    sc = o.random_scalars(77, nb * n)
+    pts = (o.gens("G", 64) + o.gens("H", 64))[:64 * nb * n]
+    want = o.msm_batch(sc, pts, nb, n)
+    d_sc, d_pts, d_out = gpu.to_device(sc), gpu.to_device(pts), gpu.malloc(64 * nb)
+    gpu.msm_batch_dev(nb, n, d_sc, d_pts, d_out)
+    assert gpu.download(d_out, 64 * nb) == want and gpu.input_flag() == 0
+    bad = bytearray(pts)
+    bad[64 * 17 + 1] ^= 2
+    d_bad = gpu.to_device(bytes(bad))
+    gpu.msm_batch_dev(nb, n, d_sc, d_bad, d_out)
+    gpu.sync()
+    assert gpu.input_flag() == 1
+    for d in (d_sc, d_pts, d_out, d_bad):
+        gpu.free(d)
+
+
 def test_msm_rejects_bad_input(gpu):
     import mpc_bulletproof_amd as m
     G = o.generator()
