@@ -165,9 +165,19 @@ def main():
     import torch.distributed as dist
     import mpc_bulletproof_amd as mb
     if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ctxs = [mb.BpGpu(local_rank) for _ in range(max(1, a.inflight))]
+        if os.environ.get("BPGPU_BENCH_REHEARSAL"):
+            # control-flow rehearsal of the multi-rank path on a ONE-GPU box: all ranks share device 0, gloo instead
+            # of RCCL (NCCL refuses two ranks on one device).  Not a measurement.
+            dev = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            dev = local_rank
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dev = local_rank
+    ctxs = [mb.BpGpu(dev) for _ in range(max(1, a.inflight))]
     gpu = ctxs[0]
     circ = gpu.circuit_create(rp, kind, idx, coeff, n1 + n2, m)
     gens = gpu.gens_create(wl["G"], wl["H"], wl["B"], wl["B"], a.window_bits)
