@@ -21,16 +21,21 @@ namespace bpk {
 // kernels of several in-flight batches overlap (profiles/: 1.75 ms/launch at 0.5 wave/SIMD before).
 constexpr int SW = 4;                 // window bits
 constexpr int SE = 1 << (SW - 1);     // 8 table entries
+constexpr int STE = 36;   // int32 per table entry slot: X Y Z + a prefix product while normalising; x y afterwards
 template <int NP, int TPB>
 __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, size_t n, int32_t *tab_all, size_t blk) {
   const int tid = threadIdx.x;
-  int32_t *tab = tab_all + blk * (NP * SE * 27 * TPB);
+  int32_t *tab = tab_all + blk * (NP * SE * STE * TPB);
   size_t i = blk * TPB + tid;
   const bool live = i < n;
   if (!live) i = n - 1;               // keep the wave uniform; result discarded
   uint32_t sp[NP][9];
   unsigned skip = 0;   // bit j, wave-uniform: every lane's j-th point is the identity (A_I2, A_O2, S2 of 1-phase proofs
-                   // when the lanes of a wave share a role) -> no table, no additions for j
+                       // when the lanes of a wave share a role) -> no table, no additions for j
+  unsigned pinf = 0;   // bit j, per lane: this lane's j-th point is the identity
+  auto slot = [&](int j, int e) { return tab + ((size_t)(j * SE + e) * STE) * TPB + tid; };
+  auto ld = [&](const int32_t *p, int off) { Fp r; for (int t = 0; t < NL; t++) r.v[t] = p[(off + t) * TPB]; return r; };
+  auto st = [&](int32_t *p, int off, const Fp &x) { for (int t = 0; t < NL; t++) p[(off + t) * TPB] = x.v[t]; };
 #pragma unroll
   for (int j = 0; j < NP; j++) {
     uint32_t s[8];
@@ -53,17 +58,49 @@ __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, si
     } else {
       P = aff_load(psrc);
     }
-    if (__all(aff_is_inf(P))) { skip |= 1u << j; continue; }
+    const bool inf = aff_is_inf(P);
+    if (__all(inf)) { skip |= 1u << j; continue; }
+    if (inf) pinf |= 1u << j;
     Jac m = jac_from_aff(P);
 #pragma unroll 1
     for (int e = 0; e < SE; e++) {
-      int32_t *dst = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
-#pragma unroll
-      for (int t = 0; t < NL; t++) { dst[t * TPB] = m.X.v[t]; dst[(NL + t) * TPB] = m.Y.v[t]; dst[(2 * NL + t) * TPB] = m.Z.v[t]; }
+      int32_t *dst = slot(j, e);
+      st(dst, 0, m.X); st(dst, NL, m.Y); st(dst, 2 * NL, m.Z);
       if (e + 1 < SE) m = jac_madd(m, P);
     }
   }
   // each lane only ever reads back its own stores (same thread, program order): no fence needed
+  if constexpr (NP >= 2) {
+    // Affine tables: one inversion per lane (Montgomery's trick over the Z of entries 2P..8P of every point) turns
+    // the 63 NP general additions of the main loop into mixed ones (~3 300 -> ~2 400 instructions each) for
+    // ~80 k instructions of normalisation.  Entry 0 is affine already.  Identity points contribute Z = 1.
+    Fp prod = fe_one<FP>();
+#pragma unroll 1
+    for (int j = 0; j < NP; j++) {
+      if ((skip >> j) & 1) continue;
+#pragma unroll 1
+      for (int e = 1; e < SE; e++) {
+        int32_t *p = slot(j, e);
+        st(p, 3 * NL, prod);
+        if (!((pinf >> j) & 1)) prod = fpmul(prod, ld(p, 2 * NL));
+      }
+    }
+    Fp pinv = inv(prod);
+#pragma unroll 1
+    for (int j = NP - 1; j >= 0; j--) {
+      if ((skip >> j) & 1) continue;
+#pragma unroll 1
+      for (int e = SE - 1; e >= 1; e--) {
+        int32_t *p = slot(j, e);
+        if ((pinf >> j) & 1) continue;
+        Fp zi = fpmul(pinv, ld(p, 3 * NL));
+        pinv = fpmul(pinv, ld(p, 2 * NL));
+        Fp zi2 = fpsqr(zi);
+        st(p, 0, fpmul(ld(p, 0), zi2));
+        st(p, NL, fpmul(ld(p, NL), fpmul(zi2, zi)));
+      }
+    }
+  }
   Jac acc = jac_inf();
   constexpr int W = num_windows<SW>();
 #pragma unroll 1
@@ -76,14 +113,21 @@ __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, si
     for (int j = 0; j < NP; j++) {
       if ((skip >> j) & 1) continue;
       int dg = recode_digit<SW>(sp[j], w);
-      if (dg != 0) {
+      if (dg != 0 && !((pinf >> j) & 1)) {
         int e = (dg < 0 ? -dg : dg) - 1;
-        const int32_t *src = tab + ((size_t)(j * SE + e) * 27) * TPB + tid;
-        Jac q;
-#pragma unroll
-        for (int t = 0; t < NL; t++) { q.X.v[t] = src[t * TPB]; q.Y.v[t] = src[(NL + t) * TPB]; q.Z.v[t] = src[(2 * NL + t) * TPB]; }
-        if (dg < 0) q.Y = neg(q.Y);
-        acc = jac_add(acc, q);
+        const int32_t *src = slot(j, e);
+        if constexpr (NP >= 2) {
+          Aff q;
+          q.x = ld(src, 0);
+          q.y = ld(src, NL);
+          if (dg < 0) q.y = neg(q.y);
+          acc = jac_madd(acc, q);
+        } else {
+          Jac q;
+          q.X = ld(src, 0); q.Y = ld(src, NL); q.Z = ld(src, 2 * NL);
+          if (dg < 0) q.Y = neg(q.Y);
+          acc = jac_add(acc, q);
+        }
       }
     }
   }
@@ -99,7 +143,7 @@ __global__ void __launch_bounds__(TPB) k_straus(StrausArgs a, JacRaw *out, size_
 }
 size_t straus_scratch_bytes(int np, size_t n) {
   const size_t tpb = 64;
-  return ((n + tpb - 1) / tpb) * (size_t)np * SE * 27 * tpb * 4;
+  return ((n + tpb - 1) / tpb) * (size_t)np * SE * STE * tpb * 4;
 }
 void straus(hipStream_t st, int np, const StrausArgs &a, JacRaw *out, size_t n, void *scratch) {
   if (!n) return;
