@@ -30,12 +30,12 @@ TRAFFIC_BYTES_PER_LAUNCH = {
     # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 16 tables (profiles/r01_pmc_*.csv).
     # k_verify_msm: fetches = 1024 x 2080 random 64-byte rows of the 4.5 GB c = 16 generator table (136 MB of
     # gathers that replace 16 doublings each) + the proof points; writes = the per-lane Straus window tables
-    "verify_msm": int((2 * 199621.2 + 19778.2) * 1024),
-    "verify_scalars": int((2 * 5402.1 + 9601.4) * 1024),
+    "verify_msm": int((2 * 160901.6 + 35644.7) * 1024),
+    "verify_scalars": int((2 * 5401.9 + 9601.6) * 1024),
 }
 # VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_msm<4,16,16> 2.28e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
-VALU_WAVE_INSTR_PER_STEP_1024 = 2.28e8 + 2.08e7 + 4.64e6 + 1.59e6
+# k_verify_msm<4,16,16> 2.23e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 2.23e8 + 2.08e7 + 4.64e6 + 1.59e6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
