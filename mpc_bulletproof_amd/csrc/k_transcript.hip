@@ -168,6 +168,7 @@ __constant__ Label TR_LABELS[LB_COUNT] = {
 __global__ void __launch_bounds__(64) k_verify_transcript(size_t nb, size_t nvar, size_t nch, const TrStep *steps, int nsteps,
                                                           const Words8 *init_state, const Words8 *points, const Words8 *scalars,
                                                           Words8 *challenges, int32_t *tr_bad) {
+  __builtin_amdgcn_s_setprio(3);   // serial hash chain at the head of every batch's dependency chain (see k_vs_prep)
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb) return;
   const Words8 *pt = points + p * nvar * 2;
