@@ -69,7 +69,17 @@ def _gen_workload(path, nb, seed0):
     G, H, B = (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * 64)()
     assert host.bph_gens(ord("G"), 0, C.c_size_t(N_BITS), G) == 0 and host.bph_gens(ord("H"), 0, C.c_size_t(N_BITS), H) == 0
     host.bph_generator(B)
-    wl = {"proofs": bytes(proofs)[:nb * pl], "proof_len": pl, "commitments": bytes(coms), "points": bytes(pts),
+    # the same proofs in the reference's wire format (R1CSProof::to_bytes) + compressed commitments
+    wire, wl_len = (C.c_uint8 * 4096)(), C.c_size_t(0)
+    wires = []
+    for i in range(nb):
+        one = (C.c_uint8 * pl).from_buffer_copy(bytes(proofs)[i * pl:(i + 1) * pl])
+        assert host.bph_proof_flat_to_wire(one, C.c_size_t(pl), wire, C.byref(wl_len)) == 0
+        wires.append(bytes(wire)[:wl_len.value])
+    ccom = (C.c_uint8 * (nb * 32))()
+    assert host.bph_compress_points(coms, C.c_size_t(nb), ccom) == 0
+    wl = {"wire_proofs": b"".join(wires), "wire_len": len(wires[0]), "wire_commitments": bytes(ccom),
+          "proofs": bytes(proofs)[:nb * pl], "proof_len": pl, "commitments": bytes(coms), "points": bytes(pts),
           "scalars": bytes(sc), "challenges": bytes(ch), "init_state": bytes(init), "dims": (n1, n - n1, k, m),
           "csr": (list(rp)[:q + 1], list(kind)[:nnz], list(idx)[:nnz], bytes(coeff)[:32 * nnz]),
           "G": bytes(G), "H": bytes(H), "B": bytes(B)}
@@ -253,6 +263,35 @@ def main():
               "note": "whole Verifier::verify incl. the transcript replay (keccak256 chain, hash_to_scalar) on the GPU; "
                       "per-proof accept bits"}
 
+    # ---- secondary: the same proofs taken in the reference's WIRE format (SURVEY 8f N3 + N1): unpack, decompress the
+    # 25 points of every proof (a square root in F_p each), transcript, verification -- all on the device
+    wire = None
+    if not a.no_combined:
+        d_wp, d_wc = gpu.to_device(wl["wire_proofs"]), gpu.to_device(wl["wire_commitments"])
+
+        def wstep(i):
+            j = i % len(ctxs)
+            ctxs[j].r1cs_verify_batch_wire_dev(gens, circ, nb, n1, wl["wire_len"], d_wp, d_wc, d_init, d_oks[j])
+
+        for i in range(len(ctxs)):
+            wstep(i)
+        sync_all()
+        for c, d in zip(ctxs, d_oks):
+            assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            wstep(i)
+        sync_all()
+        fence()
+        wdt = time.perf_counter() - t0
+        if world > 1:
+            from mpc_bulletproof_amd import sharding
+            wdt = sharding.max_over_ranks(wdt)
+        wire = {"value": world * nb * a.steps / wdt, "unit": "verifications/s", "ms_per_step": wdt / a.steps * 1e3,
+                "note": f"from {wl['wire_len']}-byte wire-format proofs + 32-byte compressed commitments: R1CSProof::from_bytes, point "
+                        "decompression, transcript replay and verification on the GPU; per-proof accept bits"}
+
     # ---- secondary: combined batch check (sum_p rho_p * check_p, one point per GPU; RCCL all-gather of
     # the 64-byte partials + local add).  Not the headline (the reference verifies proof by proof).
     comb = None
@@ -358,6 +397,7 @@ def main():
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
             "with_device_transcript": fs,
+            "from_wire_format": wire,
             "combined_batch_check": comb,
             "r1cs_prove": prove,
         }

@@ -233,6 +233,20 @@ int bpgpu_r1cs_verify_batch_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
                                    size_t n1, size_t k, const void *init_states_dev, const void *points_dev,
                                    const void *scalars_dev, void *ok_dev, void *mega_dev, void *challenges_out_dev);
 
+/* The whole of Verifier::verify from the reference's WIRE format, on the device: R1CSProof::from_bytes
+ * (r1cs/proof.rs:128-207: version byte, 8 or 11 compressed points, 3 big-endian scalars, k (L, R) pairs, a, b),
+ * point decompression, the transcript replay and the verification of bpgpu_r1cs_verify_batch_fs, for nb proofs of
+ * one circuit without randomized constraints that all have the same length (the length fixes version and k).
+ * proofs: nb x proof_len B; commitments: nb x m x 32 B compressed (as a node receives them); init_states: nb x 32 B.
+ * ok[p] = 1 iff proof p decodes (otherwise the reference returns FormatError) and verifies.  BPGPU_E_LEN when
+ * proof_len is not a valid proof size. */
+int bpgpu_r1cs_verify_batch_wire(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                 size_t proof_len, const uint8_t *proofs, const uint8_t *commitments,
+                                 const uint8_t *init_states, int32_t *ok);
+int bpgpu_r1cs_verify_batch_wire_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                     size_t proof_len, const void *proofs_dev, const void *commitments_dev,
+                                     const void *init_states_dev, void *ok_dev);
+
 /* Combined batch check (NOT a reference API -- the reference verifies proof by proof; this is
  * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random
  * weights rho (nb x 32 B, e.g. from a CSPRNG) computes  sum_p rho_p * mega_check_p  as ONE point:

@@ -934,6 +934,73 @@ int bpgpu_r1cs_verify_batch_fs(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
   return BPGPU_OK;
 }
 
+/* ---------------------------------------------------------------- Verifier::verify from wire-format proofs */
+// proof_len -> (two_phase, k): 1 + (11 | 14) * 32 + (2k + 2) * 32; the two families never share a length
+static bool wire_dims(size_t proof_len, int *two_phase, size_t *k) {
+  if (proof_len < 1 + 13 * 32 || (proof_len - 1) % 32) return false;
+  size_t el = (proof_len - 1) / 32;
+  if (el >= 13 && (el - 13) % 2 == 0) { *two_phase = 0; *k = (el - 13) / 2; return *k < 32; }
+  if (el >= 16 && (el - 16) % 2 == 0) { *two_phase = 1; *k = (el - 16) / 2; return *k < 32; }
+  return false;
+}
+static int verify_wire_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                              size_t proof_len, const void *proofs, const void *commitments, const void *init_states,
+                              void *ok) {
+  int two_phase = 0;
+  size_t k = 0;
+  if (!wire_dims(proof_len, &two_phase, &k)) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->sqrt_tab) {
+    void *t = nullptr;
+    if (hipMalloc(&t, sqrt_table_bytes()) != hipSuccess) return BPGPU_E_OOM;
+    sqrt_tables_build(ctx->st, t);
+    ctx->sqrt_tab = t;
+  }
+  const size_t m = c->m, nvar = 11 + m + 2 * k;
+  void *dcomp, *dxy, *dsc, *dfmt;
+  CK(ws_get(ctx, 0, nb * nvar * 32, &dcomp));
+  CK(ws_get(ctx, 1, nb * nvar * 64, &dxy));
+  CK(ws_get(ctx, 2, nb * 5 * 32, &dsc));
+  CK(ws_get(ctx, 15, nb * 4 + nb * nvar * 4, &dfmt));
+  int32_t *fmt_ok = (int32_t *)dfmt, *dec_ok = fmt_ok + nb;
+  wire_unpack(ctx->st, (const uint8_t *)proofs, proof_len, (const uint8_t *)commitments, nb, m, k, two_phase,
+              (Words8 *)dcomp, (Words8 *)dsc, fmt_ok);
+  points_decompress(ctx->st, (const Words8 *)dcomp, (Words8 *)dxy, dec_ok, nb * nvar, ctx->sqrt_tab);
+  // undecodable points come out as the identity: the transcript / MSM run on them, the verdict is forced to 0 below
+  CK(verify_fs_locked(ctx, g, c, nb, n1, k, init_states, dxy, dsc, ok, nullptr, nullptr));
+  wire_and_ok(ctx->st, (int32_t *)ok, fmt_ok, dec_ok, nb, nvar);
+  return launch_ok(ctx);
+}
+int bpgpu_r1cs_verify_batch_wire_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                     size_t proof_len, const void *proofs_dev, const void *commitments_dev,
+                                     const void *init_states_dev, void *ok_dev) {
+  if (!ctx || !g || !c || (nb && (!proofs_dev || !init_states_dev || !ok_dev || (c->m && !commitments_dev)))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_wire_locked(ctx, g, c, nb, n1, proof_len, proofs_dev, commitments_dev, init_states_dev, ok_dev);
+}
+int bpgpu_r1cs_verify_batch_wire(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                 size_t proof_len, const uint8_t *proofs, const uint8_t *commitments,
+                                 const uint8_t *init_states, int32_t *ok) {
+  if (!ctx || !g || !c || (nb && (!proofs || !init_states || !ok || (c->m && !commitments)))) return BPGPU_E_ARG;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t m = c->m;
+  void *dP, *dC, *dI, *dok;
+  CK(ws_get(ctx, 3, nb * proof_len + 64, &dP));
+  CK(ws_get(ctx, 4, nb * (m ? m : 1) * 32, &dC));
+  CK(ws_get(ctx, 5, nb * 32, &dI));
+  CK(ws_get(ctx, 16, nb * 4, &dok));
+  CK(h2d(ctx, dP, proofs, nb * proof_len));
+  if (m) CK(h2d(ctx, dC, commitments, nb * m * 32));
+  CK(h2d(ctx, dI, init_states, nb * 32));
+  CK(verify_wire_locked(ctx, g, c, nb, n1, proof_len, dP, dC, dI, dok));
+  CK(d2h(ctx, ok, dok, nb * 4));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
 /* ---------------------------------------------------------------- combined batch check
  * sum_p rho_p * mega_check_p as ONE point: the generator terms collapse to a single fixed-base MSM with
  * scalars sum_p rho_p * s_{p,g}; the proof-specific points go through one bucket-method MSM of

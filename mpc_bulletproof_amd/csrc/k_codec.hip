@@ -84,6 +84,71 @@ __global__ void __launch_bounds__(256) k_points_compress(const Words8 *xy, Words
   for (int j = 0; j < 8; j++) out[i].w[j] = x[j];
 }
 
+// R1CSProof::from_bytes (r1cs/proof.rs:128-207) for nb proofs of one length: one lane per (proof, point slot).
+// Writes the compressed points in the operand order of bpgpu_r1cs_verify_batch
+// (A_I1 A_O1 S1 A_I2 A_O2 S2 | V_0..V_{m-1} | T_1 T_3 T_4 T_5 T_6 | L_0.. | R_0..), the five scalars as canonical
+// little-endian words (big-endian on the wire, read modulo n: from_be_bytes_mod_order), fmt_ok[p] = version byte as
+// the length implies.
+__global__ void __launch_bounds__(256) k_wire_unpack(const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                                     size_t nb, size_t m, size_t k, int two_phase, Words8 *comp,
+                                                     Words8 *scalars, int32_t *fmt_ok) {
+  const size_t nvar = 11 + m + 2 * k, per = nvar + 5;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * per) return;
+  const size_t p = t / per, s = t - p * per;
+  const uint8_t *pr = proofs + p * proof_len;
+  const size_t head = two_phase ? 11 : 8;   // compressed points before the three scalars
+  if (s == 0) fmt_ok[p] = pr[0] == (two_phase ? 1 : 0) ? 1 : 0;
+  const uint8_t *body = pr + 1;
+  if (s < nvar) {
+    const uint8_t *src = nullptr;
+    bool identity = false;
+    if (s < 3) src = body + 32 * s;
+    else if (s < 6) { if (two_phase) src = body + 32 * s; else identity = true; }
+    else if (s < 6 + m) src = commitments + (p * m + (s - 6)) * 32;
+    else if (s < 11 + m) src = body + 32 * ((two_phase ? 6 : 3) + (s - 6 - m));
+    else if (s < 11 + m + k) src = body + 32 * (head + 3 + 2 * (s - 11 - m));            // L_i
+    else src = body + 32 * (head + 3 + 2 * (s - 11 - m - k) + 1);                        // R_i
+    uint32_t w[8];
+    for (int j = 0; j < 8; j++) {
+      w[j] = identity ? 0u : ((uint32_t)src[4 * j] | (uint32_t)src[4 * j + 1] << 8 | (uint32_t)src[4 * j + 2] << 16 | (uint32_t)src[4 * j + 3] << 24);
+    }
+    if (identity) w[7] = 0x40000000u;
+    for (int j = 0; j < 8; j++) comp[p * nvar + s].w[j] = w[j];
+  } else {
+    const size_t q = s - nvar;   // t_x t_x_blinding e_blinding a b
+    const uint8_t *src = q < 3 ? body + 32 * (head + q) : body + 32 * (head + 3 + 2 * k + (q - 3));
+    uint32_t w[8];
+    for (int j = 0; j < 8; j++) {   // big-endian bytes -> little-endian words
+      const uint8_t *b = src + 28 - 4 * j;
+      w[j] = (uint32_t)b[3] | (uint32_t)b[2] << 8 | (uint32_t)b[1] << 16 | (uint32_t)b[0] << 24;
+    }
+    // any 256-bit value modulo n: one Montgomery multiplication by R^2 brings it into range
+    uint32_t o[8];
+    pack(o, from_mont(to_mont(unpack<FN>(w))));
+    for (int j = 0; j < 8; j++) scalars[p * 5 + q].w[j] = o[j];
+  }
+}
+// ok[p] &= fmt_ok[p] & all(dec_ok[p][*])
+__global__ void __launch_bounds__(256) k_wire_and_ok(int32_t *ok, const int32_t *fmt_ok, const int32_t *dec_ok, size_t nb, size_t nvar) {
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nb) return;
+  int good = fmt_ok[p];
+  for (size_t v = 0; v < nvar; v++) good &= dec_ok[p * nvar + v];
+  if (!good) ok[p] = 0;
+}
+void wire_unpack(hipStream_t st, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments, size_t nb, size_t m,
+                 size_t k, int two_phase, Words8 *comp, Words8 *scalars, int32_t *fmt_ok) {
+  size_t tot = nb * (16 + m + 2 * k);
+  if (!tot) return;
+  hipLaunchKernelGGL(k_wire_unpack, dim3((tot + 255) / 256), dim3(256), 0, st, proofs, proof_len, commitments, nb, m, k,
+                     two_phase, comp, scalars, fmt_ok);
+}
+void wire_and_ok(hipStream_t st, int32_t *ok, const int32_t *fmt_ok, const int32_t *dec_ok, size_t nb, size_t nvar) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_wire_and_ok, dim3((nb + 255) / 256), dim3(256), 0, st, ok, fmt_ok, dec_ok, nb, nvar);
+}
+
 size_t sqrt_table_bytes() { return (size_t)SQ_DIG * 256 * NL * 4 + 65536; }
 void sqrt_tables_build(hipStream_t st, void *tab) {
   hipMemsetAsync((uint8_t *)tab + (size_t)SQ_DIG * 256 * NL * 4, 0, 65536, st);

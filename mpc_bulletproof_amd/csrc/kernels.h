@@ -163,5 +163,9 @@ size_t sqrt_table_bytes();
 void sqrt_tables_build(hipStream_t st, void *tab /* sqrt_table_bytes() */);
 void points_decompress(hipStream_t st, const Words8 *in, Words8 *out_xy, int32_t *ok, size_t n, const void *tab);
 void points_compress(hipStream_t st, const Words8 *xy, Words8 *out, size_t n);
+// wire-format proofs -> operands of the verification pipeline (k_codec.hip)
+void wire_unpack(hipStream_t st, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments, size_t nb, size_t m,
+                 size_t k, int two_phase, Words8 *comp, Words8 *scalars, int32_t *fmt_ok);
+void wire_and_ok(hipStream_t st, int32_t *ok, const int32_t *fmt_ok, const int32_t *dec_ok, size_t nb, size_t nvar);
 
 }  // namespace bpk

@@ -12,6 +12,12 @@
 using namespace mpc_bulletproof;
 using namespace mpc_bulletproof::r1cs;
 
+static std::vector<StarkPoint> unpack_points_pub(const uint8_t *b, size_t n) {
+  std::vector<StarkPoint> o(n);
+  for (size_t i = 0; i < n; i++) memcpy(o[i].xy.data(), b + 64 * i, 64);
+  return o;
+}
+
 enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4 };
 
 static int map_error(const R1CSException &e) {
@@ -295,6 +301,14 @@ int bph_proof_wire_to_flat(const uint8_t *wire, size_t wire_len, uint8_t *flat_o
     auto f = p.to_flat_bytes();
     memcpy(flat_out, f.data(), f.size());
     *flat_len = f.size();
+    return 0;
+  })
+}
+
+int bph_compress_points(const uint8_t *xy, size_t n, uint8_t *out) {
+  GUARD({
+    auto c = compress_points(unpack_points_pub(xy, n));
+    memcpy(out, c.data(), c.size());
     return 0;
   })
 }

@@ -15,6 +15,7 @@ SYMBOLS = [
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
+    "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev",
 ]
 
 
@@ -313,6 +314,19 @@ class BpGpu:
     def r1cs_verify_batch_fs_dev(self, gens, circuit, nb, n1, k, d_init, d_points, d_scalars, d_ok, d_mega=None, d_ch=None):
         self._ck(_lib.bpgpu_r1cs_verify_batch_fs_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                      d_init, d_points, d_scalars, d_ok, d_mega, d_ch))
+
+    def r1cs_verify_batch_wire(self, gens, circuit, nb, n1, proof_len, proofs, commitments, init_states):
+        """wire-format proofs (R1CSProof::to_bytes) + compressed commitments -> accept bits, all on the device"""
+        if len(proofs) != nb * proof_len or len(init_states) != 32 * nb:
+            raise BpGpuError(E_LEN, "r1cs_verify_batch_wire: length mismatch")
+        ok = (C.c_int32 * max(nb, 1))()
+        self._ck(_lib.bpgpu_r1cs_verify_batch_wire(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(proof_len),
+                                                   _buf(proofs), _buf(commitments), _buf(init_states), ok))
+        return list(ok)[:nb]
+
+    def r1cs_verify_batch_wire_dev(self, gens, circuit, nb, n1, proof_len, d_proofs, d_commitments, d_init, d_ok):
+        self._ck(_lib.bpgpu_r1cs_verify_batch_wire_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1),
+                                                       C.c_size_t(proof_len), d_proofs, d_commitments, d_init, d_ok))
 
     def r1cs_verify_combined(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, rho):
         nvar = 11 + m + 2 * k

@@ -703,3 +703,55 @@ def test_proof_wire_format_golden(golden_codec):
                  wire[:1] + H(golden_codec["invalid"][0]) + wire[33:]]
     for bad in bad_cases:
         assert host.bph_proof_wire_to_flat(o._buf(bad if bad else b"\0"), C.c_size_t(len(bad)), out, C.byref(ln)) == -3, bad[:4]
+
+
+def test_verify_batch_from_wire_format(gpu, golden_codec):
+    """bpgpu_r1cs_verify_batch_wire: reference wire-format proofs + compressed commitments -> accept bits entirely on
+    the device (unpack, point decompression, transcript, verification).  70 proofs of the 8-bit gadget: valid ones
+    accepted, a tampered scalar rejected by the verification, an undecodable point / a wrong version byte rejected
+    as the reference's FormatError would."""
+    sys_path_oracle()
+    import pymodel as pm
+    import mpc_bulletproof_amd as m
+
+    def flat_to_dict(b):
+        k, pts11, sc3, L, R, ab = bh.parse_flat_proof(b)
+        names = ("A_I1", "A_O1", "S1", "A_I2", "A_O2", "S2", "T_1", "T_3", "T_4", "T_5", "T_6")
+        p = {nm: pm.b2p(pts11[64 * i:64 * i + 64]) for i, nm in enumerate(names)}
+        for i, nm in enumerate(("t_x", "t_x_blinding", "e_blinding")):
+            p[nm] = pm.b2s(sc3[32 * i:32 * i + 32])
+        p["L_vec"] = [pm.b2p(L[64 * i:64 * i + 64]) for i in range(k)]
+        p["R_vec"] = [pm.b2p(R[64 * i:64 * i + 64]) for i in range(k)]
+        p["a"], p["b"] = pm.b2s(ab[:32]), pm.b2s(ab[32:])
+        return p
+
+    nb, n_bits = 70, 8
+    recs, cap = bh.make_range_batch(n_bits, nb, tamper={5})
+    s0 = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
+    rp, kind, idx, coeff = s0.csr()
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        wires = [pm.r1cs_proof_to_bytes(flat_to_dict(proof)) for proof, _ in recs]
+        coms = [pm.point_compress(pm.b2p(com)) for _, com in recs]
+        plen = len(wires[0])
+        assert plen == 1 + 11 * 32 + (2 * s0.k + 2) * 32 and all(len(w) == plen for w in wires)
+        bad_point = bytearray(wires[9])
+        bad_point[1 + 32 * 4:1 + 32 * 5] = H(golden_codec["invalid"][0])       # T_3 := an x off the curve
+        wires[9] = bytes(bad_point)
+        wires[11] = bytes([1]) + wires[11][1:]                                 # version byte contradicts the length
+        big = bytearray(wires[20])                                             # t_x + n encodes the same scalar
+        off = 1 + 8 * 32
+        big[off:off + 32] = (int.from_bytes(big[off:off + 32], "big") + pm.N).to_bytes(32, "big")
+        wires[20] = bytes(big)
+        init = pm.Transcript(b"RangeProofTest").state * nb
+        ok = gpu.r1cs_verify_batch_wire(g, circ, nb, s0.n1, plen, b"".join(wires), b"".join(coms), init)
+        want = [1] * nb
+        want[5] = want[9] = want[11] = 0
+        assert ok == want
+        with pytest.raises(m.BpGpuError) as e:
+            gpu.r1cs_verify_batch_wire(g, circ, nb, s0.n1, plen - 32, b"".join(w[:-32] for w in wires), b"".join(coms), init)
+        assert e.value.code == m.lib.E_LEN
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
