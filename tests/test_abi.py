@@ -41,3 +41,19 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".hip", ".cuh", ".h", ".cpp", ".hpp")) or f == "Makefile":
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/ (tests/)", ""), os.path.join(dp, f)
+
+
+def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
+    """bench.py may touch oracle/ (through tests/oracle_lib.py) only inside its cpu_baseline worker; the workload,
+    the timed GPU legs and the secondary measurements must come from the product path."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    offenders = []
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef):
+            body = ast.get_source_segment(src, node)
+            if ("oracle_lib" in body or "pymodel" in body or "liboracle" in body) and node.name != "_cpu_verify_chunk":
+                offenders.append(node.name)
+    assert offenders == [], offenders
+    assert "import oracle_lib" not in src.split("def _cpu_verify_chunk")[0]
