@@ -144,6 +144,13 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
 int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *w,
                          const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *a, const uint8_t *b,
                          bpgpu_ipp **out);
+/* All remaining rounds of a session with the transcript on the DEVICE (SURVEY 8f N1 applied to the prover): per round
+ * L, R, transcript.append_point("L" / "R"), challenge_scalar("u") (inner_product_proof.rs:119-123, 177-181), u^-1 and
+ * the fold, back to back on the stream -- no host round trip per round.  states_in: the provers' 32-byte hash-chain
+ * states after innerproduct_domain_sep (:72); L_out / R_out: nb x k x 64 B (proof-major); a_out, b_out: nb x 32 B;
+ * states_out (optional): the chain states afterwards.  The hash chain is the build's stand-in for merlin's. */
+int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uint8_t *L_out, uint8_t *R_out,
+                     uint8_t *a_out, uint8_t *b_out, uint8_t *states_out);
 void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s);
 size_t bpgpu_ipp_len(const bpgpu_ipp *s);
 int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R);

@@ -1190,12 +1190,9 @@ void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s) {
 }
 size_t bpgpu_ipp_len(const bpgpu_ipp *s) { return s ? s->n : 0; }
 
-/* c_L, c_R and the two MSMs of one round -- inner_product_proof.rs:87-114 (first) / :156-172 */
-int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
-  if (!ctx || !s || !L || !R) return BPGPU_E_ARG;
-  if (s->n < 2) return BPGPU_E_LEN;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCK(ctx, hipSetDevice(ctx->device));
+/* c_L, c_R and the two MSMs of one round -- inner_product_proof.rs:87-114 (first) / :156-172.
+ * Device part: out_xy[2p], out_xy[2p + 1] = L_p, R_p in boundary form (2 Words8 per point). */
+static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
   hipStream_t st = ctx->st;
   const size_t nb = s->nb, n = s->n, h = n / 2, seg = 2 * h + 1;
   Words8 *a = s->a[s->cur], *b = s->b[s->cur];
@@ -1204,13 +1201,8 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
     ipp_gens_scalars(st, nb, s->n0, n, a, b, s->cG, s->cH, s->cLR, s->w, s->msc);
     CK(msm_gens_dev(ctx, s->gens, nb * 2, s->n0, (const uint32_t *)s->msc, s->sums, st));
-    jac_to_boundary(st, s->sums, s->out_xy, nb * 2);
-    CK(launch_ok(ctx));
-    std::vector<uint8_t> tmp(nb * 128);
-    CK(d2h(ctx, tmp.data(), s->out_xy, nb * 128));
-    HIPCK(ctx, hipStreamSynchronize(st));
-    for (size_t p = 0; p < nb; p++) { memcpy(L + 64 * p, &tmp[128 * p], 64); memcpy(R + 64 * p, &tmp[128 * p + 64], 64); }
-    return BPGPU_OK;
+    jac_to_boundary(st, s->sums, out_xy, nb * 2);
+    return launch_ok(ctx);
   }
   const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
   const bool shared = s->first && s->shared_gens;
@@ -1252,37 +1244,33 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
     straus(st, 1, x, s->res, nb * 2 * seg, dstr);
     segmented_sum(st, s->res, s->sums, nb * 2, seg);
   }
-  jac_to_boundary(st, s->sums, s->out_xy, nb * 2);
-  CK(launch_ok(ctx));
+  jac_to_boundary(st, s->sums, out_xy, nb * 2);
+  return launch_ok(ctx);
+}
+int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
+  if (!ctx || !s || !L || !R) return BPGPU_E_ARG;
+  if (s->n < 2) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = s->nb;
+  CK(ipp_round_dev(ctx, s, s->out_xy));
   std::vector<uint8_t> tmp(nb * 128);
   CK(d2h(ctx, tmp.data(), s->out_xy, nb * 128));
-  HIPCK(ctx, hipStreamSynchronize(st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
   for (size_t p = 0; p < nb; p++) { memcpy(L + 64 * p, &tmp[128 * p], 64); memcpy(R + 64 * p, &tmp[128 * p + 64], 64); }
   return BPGPU_OK;
 }
 /* fold_witness with the round's challenges -- inner_product_proof.rs:125-146 (first) / :183-184 */
-int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t *u_inv) {
-  if (!ctx || !s || !u || !u_inv) return BPGPU_E_ARG;
-  if (s->n < 2) return BPGPU_E_LEN;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCK(ctx, hipSetDevice(ctx->device));
+// device part of the fold: du / dui = the round's challenges and their inverses (nb each) already in HBM
+static int ipp_fold_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *du, Words8 *dui) {
   hipStream_t st = ctx->st;
   const size_t nb = s->nb, n = s->n, h = n / 2;
   const int cur = s->cur, nxt = cur ^ 1;
-  Words8 *du = s->uu, *dui = s->uu + nb;
-  CK(flag_reset(ctx));
-  CK(h2d(ctx, du, u, nb * 32));
-  CK(h2d(ctx, dui, u_inv, nb * 32));
-  scalars_check(st, s->uu, 2 * nb, ctx->d_flag);
   if (s->gens) {
     ipp_gens_fold(st, nb, s->n0, n, du, dui, s->cG, s->cH);
     fold_scalars_batched(st, nb, h, du, dui, s->a[cur], s->b[cur], s->a[nxt], s->b[nxt]);
-    CK(launch_ok(ctx));
-    int bad = 0;
-    CK(flag_read(ctx, &bad));
-    if (bad) return BPGPU_E_ARG;
     s->cur = nxt; s->n = h; s->first = false;
-    return BPGPU_OK;
+    return launch_ok(ctx);
   }
   const AffDev *G = s->G[cur], *H = s->H[cur];
   const bool shared = s->first && s->shared_gens;
@@ -1311,11 +1299,62 @@ int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t
   batch_normalize(st, fres, s->G[nxt], nb * h, 8);
   batch_normalize(st, fres + nb * h, s->H[nxt], nb * h, 8);
   fold_scalars_batched(st, nb, h, du, dui, s->a[cur], s->b[cur], s->a[nxt], s->b[nxt]);
-  CK(launch_ok(ctx));
+  s->cur = nxt; s->n = h; s->first = false;
+  return launch_ok(ctx);
+}
+int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t *u_inv) {
+  if (!ctx || !s || !u || !u_inv) return BPGPU_E_ARG;
+  if (s->n < 2) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = s->nb;
+  Words8 *du = s->uu, *dui = s->uu + nb;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, du, u, nb * 32));
+  CK(h2d(ctx, dui, u_inv, nb * 32));
+  scalars_check(ctx->st, s->uu, 2 * nb, ctx->d_flag);
   int bad = 0;
   CK(flag_read(ctx, &bad));
-  if (bad) return BPGPU_E_ARG;
-  s->cur = nxt; s->n = h; s->first = false;
+  if (bad) return BPGPU_E_ARG;        // checked before the session state advances
+  return ipp_fold_dev(ctx, s, du, dui);
+}
+/* InnerProductProof::create's whole round loop on the device (SURVEY 8f N1 applied to the prover): per round the
+ * L, R MSMs, transcript.append_point("L"), ("R"), challenge_scalar("u") (inner_product_proof.rs:119-123,177-181)
+ * with the keccak hash chain in a kernel, u^-1 and the fold -- no host round trip between rounds. */
+int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uint8_t *L_out, uint8_t *R_out,
+                     uint8_t *a_out, uint8_t *b_out, uint8_t *states_out) {
+  if (!ctx || !s || !states_in || !a_out || !b_out) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = s->nb;
+  size_t k = 0;
+  for (size_t t = s->n; t > 1; t >>= 1) k++;
+  if (k && (!L_out || !R_out)) return BPGPU_E_ARG;
+  void *dstates, *dlr, *dzero;
+  CK(ws_get(ctx, 16, nb * 32, &dstates));
+  CK(ws_get(ctx, 17, (k ? k : 1) * nb * 128, &dlr));
+  CK(ws_get(ctx, 18, 4, &dzero));
+  CK(h2d(ctx, dstates, states_in, nb * 32));
+  Words8 *du = s->uu, *dui = s->uu + nb;
+  for (size_t r = 0; r < k; r++) {
+    Words8 *lr = (Words8 *)dlr + r * nb * 4;             // 2 points x 2 Words8 per proof
+    CK(ipp_round_dev(ctx, s, lr));
+    ipp_round_challenge(ctx->st, nb, (uint64_t *)dstates, lr, du);
+    HIPCK(ctx, hipMemcpyAsync(dui, du, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
+    batch_inverse(ctx->st, dui, nb, (int *)dzero);       // challenges are non-zero up to 2^-252
+    CK(ipp_fold_dev(ctx, s, du, dui));
+  }
+  std::vector<uint8_t> tmp(k * nb * 128);
+  if (k) CK(d2h(ctx, tmp.data(), dlr, k * nb * 128));
+  CK(d2h(ctx, a_out, s->a[s->cur], nb * 32));
+  CK(d2h(ctx, b_out, s->b[s->cur], nb * 32));
+  if (states_out) CK(d2h(ctx, states_out, dstates, nb * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  for (size_t p = 0; p < nb; p++)       // proof-major outputs: L_out[p][r], R_out[p][r]
+    for (size_t r = 0; r < k; r++) {
+      memcpy(L_out + (p * k + r) * 64, &tmp[(r * nb + p) * 128], 64);
+      memcpy(R_out + (p * k + r) * 64, &tmp[(r * nb + p) * 128 + 64], 64);
+    }
   return BPGPU_OK;
 }
 /* final a, b -- inner_product_proof.rs:187-192 */

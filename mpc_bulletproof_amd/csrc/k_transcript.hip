@@ -260,4 +260,28 @@ void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n) {
   if (n) hipLaunchKernelGGL(k_and_not, dim3((n + 255) / 256), dim3(256), 0, st, ok, bad, n);
 }
 
+// One IPP prover round of the transcript (inner_product_proof.rs:119-123 / :177-181) for nb provers, one lane each:
+// append_point("L", L_p), append_point("R", R_p), u_p = challenge_scalar("u").  states: 4 x u64 per prover, updated.
+__global__ void __launch_bounds__(64) k_ipp_round_challenge(size_t nb, uint64_t *states, const Words8 *lr, Words8 *u_out) {
+  __builtin_amdgcn_s_setprio(3);
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nb) return;
+  uint64_t st[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) st[i] = states[p * 4 + i];
+  uint64_t tail[9];
+  tail[0] = 64;
+  load64(lr + p * 4, tail + 1);
+  chain_hash<9>(st, 0x00, TR_LABELS[LB_L], tail);
+  load64(lr + p * 4 + 2, tail + 1);
+  chain_hash<9>(st, 0x00, TR_LABELS[LB_R], tail);
+  tr_challenge_scalar(st, TR_LABELS[LB_u], &u_out[p]);
+#pragma unroll
+  for (int i = 0; i < 4; i++) states[p * 4 + i] = st[i];
+}
+void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr, Words8 *u_out) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_ipp_round_challenge, dim3((nb + 63) / 64), dim3(64), 0, st, nb, states, lr, u_out);
+}
+
 }  // namespace bpk

@@ -158,6 +158,9 @@ void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, co
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad);
 
+// one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
+void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);
+
 // ---- wire codec of points (k_codec.hip): 32-byte compressed <-> 64-byte affine boundary form ------
 size_t sqrt_table_bytes();
 void sqrt_tables_build(hipStream_t st, void *tab /* sqrt_table_bytes() */);

@@ -6,6 +6,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 
 #include "gadgets.hpp"
 
@@ -19,6 +22,18 @@ static std::vector<StarkPoint> unpack_points_pub(const uint8_t *b, size_t n) {
 }
 
 enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4 };
+
+// BulletproofGens are created once and reused by a real caller (generators.rs:182); the flat batch entry points
+// keep one instance per capacity so that repeated calls do not rebuild generators and device tables
+static const BulletproofGens &cached_gens(size_t capacity) {
+  static std::mutex mu;
+  // never destroyed: at process exit the HIP runtime may already be gone when static destructors run
+  static auto *cache = new std::map<size_t, BulletproofGens *>();
+  std::lock_guard<std::mutex> lk(mu);
+  BulletproofGens *&slot = (*cache)[capacity];
+  if (!slot) slot = new BulletproofGens(capacity, 1);
+  return *slot;
+}
 
 static int map_error(const R1CSException &e) {
   switch (e.e) {
@@ -143,7 +158,7 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
       T0 = t;
     };
     PedersenGens pc_gens;
-    BulletproofGens bp_gens(gens_capacity, 1);
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
     lap("generators");
     std::vector<std::unique_ptr<Transcript>> trs;
     std::vector<std::unique_ptr<Prover>> provers;
@@ -251,7 +266,7 @@ int bph_range_verify_inputs(size_t nb, size_t n_bits, const uint8_t *label, size
                             uint32_t *row_ptr, uint32_t *kind, uint32_t *idx, uint8_t *coeff) {
   GUARD({
     PedersenGens pc_gens;
-    BulletproofGens bp_gens(gens_capacity, 1);
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
     std::vector<Verifier::BatchInputs> ins(nb);
     std::vector<uint32_t> rp, kd, ix;
     std::vector<uint8_t> co;

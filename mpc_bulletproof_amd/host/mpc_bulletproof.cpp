@@ -378,6 +378,10 @@ std::vector<StarkPoint> BulletproofGens::Share::H(size_t n) const {
   return std::vector<StarkPoint>(v.begin(), v.begin() + std::min(n, v.size()));
 }
 bpgpu_gens *BulletproofGens::device_tables(const PedersenGens &pc, int window_bits) const {
+  if (window_bits == 0) {
+    if (const char *e = getenv("BPH_WINDOW_BITS")) window_bits = atoi(e);
+    if (window_bits == 0) window_bits = gens_capacity <= 64 ? 16 : (gens_capacity <= 1024 ? 12 : 8);
+  }
   std::array<uint8_t, 128> key;
   memcpy(key.data(), pc.B.xy.data(), 64);
   memcpy(key.data() + 64, pc.B_blinding.xy.data(), 64);
@@ -1031,6 +1035,27 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   }
   lap("prove: ipp_begin");
   try {
+    if (!getenv("BPH_HOST_IPP_TRANSCRIPT")) {
+      // the k rounds back to back on the device, hash chain included (bpgpu_ipp_run_fs); the host transcripts are
+      // advanced to the same state afterwards
+      size_t k = 0;
+      for (size_t t = padded_n; t > 1; t >>= 1) k++;
+      std::vector<uint8_t> st_in(nb * 32), st_out(nb * 32), L(nb * k * 64 + 1), R(nb * k * 64 + 1), a(nb * 32), b(nb * 32);
+      for (size_t p = 0; p < nb; p++) memcpy(&st_in[32 * p], cs[p]->tr.state(), 32);
+      d.check(bpgpu_ipp_run_fs(d.ctx(), ipp, st_in.data(), L.data(), R.data(), a.data(), b.data(), st_out.data()), "bpgpu_ipp_run_fs");
+      for (size_t p = 0; p < nb; p++) {
+        cs[p]->tr.set_state(&st_out[32 * p]);
+        for (size_t r = 0; r < k; r++) {
+          StarkPoint Lp, Rp;
+          memcpy(Lp.xy.data(), &L[(p * k + r) * 64], 64);
+          memcpy(Rp.xy.data(), &R[(p * k + r) * 64], 64);
+          proofs[p].ipp_proof.L_vec.push_back(Lp);
+          proofs[p].ipp_proof.R_vec.push_back(Rp);
+        }
+        proofs[p].ipp_proof.a = Scalar::from_bytes_le(&a[32 * p]);
+        proofs[p].ipp_proof.b = Scalar::from_bytes_le(&b[32 * p]);
+      }
+    } else {
     std::vector<uint8_t> L(nb * 64), R(nb * 64), ub(nb * 32), uib(nb * 32);
     while (bpgpu_ipp_len(ipp) > 1) {
       d.check(bpgpu_ipp_round(d.ctx(), ipp, L.data(), R.data()), "bpgpu_ipp_round");
@@ -1053,6 +1078,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     for (size_t p = 0; p < nb; p++) {
       proofs[p].ipp_proof.a = Scalar::from_bytes_le(&a[32 * p]);
       proofs[p].ipp_proof.b = Scalar::from_bytes_le(&b[32 * p]);
+    }
     }
   } catch (...) {
     bpgpu_ipp_destroy(d.ctx(), ipp);

@@ -7,6 +7,7 @@
 // compiled code); INTEGRATION.md shows the Rust-side binding of the same C ABI.
 #pragma once
 #include <array>
+#include <cstring>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -116,6 +117,7 @@ class Transcript {
   void validate_and_append_point(const std::string &label, const StarkPoint &p);   // throws ProofException(VerificationError)
   Scalar challenge_scalar(const std::string &label);
   const uint8_t *state() const { return state_; }   // the 32-byte hash-chain state (input of the device transcript)
+  void set_state(const uint8_t s[32]) { memcpy(state_, s, 32); }   // resume after a device-side stretch of the chain
  private:
   uint8_t state_[32];
 };
@@ -142,7 +144,9 @@ class BulletproofGens {
   };
   Share share(size_t j) const { return Share{this, j}; }
   // resident fixed-base tables of share 0 for (B, B_blinding) -- built on first use
-  bpgpu_gens *device_tables(const PedersenGens &pc, int window_bits = 8) const;
+  // window_bits 0 = by capacity (BPH_WINDOW_BITS overrides): 16-bit windows up to 64 generators per side (4.5 GB),
+  // 12-bit up to 1024 (5.9 GB), 8-bit beyond (17 GB at 32768)
+  bpgpu_gens *device_tables(const PedersenGens &pc, int window_bits = 0) const;
  private:
   std::vector<std::vector<StarkPoint>> G_vec_, H_vec_;
   mutable bpgpu_gens *tables_ = nullptr;

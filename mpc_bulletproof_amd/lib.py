@@ -11,7 +11,7 @@ SYMBOLS = [
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
-    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
@@ -235,6 +235,13 @@ class BpGpu:
         a, b = _out(32 * nb), _out(32 * nb)
         self._ck(_lib.bpgpu_ipp_finish(self.ctx, s, a, b))
         return bytes(a)[:32 * nb], bytes(b)[:32 * nb]
+
+    def ipp_run_fs(self, s, nb, k, states):
+        """all rounds with the transcript on the device -> (L bytes nb*k*64, R, a, b, states_out)"""
+        L, R = _out(64 * nb * max(k, 1)), _out(64 * nb * max(k, 1))
+        a, b, so = _out(32 * nb), _out(32 * nb), _out(32 * nb)
+        self._ck(_lib.bpgpu_ipp_run_fs(self.ctx, s, _buf(states), L, R, a, b, so))
+        return bytes(L)[:64 * nb * k], bytes(R)[:64 * nb * k], bytes(a)[:32 * nb], bytes(b)[:32 * nb], bytes(so)[:32 * nb]
 
     def ipp_destroy(self, s):
         _lib.bpgpu_ipp_destroy(self.ctx, s)

@@ -755,3 +755,41 @@ def test_verify_batch_from_wire_format(gpu, golden_codec):
     finally:
         gpu.gens_destroy(g)
         gpu.circuit_destroy(circ)
+
+
+@pytest.mark.parametrize("resident", [True, False])
+def test_ipp_rounds_with_device_transcript(gpu, resident):
+    """bpgpu_ipp_run_fs: all rounds of InnerProductProof::create with the hash chain on the device give the oracle's
+    L, R, a, b (and leave the transcripts where the host's would be), over resident generator tables and in the
+    generator-folding mode."""
+    sys_path_oracle()
+    import pymodel as pm
+    nb, n, k = 3, 32, 5
+    Gp, Hp, B = o.gens("G", n), o.gens("H", n), o.generator()
+    a, b = o.random_scalars(61, nb * n), o.random_scalars(62, nb * n)
+    Gf, Hf = o.random_scalars(63, nb * n), o.random_scalars(64, nb * n)
+    w = o.random_scalars(65, nb)
+    Q = b"".join(o.point_mul(w[32 * p:32 * p + 32], B) for p in range(nb))
+    trs = [pm.Transcript(b"innerproducttest") for _ in range(nb)]
+    for t in trs:
+        t.innerproduct_domain_sep(n)
+    states = b"".join(t.state for t in trs)
+    g = gpu.gens_create(Gp, Hp, B, B, 8) if resident else None
+    s = gpu.ipp_begin_gens(g, nb, n, w, Gf, Hf, a, b) if resident else gpu.ipp_begin(nb, n, Q, Gf, Hf, Gp, Hp, True, a, b)
+    try:
+        L, R, aa, bb, st_out = gpu.ipp_run_fs(s, nb, k, states)
+        for p in range(nb):
+            sl = slice(32 * n * p, 32 * n * (p + 1))
+            Lo, Ro, ao, bo, ch = o.ipp_create(b"innerproducttest", n, Q[64 * p:64 * p + 64], Gf[sl], Hf[sl], Gp, Hp, a[sl], b[sl])
+            assert (L[64 * k * p:64 * k * (p + 1)], R[64 * k * p:64 * k * (p + 1)]) == (Lo, Ro)
+            assert (aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (ao, bo)
+            t = trs[p]
+            for r in range(k):
+                t.append_message(b"L", Lo[64 * r:64 * r + 64])
+                t.append_message(b"R", Ro[64 * r:64 * r + 64])
+                assert pm.s2b(t.challenge_scalar(b"u")) == ch[32 * r:32 * r + 32]
+            assert st_out[32 * p:32 * p + 32] == t.state
+    finally:
+        gpu.ipp_destroy(s)
+        if g is not None:
+            gpu.gens_destroy(g)

@@ -35,6 +35,7 @@ def run(nb, seed0=900):
 
 run(2)   # warm-up: generator tables, workspaces
 for nb in (1, 16, 64, 256):
+    run(nb)   # grows the workspaces for this batch size
     dt, vals, proofs, com, L = run(nb)
     print(f"nb={nb:4d}: {dt * 1e3:9.1f} ms  {nb / dt:9.1f} proofs/s  {nb * q / dt / 1e6:8.3f} M constraints/s  ({q} constraints, n={n}, proof {L} B)")
 # parity + CPU baseline on one prover
