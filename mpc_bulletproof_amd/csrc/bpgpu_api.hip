@@ -29,6 +29,7 @@ struct bpgpu_ctx {
   std::string err;
   int *d_flag = nullptr;          // device int: bad-input flag
   void *sqrt_tab = nullptr;       // F_p square-root tables of the point codec (built on first use)
+  struct bpgpu_gens *gen_tab = nullptr;   // 16-bit-window table of the curve generator (bpgpu_generator_mul)
   Slot ws[20];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
@@ -189,6 +190,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   for (auto &s : ctx->ws) if (s.p) hipFree(s.p);
   hipFree(ctx->d_flag);
   hipFree(ctx->sqrt_tab);
+  if (ctx->gen_tab) { hipFree(ctx->gen_tab->points); hipFree(ctx->gen_tab->table); delete ctx->gen_tab; }
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev2);
   if (ctx->st2 != ctx->st) hipStreamDestroy(ctx->st2);
@@ -1501,27 +1503,26 @@ void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s) {
 int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out) {
   if (!ctx || (n && (!scalars || !out))) return BPGPU_E_ARG;
   if (!n) return BPGPU_OK;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  HIPCK(ctx, hipSetDevice(ctx->device));
   static const uint8_t GEN[64] = {0xca,0xcf,0x43,0xc9,0x8b,0x3d,0x72,0x3d,0xe0,0x19,0x18,0x0d,0x9b,0xfd,0xac,0xde,0xc7,0xf0,0x40,0x5a,0x41,0xed,0xec,0x7b,0x1b,0x97,0x99,0x85,0xc1,0x15,0xef,0x01,
                                   0x1f,0xdc,0xe8,0x36,0x0c,0x00,0x73,0x28,0xa3,0x43,0xbe,0x1a,0xd1,0xec,0x53,0xde,0x62,0xec,0x46,0xdf,0x01,0x48,0xbe,0xb7,0x30,0x97,0xa4,0x0a,0x06,0x68,0x56,0x00};
-  void *dsc, *dg, *dgp, *dres, *dout;
+  if (!ctx->gen_tab) {   // fixed-base table of the generator: 16 windows x 2^15 multiples (34 MB), built once per context
+    bpgpu_gens *t = nullptr;
+    int rc = bpgpu_gens_create(ctx, nullptr, nullptr, 0, GEN, GEN, 16, &t);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->gen_tab) ctx->gen_tab = t;
+    else { hipFree(t->points); hipFree(t->table); delete t; }
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *dsc, *dres, *dout;
   CK(ws_get(ctx, 0, n * 32, &dsc));
-  CK(ws_get(ctx, 1, 64, &dg));
-  CK(ws_get(ctx, 2, sizeof(AffDev), &dgp));
   CK(ws_get(ctx, 3, n * sizeof(JacRaw), &dres));
   CK(ws_get(ctx, 5, n * 64, &dout));
   CK(flag_reset(ctx));
   CK(h2d(ctx, dsc, scalars, n * 32));
-  CK(h2d(ctx, dg, GEN, 64));
   scalars_check(ctx->st, (Words8 *)dsc, n, ctx->d_flag);
-  points_from_boundary(ctx->st, (Words8 *)dg, (AffDev *)dgp, 1, ctx->d_flag);
-  StrausArgs a{};
-  a.pts[0] = (AffDev *)dgp; a.pt_stride[0] = 0;
-  a.sc[0] = (uint32_t *)dsc; a.sc_stride[0] = 8;
-  void *dstr;
-  CK(straus_ws(ctx, 1, n, &dstr));
-  straus(ctx->st, 1, a, (JacRaw *)dres, n, dstr);
+  fixed_single16(ctx->st, ctx->gen_tab->table, (const uint32_t *)dsc, (JacRaw *)dres, n);   // 16 table additions per scalar
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, n);
   CK(launch_ok(ctx));
   int bad = 0;

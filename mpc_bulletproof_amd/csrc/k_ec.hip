@@ -342,6 +342,35 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
   else return false;
   return true;
 }
+// out[i] = scalars[i] * P_0 by table lookups, one lane per scalar (GeneratorsChain::next, generators.rs:112-124:
+// every Bulletproofs generator is a hashed scalar times the curve generator -- SURVEY 8f N2)
+template <int C>
+__global__ void __launch_bounds__(64) k_fixed_single(const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8], r[9];
+#pragma unroll
+  for (int t = 0; t < 8; t++) s[t] = scalars[i * 8 + t];
+  recode_add_k<C>(r, s);
+  Jac acc = jac_inf();
+#pragma unroll 1
+  for (int w = 0; w < W; w++) {
+    int dg = recode_digit<C>(r, w);
+    if (dg != 0) {
+      Aff q = aff_load(table + (size_t)w * HALF + ((dg < 0 ? -dg : dg) - 1));
+      if (dg < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+  }
+  raw_store(&out[i], acc);
+}
+void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL((k_fixed_single<16>), dim3((n + 63) / 64), dim3(64), 0, st, table, scalars, out, n);
+}
+
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
 size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
   size_t total = (2 + 2 * n) * (252 / c + 1);

@@ -72,6 +72,8 @@ void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, 
 // out[b] = sum_g scalars[b*sc_stride + g*8 ..] * P_g over the generators [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] of a
 // table built for capacity cap >= n, via table lookups (plain canonical scalars, 2 + 2n per MSM).
 // partials: scratch of nb * fixed_msm_chunks(c, n, nb) points (NULL: one block per MSM).
+// out[i] = scalars[i] * (generator 0 of a c = 16 table), one lane per scalar
+void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n);
 size_t fixed_msm_chunks(int c, size_t n, size_t nb);
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
                size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials);

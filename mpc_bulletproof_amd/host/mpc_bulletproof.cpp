@@ -361,12 +361,14 @@ BulletproofGens::~BulletproofGens() {
 }
 void BulletproofGens::increase_capacity(size_t new_capacity) {
   if (gens_capacity >= new_capacity) return;
-  for (size_t i = 0; i < party_capacity; i++) {
-    auto g = generators_chain('G', (uint32_t)i, gens_capacity, new_capacity - gens_capacity);
-    auto h = generators_chain('H', (uint32_t)i, gens_capacity, new_capacity - gens_capacity);
-    G_vec_[i].insert(G_vec_[i].end(), g.begin(), g.end());
-    H_vec_[i].insert(H_vec_[i].end(), h.begin(), h.end());
-  }
+  // the 2 * party_capacity hash chains are independent (generators.rs:216-233): one host thread each; the
+  // scalar -> point step of every chain is one bpgpu_generator_mul call (thread-safe)
+  parallel_for(2 * party_capacity, [&](size_t t) {
+    const size_t i = t / 2;
+    auto v = generators_chain(t % 2 ? 'H' : 'G', (uint32_t)i, gens_capacity, new_capacity - gens_capacity);
+    auto &dst = t % 2 ? H_vec_[i] : G_vec_[i];
+    dst.insert(dst.end(), v.begin(), v.end());
+  });
   gens_capacity = new_capacity;
 }
 std::vector<StarkPoint> BulletproofGens::Share::G(size_t n) const {
