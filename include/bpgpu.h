@@ -52,8 +52,9 @@ void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for e
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
- * bench.py's `roofline` uses).  kinds: 0 verify_scalars, 1 fixed-base MSM, 2 point import,
- * 3 variable-base Straus, 4 verify tail, 5 device transcript.  read() synchronises, returns sums since the last read. */
+ * bench.py's `roofline` uses).  kinds: 0 scalar assembly (prep + k_verify_scalars), 4 verify tail, 5 device
+ * transcript, 6 the fused mega_check MSM launch; 1 fixed-base MSM, 2 point import, 3 Straus when the halves are
+ * launched separately.  read() synchronises, returns sums since the last read. */
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]);
 
@@ -97,7 +98,7 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
 /* ---- resident generators ---------------------------------------------------------------------
  * BulletproofGens::share(0).G(n) / .H(n) and PedersenGens{B, B_blinding}
  *   -- src/generators.rs:32-37,158-167,310-320.  Uploads the points once and precomputes signed
- * fixed-window tables (window_bits in {4..16}; table bytes = (2*cap+2) * (252/c+1) * 2^(c-1) * 64). */
+ * fixed-window tables (window_bits in {4, 8, 10, 12, 14, 16}; table bytes = (2*cap+2) * (252/c+1) * 2^(c-1) * 64). */
 int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t gens_capacity,
                       const uint8_t B[64], const uint8_t B_blinding[64], int window_bits,
                       bpgpu_gens **out);
