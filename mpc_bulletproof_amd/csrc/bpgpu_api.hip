@@ -1505,13 +1505,15 @@ int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_
   if (!n) return BPGPU_OK;
   static const uint8_t GEN[64] = {0xca,0xcf,0x43,0xc9,0x8b,0x3d,0x72,0x3d,0xe0,0x19,0x18,0x0d,0x9b,0xfd,0xac,0xde,0xc7,0xf0,0x40,0x5a,0x41,0xed,0xec,0x7b,0x1b,0x97,0x99,0x85,0xc1,0x15,0xef,0x01,
                                   0x1f,0xdc,0xe8,0x36,0x0c,0x00,0x73,0x28,0xa3,0x43,0xbe,0x1a,0xd1,0xec,0x53,0xde,0x62,0xec,0x46,0xdf,0x01,0x48,0xbe,0xb7,0x30,0x97,0xa4,0x0a,0x06,0x68,0x56,0x00};
-  if (!ctx->gen_tab) {   // fixed-base table of the generator: 16 windows x 2^15 multiples (34 MB), built once per context
+  bool have;
+  { std::lock_guard<std::mutex> lk(ctx->mu); have = ctx->gen_tab != nullptr; }
+  if (!have) {   // fixed-base table of the generator: 16 windows x 2^15 multiples (34 MB), built once per context
     bpgpu_gens *t = nullptr;
-    int rc = bpgpu_gens_create(ctx, nullptr, nullptr, 0, GEN, GEN, 16, &t);
+    int rc = bpgpu_gens_create(ctx, nullptr, nullptr, 0, GEN, GEN, 16, &t);   // takes the context lock itself
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->gen_tab) ctx->gen_tab = t;
-    else { hipFree(t->points); hipFree(t->table); delete t; }
+    else { hipFree(t->points); hipFree(t->table); delete t; }   // another thread won the race
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
