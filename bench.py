@@ -27,15 +27,15 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 16 tables (profiles/r01_pmc_*.csv).
-    # k_verify_msm: fetches = 1024 x 2080 random 64-byte rows of the 4.5 GB c = 16 generator table (136 MB of
-    # gathers that replace 16 doublings each) + the proof points; writes = the per-lane Straus window tables
-    "verify_msm": int((2 * 160901.6 + 35644.7) * 1024),
-    "verify_scalars": int((2 * 5401.9 + 9601.6) * 1024),
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 20 tables (profiles/r01_pmc_*.csv).
+    # k_verify_msm: fetches = 1024 x 1690 random 64-byte rows of the 57 GB c = 20 generator table (108 MB of
+    # gathers that replace 20 doublings each) + the proof points; writes = the per-lane Straus window tables
+    "verify_msm": int((2 * 133840.3 + 35644.3) * 1024),
+    "verify_scalars": int((2 * 5402.1 + 9601.5) * 1024),
 }
 # VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_msm<4,16,16> 2.23e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
-VALU_WAVE_INSTR_PER_STEP_1024 = 2.23e8 + 2.08e7 + 4.64e6 + 1.59e6
+# k_verify_msm<4,20,16> 2.07e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 2.07e8 + 2.08e7 + 4.64e6 + 1.59e6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
@@ -107,7 +107,9 @@ def main():
     ap.add_argument("--steps", type=int, default=1024)
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1024)
-    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "16")))
+    ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "20")),
+                    help="window of the resident generator tables: 20 bits = 13 table additions per generator term, a 57 GB "
+                         "table for the 130 generators of the 64-bit gadget (16 bits: 16 additions, 4.5 GB)")
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
@@ -393,7 +395,7 @@ def main():
             "roofline_valu_issue": ({"bound": "VALU issue slots", "achieved": VALU_WAVE_INSTR_PER_STEP_1024 / step_s,
                                      "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s", "frac": VALU_WAVE_INSTR_PER_STEP_1024 / step_s / VALU_ISSUE_PEAK,
                                      "note": "instructions per step from the PMC pass of the default configuration (profiles/r01_pmc_sq_summary.txt)"}
-                                    if nb == 1024 and vnp == 4 and a.window_bits == 16 and not os.environ.get("BPGPU_NO_FUSE") else None),
+                                    if nb == 1024 and vnp == 4 and a.window_bits == 20 and not os.environ.get("BPGPU_NO_FUSE") else None),
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
             "with_device_transcript": fs,

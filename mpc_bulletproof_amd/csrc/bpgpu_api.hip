@@ -485,7 +485,7 @@ int bpgpu_points_compress(bpgpu_ctx *ctx, const uint8_t *xy, size_t n, uint8_t *
 int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t cap, const uint8_t B[64],
                       const uint8_t Bb[64], int c, bpgpu_gens **out) {
   if (!ctx || !out || !B || !Bb || (cap && (!G || !H))) return BPGPU_E_ARG;
-  if (!(c == 4 || c == 8 || c == 10 || c == 12 || c == 14 || c == 16)) return BPGPU_E_ARG;
+  if (!(c == 4 || c == 8 || c == 10 || c == 12 || c == 14 || c == 16 || c == 20)) return BPGPU_E_ARG;
   *out = nullptr;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -513,11 +513,20 @@ int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t
   GCK(hipMalloc(&dxy, ng * 64));
   GCK(hipMalloc((void **)&g->points, ng * sizeof(AffDev)));
   GCK(hipMalloc((void **)&g->table, entries * sizeof(AffDev)));
-  GCK(hipMalloc(&scratch, (ng * W + entries) * sizeof(JacRaw)));
+  // the Jacobian staging of the table is built for groups of generators so that it stays below ~8 GB
+  // (a 20-bit-window table of the 64-bit gadget's 130 generators is 57 GB; staged whole it would need 95 GB more)
+  const size_t per_gen = W * ((size_t)1 << (c - 1));                 // table rows per generator
+  size_t group = ((size_t)8 << 30) / ((per_gen + W) * sizeof(JacRaw));
+  if (group < 1) group = 1;
+  if (group > ng) group = ng;
+  GCK(hipMalloc(&scratch, group * (W + per_gen) * sizeof(JacRaw)));
   GCK(hipMemsetAsync(ctx->d_flag, 0, sizeof(int), ctx->st));
   GCK(hipMemcpyAsync(dxy, host.data(), ng * 64, hipMemcpyHostToDevice, ctx->st));
   points_from_boundary(ctx->st, (Words8 *)dxy, g->points, ng, ctx->d_flag);
-  fixed_table_build(ctx->st, c, g->points, ng, g->table, (JacRaw *)scratch);
+  for (size_t g0 = 0; g0 < ng; g0 += group) {
+    size_t cnt = ng - g0 < group ? ng - g0 : group;
+    fixed_table_build(ctx->st, c, g->points + g0, cnt, g->table + g0 * per_gen, (JacRaw *)scratch);
+  }
   GCK(hipGetLastError());
   int bad = 0;
   GCK(hipMemcpyAsync(&bad, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st));

@@ -160,7 +160,7 @@ BP_HD void aff_to_boundary(uint32_t xy[16], const Aff &a) {
 // 256-bit scalar integer helpers (canonical words): signed fixed-window digits via the "+K" trick:
 // s' = s + sum_w 2^(c-1) 2^(cw); digit_w = window_w(s') - 2^(c-1) in [-2^(c-1), 2^(c-1)-1].
 template <int C> BP_HD constexpr int num_windows() { return 252 / C + 1; }
-// sp has 9 words (288 bits) so that the top window of any C <= 16 is representable
+// sp has 9 words (288 bits) so that the top window of any C <= 20 is representable (W * C <= 273)
 template <int C> BP_HD void recode_add_k(uint32_t out[9], const uint32_t s[8]) {
   uint64_t carry = 0;
 #pragma unroll

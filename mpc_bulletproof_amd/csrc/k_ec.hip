@@ -336,6 +336,7 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
   if (c == 16 && np == 2) launch_verify_msm<2, 16>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 16 && np == 3) launch_verify_msm<3, 16>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 16 && np == 4) launch_verify_msm<4, 16>(st, a, out_var, n_lanes, scratch, f);
+  else if (c == 20 && np == 4) launch_verify_msm<4, 20>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 8 && np == 2) launch_verify_msm<2, 8>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 8 && np == 3) launch_verify_msm<3, 8>(st, a, out_var, n_lanes, scratch, f);
   else if (c == 8 && np == 4) launch_verify_msm<4, 8>(st, a, out_var, n_lanes, scratch, f);
@@ -404,6 +405,7 @@ void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap,
     case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
     case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
     case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
     default: return;   // rejected by the C-ABI before reaching here
   }
   if (chunks > 1) segmented_sum(st, partials, out, nb, chunks);

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(128) k_tab_fill(int c, size_t nbases, const Ja
   Jac base = raw_load(&bases[l]);
   unsigned d0 = (unsigned)r * 8 + 1;
   Jac acc = jac_inf();
-  for (int bit = 15; bit >= 0; bit--) {
+  for (int bit = c - 1; bit >= 0; bit--) {   // d0 < 2^(c-1)
     acc = jac_dbl(acc);
     if ((d0 >> bit) & 1) acc = jac_add(acc, base);
   }

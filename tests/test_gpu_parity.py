@@ -127,9 +127,9 @@ def test_msm_rejects_bad_input(gpu):
         gpu.msm(N.to_bytes(32, "little"), G)
 
 
-@pytest.mark.parametrize("c", [4, 8])
+@pytest.mark.parametrize("c", [4, 8, 20])
 def test_msm_gens(gpu, c):
-    cap = 16
+    cap = 16     # 20-bit windows: 13 x 2^19 table rows per generator (436 MB each, 15 GB for the 34 generators)
     Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
     g = gpu.gens_create(Gp, Hp, B, B, c)
     try:
