@@ -305,11 +305,204 @@ __global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, siz
                                                         size_t sc_stride, JacRaw *out, size_t nb) {
   fixed_small_body<C, LPM>(table, n, cap, scalars, sc_stride, out, nb, blockIdx.x);
 }
+// ---- window-parallel variable-base part of the mega_check (the 11 + m + 2k proof points of every proof) -----------
+// Straus with a doubling chain per lane pays 252 doublings for every 4 points.  Here the three phases are split:
+//   tables   lane per 4 points (role-major): {1..8} P_j, normalised to affine with one inversion per lane,
+//            written as AffRaw rows tab[proof][point][entry]; the points come straight from the ABI bytes
+//   windows  one WAVE per proof, lane w = window w (64 signed 4-bit windows): S_w = sum_j d_{j,w} P_j by mixed
+//            additions from the tables -- no doublings
+//   horner   one LANE per proof: sum_w 16^w S_w with the proof's only 252 doublings, + the fixed-base partial,
+//            identity test (replaces k_verify_finalize)
+// ~80 k wave-instructions per proof against ~113 k for the per-lane Straus, and a shorter kernel chain.
+struct AffRaw { int32_t v[2 * NL]; };   // raw Montgomery limbs x[9] y[9]; all zero = identity
+struct TablesArgs {
+  const AffDev *points;     // ABI bytes, nb x nvar x 64 B
+  size_t nb, nvar, lanes;   // lanes = ceil(nvar / 4) per proof
+  AffRaw *tab;              // nb x nvar x 8
+  int32_t *scratch;         // lane-strided staging: blocks x 4 x 8 x STE x 64 int32
+  int *bad;
+};
+constexpr int TNP = 4;
+__device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
+  constexpr int TPB = 64;
+  const int tid = threadIdx.x;
+  int32_t *stg = a.scratch + blk * (TNP * SE * STE * TPB);
+  size_t i = blk * TPB + tid;
+  const size_t n = a.nb * a.lanes;
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  const size_t r = i / a.nb, p = i - r * a.nb;        // role-major: a wave holds one role of 64 proofs
+  auto slot = [&](int j, int e) { return stg + ((size_t)(j * SE + e) * STE) * TPB + tid; };
+  auto ld = [&](const int32_t *q, int off) { Fp x; for (int t = 0; t < NL; t++) x.v[t] = q[(off + t) * TPB]; return x; };
+  auto st = [&](int32_t *q, int off, const Fp &x) { for (int t = 0; t < NL; t++) q[(off + t) * TPB] = x.v[t]; };
+  unsigned skip = 0, pinf = 0;   // bit j: wave-uniform / per-lane "point j is the identity (or beyond nvar)"
+#pragma unroll
+  for (int j = 0; j < TNP; j++) {
+    const size_t v = r + (size_t)j * a.lanes;
+    Aff P;
+    P.x = fe_zero<FP>();
+    P.y = fe_zero<FP>();
+    if (v < a.nvar) {
+      const AffDev *psrc = a.points + p * a.nvar + v;
+      uint32_t w[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
+      if (!aff_from_boundary(P, w)) {
+        if (live) atomicOr(a.bad, 1);
+        P.x = fe_zero<FP>();
+        P.y = fe_zero<FP>();
+      }
+    }
+    const bool inf = aff_is_inf(P);
+    if (__all(inf)) { skip |= 1u << j; continue; }
+    if (inf) pinf |= 1u << j;
+    Jac m = jac_from_aff(P);
+#pragma unroll 1
+    for (int e = 0; e < SE; e++) {
+      int32_t *dst = slot(j, e);
+      st(dst, 0, m.X); st(dst, NL, m.Y); st(dst, 2 * NL, m.Z);
+      if (e + 1 < SE) m = jac_madd(m, P);
+    }
+  }
+  // Montgomery's trick over the Z of entries 2P..8P of the lane's points (entry 0 is affine already)
+  Fp prod = fe_one<FP>();
+#pragma unroll 1
+  for (int j = 0; j < TNP; j++) {
+    if ((skip >> j) & 1) continue;
+#pragma unroll 1
+    for (int e = 1; e < SE; e++) {
+      int32_t *q = slot(j, e);
+      st(q, 3 * NL, prod);
+      if (!((pinf >> j) & 1)) prod = fpmul(prod, ld(q, 2 * NL));
+    }
+  }
+  Fp pinv = inv(prod);
+#pragma unroll 1
+  for (int j = TNP - 1; j >= 0; j--) {
+    const size_t v = r + (size_t)j * a.lanes;
+    AffRaw *row = a.tab + (p * a.nvar + v) * SE;
+    const bool dead = ((skip >> j) & 1) || ((pinf >> j) & 1);
+#pragma unroll 1
+    for (int e = SE - 1; e >= 0; e--) {
+      Fp x = fe_zero<FP>(), y = fe_zero<FP>();
+      if (!dead) {
+        int32_t *q = slot(j, e);
+        x = ld(q, 0);
+        y = ld(q, NL);
+        if (e >= 1) {
+          Fp zi = fpmul(pinv, ld(q, 3 * NL));
+          pinv = fpmul(pinv, ld(q, 2 * NL));
+          Fp zi2 = fpsqr(zi);
+          x = fpmul(x, zi2);
+          y = fpmul(y, fpmul(zi2, zi));
+        }
+      }
+      if (live && v < a.nvar) {
+#pragma unroll
+        for (int t = 0; t < NL; t++) { row[e].v[t] = x.v[t]; row[e].v[NL + t] = y.v[t]; }
+      }
+    }
+  }
+}
+// one wave per proof, lane = window
+__global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const uint32_t *scalars /* nb x nvar x 8 words */,
+                                                       size_t nvar, JacRaw *winsum) {
+  const size_t p = blockIdx.x;
+  const int w = threadIdx.x;
+  Jac acc = jac_inf();
+#pragma unroll 1
+  for (size_t v = 0; v < nvar; v++) {
+    uint32_t s[8], sp[9];
+    const uint32_t *src = scalars + (p * nvar + v) * 8;
+#pragma unroll
+    for (int t = 0; t < 8; t++) s[t] = src[t];
+    recode_add_k<SW>(sp, s);
+    const int dg = recode_digit<SW>(sp, w);
+    if (dg != 0) {
+      const AffRaw *e = tab + (p * nvar + v) * SE + ((dg < 0 ? -dg : dg) - 1);
+      Aff q;
+#pragma unroll
+      for (int t = 0; t < NL; t++) { q.x.v[t] = e->v[t]; q.y.v[t] = e->v[NL + t]; }
+      if (!aff_is_inf(q)) {
+        if (dg < 0) q.y = neg(q.y);
+        acc = jac_madd(acc, q);
+      }
+    }
+  }
+  raw_store(&winsum[p * 64 + w], acc);
+}
+// one lane per proof: Horner over the 64 window sums, + the fixed-base partial, identity test
+__global__ void __launch_bounds__(64) k_verify_horner(const JacRaw *winsum, const JacRaw *fixed, size_t nb, int32_t *ok,
+                                                      Words8 *mega) {
+  __builtin_amdgcn_s_setprio(2);   // 16 waves carrying the longest link of the chain
+  size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= nb) return;
+  constexpr int W = num_windows<SW>();
+  Jac acc = raw_load(&winsum[p * 64 + W - 1]);
+#pragma unroll 1
+  for (int w = W - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int d = 0; d < SW; d++) acc = jac_dbl(acc);
+    acc = jac_add(acc, raw_load(&winsum[p * 64 + w]));
+  }
+  acc = jac_add(acc, raw_load(&fixed[p]));
+  bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
+  ok[p] = inf ? 1 : 0;
+  if (mega) {
+    uint32_t w[16];
+    if (inf) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) w[j] = 0;
+    } else {
+      aff_to_boundary(w, jac_to_aff(acc));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { mega[2 * p].w[j] = w[j]; mega[2 * p + 1].w[j] = w[8 + j]; }
+  }
+}
+struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
+// tables (blocks [0, table_blocks)) and the small fixed-base MSMs in one launch
+template <int C, int LPM>
+__global__ void __launch_bounds__(64) k_verify_tabfix(TablesArgs t, unsigned table_blocks, FixedSmallArgs f) {
+  if (blockIdx.x < table_blocks) tables_body(t, blockIdx.x);
+  else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - table_blocks);
+}
+size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
+  size_t lanes = (nvar + TNP - 1) / TNP, blocks = (nb * lanes + 63) / 64;
+  return blocks * TNP * SE * STE * 64 * 4 + nb * nvar * SE * sizeof(AffRaw) + nb * 64 * sizeof(JacRaw) + 256;
+}
+template <int C>
+static void launch_tabfix(hipStream_t st, const TablesArgs &t, unsigned tb, const FixedSmallArgs &f) {
+  if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_tabfix<C, 16>), dim3(tb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, t, tb, f);
+  else hipLaunchKernelGGL((k_verify_tabfix<C, 32>), dim3(tb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, t, tb, f);
+}
+// The whole MSM + verdict of a batch in three launches; false = unsupported combination (use the other paths).
+// var_scalars: nb x nvar x 8 words (operand order); fixed scalars as for fixed_msm; scratch: verify_wp_scratch_bytes.
+bool verify_msm_window_parallel(hipStream_t st, const AffDev *points_abi, const uint32_t *var_scalars, size_t nb, size_t nvar,
+                                int c, const AffDev *table, size_t n, size_t cap, const uint32_t *fixed_scalars,
+                                size_t sc_stride, JacRaw *out_fixed, void *scratch, int *bad, int32_t *ok, Words8 *mega) {
+  const size_t total = (2 + 2 * n) * (252 / c + 1);
+  if (nb < 64 || total > 16384 || !nvar || !(c == 8 || c == 16 || c == 20)) return false;
+  TablesArgs t{};
+  t.points = points_abi; t.nb = nb; t.nvar = nvar; t.lanes = (nvar + TNP - 1) / TNP; t.bad = bad;
+  const size_t blocks = (nb * t.lanes + 63) / 64;
+  uint8_t *sp = (uint8_t *)scratch;
+  t.scratch = (int32_t *)sp; sp += blocks * TNP * SE * STE * 64 * 4;
+  t.tab = (AffRaw *)sp; sp += nb * nvar * SE * sizeof(AffRaw);
+  JacRaw *winsum = (JacRaw *)(((uintptr_t)sp + 63) & ~(uintptr_t)63);
+  FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, nb};
+  if (c == 8) launch_tabfix<8>(st, t, (unsigned)blocks, f);
+  else if (c == 16) launch_tabfix<16>(st, t, (unsigned)blocks, f);
+  else launch_tabfix<20>(st, t, (unsigned)blocks, f);
+  hipLaunchKernelGGL(k_verify_windows, dim3(nb), dim3(64), 0, st, t.tab, var_scalars, nvar, winsum);
+  hipLaunchKernelGGL(k_verify_horner, dim3((nb + 63) / 64), dim3(64), 0, st, winsum, out_fixed, nb, ok, mega);
+  return true;
+}
+
 // Both halves of a batch's mega_check MSM in ONE launch: blocks [0, straus_blocks) run the per-lane Straus over the
 // proof points, the rest the table-lookup MSMs over the generators.  A single 1024-proof batch gives either part
 // only 100-250 waves for 1024 SIMDs and a stream runs one kernel at a time, so launching them together doubles the
 // waves each in-flight batch keeps on the chip.
-struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
 template <int NP, int C, int LPM>
 __global__ void __launch_bounds__(64) k_verify_msm(StrausArgs a, JacRaw *out, size_t n, int32_t *tab_all,
                                                    unsigned straus_blocks, FixedSmallArgs f) {

@@ -290,16 +290,19 @@ def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
         gpu.circuit_destroy(circ)
 
 
-@pytest.mark.parametrize("np_,fuse", [(4, True), (3, True), (2, True), (4, False), (1, False)])
-def test_verify_batch_fused_and_split_launches(gpu, monkeypatch, np_, fuse):
-    """Batches of >= 64 proofs take the fused mega_check launch (role-major Straus lanes + small fixed-base MSMs in
-    one kernel, points validated in-kernel); 18 proof points with 4 per lane leave a remainder launch.  Accept
-    bits, mega_check points (tampered proofs included) and all MSM scalars must equal the oracle's for every
-    points-per-lane setting, fused or not."""
+@pytest.mark.parametrize("np_,fuse,wp,c", [(4, True, 1, 8), (4, True, 1, 16), (4, True, 0, 8), (3, True, 0, 8), (2, True, 0, 8),
+                                           (4, False, 0, 8), (1, False, 0, 8)])
+def test_verify_batch_launch_variants(gpu, monkeypatch, np_, fuse, wp, c):
+    """Batches of >= 64 proofs take the window-parallel path (tables | windows | Horner + verdict, 18 proof points =
+    4.5 table lanes per proof); BPGPU_WINDOW_PARALLEL=0 selects the fused Straus launch (role-major lanes + small
+    fixed-base MSMs in one kernel, a remainder launch for 18 mod 4 points), BPGPU_NO_FUSE=1 the separate launches.
+    Accept bits, mega_check points (tampered proofs included) and all MSM scalars must equal the oracle's in every
+    variant."""
     monkeypatch.setenv("BPGPU_STRAUS_NP", str(np_))
+    monkeypatch.setenv("BPGPU_WINDOW_PARALLEL", str(wp))
     if not fuse:
         monkeypatch.setenv("BPGPU_NO_FUSE", "1")
-    test_range_verify_batch(gpu, 8, 70, 8)
+    test_range_verify_batch(gpu, 8, 70, c)
 
 
 def test_verify_batch_rejects_malformed_inputs_in_fused_launch(gpu):
