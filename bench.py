@@ -27,15 +27,16 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
 # runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
 TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, 4 points per lane, c = 20 tables (profiles/r01_pmc_*.csv).
-    # k_verify_msm: fetches = 1024 x 1690 random 64-byte rows of the 57 GB c = 20 generator table (108 MB of
-    # gathers that replace 20 doublings each) + the proof points; writes = the per-lane Straus window tables
-    "verify_msm": int((2 * 133840.3 + 35644.3) * 1024),
-    "verify_scalars": int((2 * 5402.1 + 9601.5) * 1024),
+    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, window-parallel path, c = 20 tables (profiles/r01_pmc_*.csv).
+    # k_verify_tabfix: fetches = 1024 x 1690 random 64-byte rows of the 57 GB c = 20 generator table (108 MB of
+    # gathers that replace 20 doublings each) + the proof points; writes = the affine tables of the proof points
+    "verify_msm": int((2 * 125656.9 + 37454.3) * 1024),
+    "verify_windows": int((2 * 7843.1 + 6912.0) * 1024),
+    "verify_scalars": int((2 * 5402.0 + 9601.5) * 1024),
 }
 # VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_msm<4,20,16> 2.07e8 + k_verify_scalars 2.08e7 + k_verify_finalize 4.6e6 + k_vs_prep 1.6e6
-VALU_WAVE_INSTR_PER_STEP_1024 = 2.07e8 + 2.08e7 + 4.64e6 + 1.59e6
+# k_verify_tabfix<20,16> 9.53e7 + k_verify_windows 5.49e7 + k_verify_scalars 2.08e7 + k_verify_horner 1.23e7 + k_vs_prep 1.6e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 9.53e7 + 5.49e7 + 2.08e7 + 1.23e7 + 1.59e6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
@@ -356,23 +357,41 @@ def main():
     if rank == 0:
         nvar = 11 + m + 2 * k
         nterms = 13 + m + 2 * (1 << k) + 2 * k
-        # dominant kernel = variable-base Straus over nb * nvar (scalar, point) pairs, 96 B per term
-        dom = max(("verify_msm", "straus", "fixed_msm", "verify_scalars"), key=lambda n_: prof.get(n_, (0.0, 0))[0])
+        # Which launch path ran: window-parallel (k_verify_tabfix | k_verify_windows | k_verify_horner), the fused Straus
+        # launch (k_verify_msm) or separate launches.  The roofline's dominant kernel = the one with the largest summed
+        # duration among the kernels that consume algorithmic bytes (96 B per MSM term = 64 B point +
+        # 32 B scalar; the Horner pass only reads intermediates).
+        wp = prof.get("verify_windows", (0.0, 0))[1] > 0
+        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
+        W = 252 // a.window_bits + 1
+        if wp:
+            names = {"verify_msm": f"k_verify_tabfix<{a.window_bits},16>", "verify_windows": "k_verify_windows",
+                     "verify_scalars": "k_verify_scalars"}
+            bytes_per_proof = {"verify_msm": nvar * 64 + (nterms - nvar) * 96, "verify_windows": nvar * 32,
+                               "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
+        else:
+            names = {"verify_msm": f"k_verify_msm<{vnp},{a.window_bits},16>", "straus": f"k_straus<{vnp},64>",
+                     "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}
+            bytes_per_proof = {"verify_msm": nterms * 96, "straus": nvar * 96, "fixed_msm": (nterms - nvar) * 96,
+                               "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
+        dom = max(names, key=lambda n_: prof.get(n_, (0.0, 0))[0])
         ms, cnt = prof[dom]
         avg_s = ms / max(cnt, 1) / 1e3
-        terms = {"verify_msm": nterms, "straus": nvar, "fixed_msm": nterms - nvar, "verify_scalars": 0}[dom]
-        alg_bytes = nb * (terms * 96 if dom != "verify_scalars" else (6 + k + 5) * 32 + nterms * 32)
+        alg_bytes = nb * bytes_per_proof[dom]
         achieved = alg_bytes / avg_s / 1e9
-        # integer roofline: algorithmic F_p multiplications x 94 v_mad_u64_u32 each (csrc/fe29.cuh), per step
-        # (Straus: one 252-doubling chain per lane + table build and 63 window additions per non-identity point --
-        # A_I2, A_O2, S2 are the identity in 1-phase proofs and are skipped; fixed-base: one mixed addition per
-        # (generator, window) + the 16-lane butterfly)
-        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
-        lanes = nvar // vnp + nvar % vnp
-        W = 252 // a.window_bits + 1
-        fp_straus = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
+        # integer roofline: algorithmic F_p multiplications x 94 limb MADs each (csrc/fe29.cuh), per step.
+        # window-parallel: per non-identity proof point 7 table additions + 60 window additions (mixed, 11 mul), one
+        # inversion per 8 points (~310), per proof 252 doublings (9) + 64 additions (16) in the Horner pass;
+        # fixed-base: one mixed addition per (generator, window) + the 16-lane butterfly.  A_I2, A_O2, S2 are the
+        # identity in 1-phase proofs and are skipped.
+        if wp:
+            fp_var = nb * ((nvar - 3) * (7 + 60) * 11 + ((nvar + 7) // 8) * 310 + 252 * 9 + 64 * 16)
+        else:
+            lanes = nvar // vnp + nvar % vnp
+            fp_var = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
         fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
-        fpmul = {"verify_msm": fp_straus + fp_fixed, "straus": fp_straus, "fixed_msm": fp_fixed, "verify_scalars": 0}[dom]
+        fpmul = {"verify_msm": fp_fixed + (0 if wp else fp_var), "straus": fp_var, "fixed_msm": fp_fixed}.get(dom, 0)
+        fp_straus = fp_var
         step_s = dt / a.steps
         out = {
             "metric": "range-proof verifications/sec (64-bit, m=1)",
@@ -382,20 +401,20 @@ def main():
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
-            "roofline": {"bound": "hbm", "kernel": {"verify_msm": f"k_verify_msm<{vnp},{a.window_bits},16>", "straus": f"k_straus<{vnp},64>", "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}[dom],
+            "roofline": {"bound": "hbm", "kernel": names[dom],
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "avg_launch_ms": avg_s * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
                          "note": "avg launch duration is measured with steps overlapping on the GPU (steps_in_flight); "
                                  "solo launch times are in DESIGN.md.  The path is VALU-integer bound: see roofline_int"},
-            "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "Straus + fixed-base halves of one step's mega_check MSMs / wall time per step",
+            "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "variable-base + fixed-base halves of one step's mega_check MSMs / wall time per step",
                              "achieved": (fp_straus + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
                              "frac": (fp_straus + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS,
                              "dominant_kernel_frac_at_its_avg_launch": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
             "roofline_valu_issue": ({"bound": "VALU issue slots", "achieved": VALU_WAVE_INSTR_PER_STEP_1024 / step_s,
                                      "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s", "frac": VALU_WAVE_INSTR_PER_STEP_1024 / step_s / VALU_ISSUE_PEAK,
                                      "note": "instructions per step from the PMC pass of the default configuration (profiles/r01_pmc_sq_summary.txt)"}
-                                    if nb == 1024 and vnp == 4 and a.window_bits == 20 and not os.environ.get("BPGPU_NO_FUSE") else None),
+                                    if nb == 1024 and wp and a.window_bits == 20 else None),
             "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
             "cpu_baseline": cpu,
             "with_device_transcript": fs,

@@ -52,9 +52,10 @@ void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for e
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
- * bench.py's `roofline` uses).  kinds: 0 scalar assembly (prep + k_verify_scalars), 4 verify tail, 5 device
- * transcript, 6 the fused mega_check MSM launch; 1 fixed-base MSM, 2 point import, 3 Straus when the halves are
- * launched separately.  read() synchronises, returns sums since the last read. */
+ * bench.py's `roofline` uses).  kinds: 0 scalar assembly (prep + k_verify_scalars), 5 device transcript, 6 tables +
+ * fixed-base MSMs (k_verify_tabfix; or the fused Straus launch), 7 window sums, 4 Horner + verdict (or the verify
+ * tail); 1 fixed-base MSM, 2 point import, 3 Straus when launched separately.  read() synchronises, returns sums
+ * since the last read. */
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]);
 

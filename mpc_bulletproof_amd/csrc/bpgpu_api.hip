@@ -798,14 +798,17 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   ar.inner = nb; ar.out_outer = 1; ar.out_stride = nres;
   // default: window-parallel variable-base part (tables | windows | Horner + verdict), see k_ec.hip
   const bool no_wp = getenv("BPGPU_WINDOW_PARALLEL") && atoi(getenv("BPGPU_WINDOW_PARALLEL")) == 0;
-  if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1) {
+  if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
     void *dwp;
     CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
-    ProfScope ps(ctx, 6, ctx->st);
-    if (verify_msm_window_parallel(ctx->st, (const AffDev *)points, (const uint32_t *)dvar, nb, nvar, g->c, g->table, np, g->cap,
-                                   (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres, dwp, ctx->d_flag, (int32_t *)ok,
-                                   (Words8 *)mega))
-      return launch_ok(ctx);
+    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag};
+    { ProfScope ps(ctx, 6, ctx->st);
+      verify_wp_tabfix(ctx->st, v, g->c, g->table, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
+    { ProfScope ps(ctx, 7, ctx->st);
+      verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
+    { ProfScope ps(ctx, 4, ctx->st);
+      verify_wp_horner(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
+    return launch_ok(ctx);
   }
   bool fused = false;
   if (!no_fuse && lanes && fixed_msm_chunks(g->c, np, nb) == 1) {

@@ -322,7 +322,7 @@ struct TablesArgs {
   int32_t *scratch;         // lane-strided staging: blocks x 4 x 8 x STE x 64 int32
   int *bad;
 };
-constexpr int TNP = 4;
+constexpr int TNP = 8;
 __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
   constexpr int TPB = 64;
   const int tid = threadIdx.x;
@@ -476,27 +476,45 @@ static void launch_tabfix(hipStream_t st, const TablesArgs &t, unsigned tb, cons
   if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_tabfix<C, 16>), dim3(tb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, t, tb, f);
   else hipLaunchKernelGGL((k_verify_tabfix<C, 32>), dim3(tb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, t, tb, f);
 }
-// The whole MSM + verdict of a batch in three launches; false = unsupported combination (use the other paths).
-// var_scalars: nb x nvar x 8 words (operand order); fixed scalars as for fixed_msm; scratch: verify_wp_scratch_bytes.
-bool verify_msm_window_parallel(hipStream_t st, const AffDev *points_abi, const uint32_t *var_scalars, size_t nb, size_t nvar,
-                                int c, const AffDev *table, size_t n, size_t cap, const uint32_t *fixed_scalars,
-                                size_t sc_stride, JacRaw *out_fixed, void *scratch, int *bad, int32_t *ok, Words8 *mega) {
+// The whole MSM + verdict of a batch in three launches (timed separately by the API's profile scopes).
+bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
   const size_t total = (2 + 2 * n) * (252 / c + 1);
-  if (nb < 64 || total > 16384 || !nvar || !(c == 8 || c == 16 || c == 20)) return false;
+  return nb >= 64 && total <= 16384 && nvar && (c == 8 || c == 16 || c == 20);
+}
+static TablesArgs wp_args(const VerifyWp &v, JacRaw **winsum, unsigned *blocks) {
   TablesArgs t{};
-  t.points = points_abi; t.nb = nb; t.nvar = nvar; t.lanes = (nvar + TNP - 1) / TNP; t.bad = bad;
-  const size_t blocks = (nb * t.lanes + 63) / 64;
-  uint8_t *sp = (uint8_t *)scratch;
-  t.scratch = (int32_t *)sp; sp += blocks * TNP * SE * STE * 64 * 4;
-  t.tab = (AffRaw *)sp; sp += nb * nvar * SE * sizeof(AffRaw);
-  JacRaw *winsum = (JacRaw *)(((uintptr_t)sp + 63) & ~(uintptr_t)63);
-  FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, nb};
-  if (c == 8) launch_tabfix<8>(st, t, (unsigned)blocks, f);
-  else if (c == 16) launch_tabfix<16>(st, t, (unsigned)blocks, f);
-  else launch_tabfix<20>(st, t, (unsigned)blocks, f);
-  hipLaunchKernelGGL(k_verify_windows, dim3(nb), dim3(64), 0, st, t.tab, var_scalars, nvar, winsum);
-  hipLaunchKernelGGL(k_verify_horner, dim3((nb + 63) / 64), dim3(64), 0, st, winsum, out_fixed, nb, ok, mega);
-  return true;
+  t.points = v.points_abi; t.nb = v.nb; t.nvar = v.nvar; t.lanes = (v.nvar + TNP - 1) / TNP; t.bad = v.bad;
+  const size_t nblk = (v.nb * t.lanes + 63) / 64;
+  uint8_t *sp = (uint8_t *)v.scratch;
+  t.scratch = (int32_t *)sp; sp += nblk * TNP * SE * STE * 64 * 4;
+  t.tab = (AffRaw *)sp; sp += v.nb * v.nvar * SE * sizeof(AffRaw);
+  *winsum = (JacRaw *)(((uintptr_t)sp + 63) & ~(uintptr_t)63);
+  *blocks = (unsigned)nblk;
+  return t;
+}
+// tables of the proof points | table-lookup MSMs over the generators (fixed scalars as for fixed_msm)
+void verify_wp_tabfix(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
+                      const uint32_t *fixed_scalars, size_t sc_stride, JacRaw *out_fixed) {
+  JacRaw *winsum;
+  unsigned blocks;
+  TablesArgs t = wp_args(v, &winsum, &blocks);
+  FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
+  if (c == 8) launch_tabfix<8>(st, t, blocks, f);
+  else if (c == 16) launch_tabfix<16>(st, t, blocks, f);
+  else launch_tabfix<20>(st, t, blocks, f);
+}
+// var_scalars: nb x nvar x 8 words in operand order
+void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_scalars) {
+  JacRaw *winsum;
+  unsigned blocks;
+  TablesArgs t = wp_args(v, &winsum, &blocks);
+  hipLaunchKernelGGL(k_verify_windows, dim3(v.nb), dim3(64), 0, st, t.tab, var_scalars, v.nvar, winsum);
+}
+void verify_wp_horner(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
+  JacRaw *winsum;
+  unsigned blocks;
+  (void)wp_args(v, &winsum, &blocks);
+  hipLaunchKernelGGL(k_verify_horner, dim3((v.nb + 63) / 64), dim3(64), 0, st, winsum, fixed, v.nb, ok, mega);
 }
 
 // Both halves of a batch's mega_check MSM in ONE launch: blocks [0, straus_blocks) run the per-lane Straus over the

@@ -49,12 +49,15 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
                       const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride_words,
                       JacRaw *out_fixed, size_t nb);
 
-// Window-parallel variant of the same (k_ec.hip): tables | windows | Horner + verdict in three launches; writes ok / mega
-// itself (no verify_finalize).  false = unsupported combination.
+// Window-parallel variant of the same (k_ec.hip): tables | windows | Horner + verdict in three launches; the last one
+// writes ok / mega itself (no verify_finalize).
+struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; };
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);
-bool verify_msm_window_parallel(hipStream_t st, const AffDev *points_abi, const uint32_t *var_scalars, size_t nb, size_t nvar,
-                                int c, const AffDev *table, size_t n, size_t cap, const uint32_t *fixed_scalars,
-                                size_t sc_stride_words, JacRaw *out_fixed, void *scratch, int *bad, int32_t *ok, Words8 *mega);
+bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n);
+void verify_wp_tabfix(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
+                      const uint32_t *fixed_scalars, size_t sc_stride_words, JacRaw *out_fixed);
+void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_scalars);
+void verify_wp_horner(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega);
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
 int pippenger_window(size_t n);

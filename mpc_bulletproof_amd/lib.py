@@ -120,7 +120,7 @@ class BpGpu:
         ms = (C.c_double * 8)()
         cnt = (C.c_uint64 * 8)()
         self._ck(_lib.bpgpu_profile_read(self.ctx, ms, cnt))
-        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm"]
+        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm", "verify_windows"]
         return {n: (ms[i], int(cnt[i])) for i, n in enumerate(names)}
 
     # ---- scalar field
