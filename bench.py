@@ -100,18 +100,19 @@ def _cpu_verify_chunk(args):
 
 
 def main():
-    # deep step pipelining needs hardware queues (ROCm default: 4) and is better with one stream per context
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # deep step pipelining needs hardware queues (ROCm default: 4; measured: 16 queues/16 steps in flight 2.88 M/s,
+    # 24/24 3.08 M/s, 32/32 3.12 M/s, 32/48 2.71 M/s, 64/64 2.89 M/s) and is better with one stream per context
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=64)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "20")),
                     help="window of the resident generator tables: 20 bits = 13 table additions per generator term, a 57 GB "
                          "table for the 130 generators of the 64-bit gadget (16 bits: 16 additions, 4.5 GB)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "32")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
