@@ -796,3 +796,60 @@ def test_ipp_rounds_with_device_transcript(gpu, resident):
         gpu.ipp_destroy(s)
         if g is not None:
             gpu.gens_destroy(g)
+
+
+@pytest.mark.parametrize("kind,param,values_fn,nverify", [
+    ("multi", 8 | (2 << 16), lambda i: [(37 * i + 5) % 256, (91 * i + 200) % 256], 0),      # m = 2, n = 16, k = 4 -> 21 points
+    ("multi", 4 | (3 << 16), lambda i: [i % 16, (5 * i + 3) % 16, (11 * i + 7) % 16], 0),   # m = 3, n = 12 -> padded 16, 22 points
+    ("example", 0, lambda i: [3 + i, 4, 6, 1, 0, 9], 1),        # m = 5, n = 1, k = 0 -> 16 points (c2 = 9 is public: one circuit)
+])
+def test_verify_batch_other_circuits_all_launch_variants(gpu, monkeypatch, kind, param, values_fn, nverify):
+    """Batches of 70 proofs of circuits with several commitments / padding / k = 0 through the window-parallel, fused
+    and separate launch paths: accept bits, mega_check points and MSM scalars as the oracle's (tampered included)."""
+    nb = 70
+    okind = o.K_RANGE_MULTI if kind == "multi" else o.K_EXAMPLE
+    label = b"RangeProofTest" if kind == "multi" else b"ExampleGadget"
+    cap = 16
+    recs = []
+    for i in range(nb):
+        vals = values_fn(i)
+        if kind == "example":     # (a1 + a2)(b1 + b2) = c1 + c2 with c2 public
+            a1, a2, b1, b2 = vals[0], vals[1], vals[2], vals[3]
+            c2 = vals[5]
+            vals = [a1, a2, b1, b2, (a1 + a2) * (b1 + b2) - c2, c2]
+        rc, proof, com = o.r1cs_prove(okind, param, label, vals, 4000 + i, cap)
+        assert rc == 0
+        if i in (2, 41):
+            bad = bytearray(proof)
+            bad[8 + 64 * 11 + 5] ^= 1      # t_x
+            proof = bytes(bad)
+        recs.append((proof, com, vals[-nverify:] if nverify else []))
+    sessions = [o.VerifySession(okind, param, label, vv, com, proof, cap) for proof, com, vv in recs]
+    s0 = sessions[0]
+    rp, kd, ix, coeff = s0.csr()
+    pts = sc = ch = b""
+    for (proof, com, _), s in zip(recs, sessions):
+        k, p, q = bh.verify_inputs(proof, com)
+        pts += p
+        sc += q
+        ch += s.challenges()
+    want_ok = [1 if s.rc == 0 else 0 for s in sessions]
+    assert want_ok.count(0) == 2
+    for env in ({}, {"BPGPU_WINDOW_PARALLEL": "0"}, {"BPGPU_NO_FUSE": "1"}):
+        for kk in ("BPGPU_WINDOW_PARALLEL", "BPGPU_NO_FUSE"):
+            monkeypatch.delenv(kk, raising=False)
+        for kk, vv in env.items():
+            monkeypatch.setenv(kk, vv)
+        circ = gpu.circuit_create(rp, kd, ix, coeff, s0.n1 + s0.n2, s0.m)
+        g = _gens(gpu, cap, 8)
+        try:
+            ok, mega, full = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, True, True)
+            assert ok == want_ok, env
+            for i, s in enumerate(sessions):
+                assert mega[64 * i:64 * i + 64] == s.mega_check(), (env, i)
+                assert full[32 * s.nterms * i:32 * s.nterms * (i + 1)] == s.msm_terms()[0], (env, i)
+        finally:
+            gpu.gens_destroy(g)
+            gpu.circuit_destroy(circ)
+    for s in sessions:
+        s.close()
