@@ -6,6 +6,7 @@
 // The Rust toolchain is absent from the build image, so this mirror is C++ (the reference is
 // compiled code); INTEGRATION.md shows the Rust-side binding of the same C ABI.
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cstring>
 #include <cstdint>
@@ -194,6 +195,34 @@ struct Variable {                                                  // linear_com
   bool operator<(const Variable &o) const { return kind != o.kind ? kind < o.kind : index < o.index; }
   static Variable one() { return Variable{One, 0}; }
 };
+// terms of a linear combination, ordered by variable: a small sorted vector (the reference's HashMap; a node-based
+// map costs one allocation per term -- 2 x 10^6 of them when 256 provers build 2064 constraints each)
+class TermMap {
+ public:
+  typedef std::pair<Variable, Scalar> value_type;
+  typedef std::vector<value_type>::iterator iterator;
+  typedef std::vector<value_type>::const_iterator const_iterator;
+  iterator begin() { return v_.begin(); }
+  iterator end() { return v_.end(); }
+  const_iterator begin() const { return v_.begin(); }
+  const_iterator end() const { return v_.end(); }
+  size_t size() const { return v_.size(); }
+  iterator find(const Variable &k) { auto it = lower(k); return it != v_.end() && !(k < it->first) ? it : v_.end(); }
+  Scalar &operator[](const Variable &k) {
+    auto it = lower(k);
+    if (it == v_.end() || k < it->first) it = v_.insert(it, value_type(k, Scalar()));
+    return it->second;
+  }
+ private:
+  iterator lower(const Variable &k) {
+    if (v_.size() > 16)
+      return std::lower_bound(v_.begin(), v_.end(), k, [](const value_type &a, const Variable &b) { return a.first < b; });
+    auto it = v_.begin();
+    while (it != v_.end() && it->first < k) ++it;      // a handful of terms per row: linear beats binary
+    return it;
+  }
+  std::vector<value_type> v_;
+};
 class LinearCombination {                                          // linear_combination.rs:118-121
  public:
   LinearCombination() {}
@@ -204,7 +233,7 @@ class LinearCombination {                                          // linear_com
   LinearCombination operator-(const LinearCombination &o) const;
   LinearCombination operator-() const;
   LinearCombination operator*(const Scalar &s) const;
-  std::map<Variable, Scalar> terms;
+  TermMap terms;
 };
 inline LinearCombination operator*(const Variable &v, const Scalar &s) { LinearCombination l; l.terms[v] = s; return l; }
 
