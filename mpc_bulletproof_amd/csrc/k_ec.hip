@@ -479,7 +479,7 @@ static void launch_tabfix(hipStream_t st, const TablesArgs &t, unsigned tb, cons
 // The whole MSM + verdict of a batch in three launches (timed separately by the API's profile scopes).
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
   const size_t total = (2 + 2 * n) * (252 / c + 1);
-  return nb >= 64 && total <= 16384 && nvar && (c == 8 || c == 16 || c == 20);
+  return nb >= 1 && total <= 16384 && nvar && (c == 8 || c == 16 || c == 20);
 }
 static TablesArgs wp_args(const VerifyWp &v, JacRaw **winsum, unsigned *blocks) {
   TablesArgs t{};
