@@ -1225,7 +1225,12 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
     sc_dot_batched(st, nb, h, a, n, b + h, n, s->cLR, 2);        // c_L = <a_L, b_R>
     sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
     ipp_gens_scalars(st, nb, s->n0, n, a, b, s->cG, s->cH, s->cLR, s->w, s->msc);
-    CK(msm_gens_dev(ctx, s->gens, nb * 2, s->n0, (const uint32_t *)s->msc, s->sums, st));
+    {
+      size_t chunks = fixed_msm_ipp_chunks(s->gens->c, s->n0, nb * 2);
+      void *dpart = nullptr;
+      if (chunks > 1) CK(ws_get(ctx, 12, nb * 2 * chunks * sizeof(JacRaw), &dpart));
+      fixed_msm_ipp(st, s->gens->c, s->gens->table, s->n0, s->gens->cap, n, (const uint32_t *)s->msc, s->sums, nb * 2, (JacRaw *)dpart);
+    }
     jac_to_boundary(st, s->sums, out_xy, nb * 2);
     return launch_ok(ctx);
   }

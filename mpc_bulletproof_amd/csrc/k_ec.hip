@@ -583,6 +583,102 @@ void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars
   hipLaunchKernelGGL((k_fixed_single<16>), dim3((n + 63) / 64), dim3(64), 0, st, table, scalars, out, n);
 }
 
+// The L / R MSMs of an IPP round over resident generators (k_ipp_gens_scalars' compact layout: B, n0/2 G terms, n0/2 H
+// terms per MSM; MSM 2p = L_p, 2p + 1 = R_p).  Block (chunk, msm) as k_fixed_msm; only non-zero terms are walked.
+template <int C, int TPB>
+__global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size_t n0, size_t cap, size_t cur,
+                                                       const uint32_t *scalars, JacRaw *out, size_t pairs_per_chunk) {
+  __shared__ int32_t red[27 * (TPB / 2)];
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const int tid = threadIdx.x;
+  const size_t per = 1 + n0, half = n0 / 2, h = cur / 2;
+  const uint32_t *sc = scalars + (size_t)blockIdx.y * per * 8;
+  const bool is_R = (blockIdx.y & 1) != 0;
+  const size_t total = per * W;
+  const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
+  const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
+  Jac acc = jac_inf();
+  uint32_t curw[16];
+  int dcur = 0;
+  size_t l = lo + tid;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < hi) {
+      size_t t = ll / W;
+      int w = (int)(ll - t * W);
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = sc[t * 8 + k];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t gen = 0;                                    // B
+        if (t > 0) {
+          const bool isH = t - 1 >= half;
+          const size_t j = isH ? t - 1 - half : t - 1;
+          const bool use_hi = is_R ? isH : !isH;           // L: G_hi, H_lo;  R: G_lo, H_hi
+          const size_t i = (j / h) * cur + (use_hi ? h : 0) + j % h;
+          gen = (isH ? 2 + cap : 2) + i;
+        }
+        const AffDev *e = table + (gen * W + w) * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[k] = e->w[k];
+      }
+    }
+  };
+  fetch(l, curw, dcur);
+  while (l < hi) {
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + TPB, nxt, dnxt);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(curw);
+      q.y = unpack<FP>(curw + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) curw[k] = nxt[k];
+    dcur = dnxt;
+    l += TPB;
+  }
+  acc = block_sum<TPB>(acc, red);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
+  size_t total = (1 + n0) * (252 / c + 1);
+  size_t by_work = (total + 511) / 512, by_fill = (2048 + nmsm - 1) / (nmsm ? nmsm : 1);
+  size_t ch = by_work < by_fill ? by_work : by_fill;
+  return ch ? ch : 1;
+}
+template <int C>
+static void launch_fixed_ipp(hipStream_t st, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                             JacRaw *dst, size_t nmsm, size_t chunks) {
+  size_t total = (1 + n0) * num_windows<C>();
+  size_t per = (total + chunks - 1) / chunks;
+  hipLaunchKernelGGL((k_fixed_msm_ipp<C, 128>), dim3(chunks, nmsm), dim3(128), 0, st, table, n0, cap, cur, scalars, dst, per);
+}
+// partials: nmsm * fixed_msm_ipp_chunks(c, n0, nmsm) points (unused when that is 1)
+void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                   JacRaw *out, size_t nmsm, JacRaw *partials) {
+  if (!nmsm) return;
+  size_t chunks = partials ? fixed_msm_ipp_chunks(c, n0, nmsm) : 1;
+  JacRaw *dst = chunks > 1 ? partials : out;
+  switch (c) {
+    case 4: launch_fixed_ipp<4>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 8: launch_fixed_ipp<8>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 10: launch_fixed_ipp<10>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 12: launch_fixed_ipp<12>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 14: launch_fixed_ipp<14>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 16: launch_fixed_ipp<16>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 20: launch_fixed_ipp<20>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    default: return;
+  }
+  if (chunks > 1) segmented_sum(st, partials, out, nmsm, chunks);
+}
+
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
 size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
   size_t total = (2 + 2 * n) * (252 / c + 1);

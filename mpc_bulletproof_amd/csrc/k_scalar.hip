@@ -288,35 +288,31 @@ void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, si
 // sum over the original i == t (mod cur) of cG_i * G_i, so the round's L and R (inner_product_proof.rs:90-114,
 // 159-172) are MSMs over the ORIGINAL generators with scalars a_.. * cG_i / b_.. * cH_i -- table lookups
 // without a single doubling -- and the fold of G, H (:125-146, 202-248) becomes a scalar update of cG, cH.
-// msc layout: [proof][L | R][B, B_blinding, G_0..G_{n0-1}, H_0..H_{n0-1}];  Q = w * B.
+// msc layout, compact (only the non-zero terms): [proof][L | R][1 + n0] = B scalar (c * w, Q = w * B), n0/2 G terms,
+// n0/2 H terms.  With h = cur / 2 the j-th "hi" generator index is (j / h) cur + h + j % h, the j-th "lo" one
+// (j / h) cur + j % h;  L uses G_hi and H_lo, R uses G_lo and H_hi (k_fixed_msm_ipp applies the same enumeration).
 __global__ void __launch_bounds__(256) k_ipp_gens_scalars(size_t n0, size_t cur, const Words8 *a, const Words8 *b,
                                                           const Words8 *cG, const Words8 *cH, const Words8 *cLR,
                                                           const Words8 *w, Words8 *msc) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
   if (i >= n0) return;
-  const size_t h = cur / 2, t = i & (cur - 1), tl = t & (h - 1), per = 2 + 2 * n0;
+  const size_t h = cur / 2, t = i & (cur - 1), tl = t & (h - 1), per = 1 + n0, half = n0 / 2;
   const bool hi = t >= h;
+  const size_t j = (i / cur) * h + tl;            // rank of i among the hi (or lo) indices
   const Words8 *ap = a + p * cur, *bp = b + p * cur;
   Words8 *L = msc + (p * 2) * per, *R = L + per;
   Fn cg = load_plain(&cG[p * n0 + i]), ch = load_plain(&cH[p * n0 + i]);
-  Fn zero = fe_zero<FN>();
   if (hi) {
-    store_plain(&L[2 + i], mul(load_plain(&ap[tl]), cg));        // <a_L, G_R>
-    store_plain(&L[2 + n0 + i], zero);
-    store_plain(&R[2 + i], zero);
-    store_plain(&R[2 + n0 + i], mul(load_plain(&bp[tl]), ch));   // <b_L, H_R>
+    store_plain(&L[1 + j], mul(load_plain(&ap[tl]), cg));            // <a_L, G_R>
+    store_plain(&R[1 + half + j], mul(load_plain(&bp[tl]), ch));     // <b_L, H_R>
   } else {
-    store_plain(&L[2 + i], zero);
-    store_plain(&L[2 + n0 + i], mul(load_plain(&bp[h + tl]), ch));   // <b_R, H_L>
-    store_plain(&R[2 + i], mul(load_plain(&ap[h + tl]), cg));        // <a_R, G_L>
-    store_plain(&R[2 + n0 + i], zero);
+    store_plain(&L[1 + half + j], mul(load_plain(&bp[h + tl]), ch)); // <b_R, H_L>
+    store_plain(&R[1 + j], mul(load_plain(&ap[h + tl]), cg));        // <a_R, G_L>
   }
   if (i == 0) {
     Fn ww = load_plain(&w[p]);
     store_plain(&L[0], mul(load_plain(&cLR[2 * p]), ww));       // c_L * Q
-    store_plain(&L[1], zero);
     store_plain(&R[0], mul(load_plain(&cLR[2 * p + 1]), ww));   // c_R * Q
-    store_plain(&R[1], zero);
   }
 }
 void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,

@@ -84,6 +84,10 @@ void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, 
 // partials: scratch of nb * fixed_msm_chunks(c, n, nb) points (NULL: one block per MSM).
 // out[i] = scalars[i] * (generator 0 of a c = 16 table), one lane per scalar
 void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n);
+// L / R MSMs of an IPP round over resident generators, compact scalars (k_ipp_gens_scalars)
+size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm);
+void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                   JacRaw *out, size_t nmsm, JacRaw *partials);
 size_t fixed_msm_chunks(int c, size_t n, size_t nb);
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
                size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials);
