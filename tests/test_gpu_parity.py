@@ -599,6 +599,18 @@ def test_verify_batch_full_size_1024x64bit(gpu):
         clean_sc = b"".join(base[j % distinct][1] for j in range(nb))
         assert gpu.r1cs_verify_combined(g, circ, nb, 64, 6, 1, pts, clean_sc, ch, rho) == bytes(64)
         assert gpu.r1cs_verify_combined(g, circ, nb, 64, 6, 1, pts, sc, ch, rho) != bytes(64)
+        # a batch size that fills neither the last 4-proof block of the fixed-base lanes nor the last table wave,
+        # over 16-bit-window tables (the bench uses 20-bit ones: same kernels, other template instance)
+        nb2 = 1027
+        g16 = _gens(gpu, cap, 16)
+        try:
+            p2 = pts + pts[:3 * len(base[0][0])]
+            s2 = sc + sc[:3 * 160]
+            c2 = ch + ch[:3 * len(base[0][2])]
+            ok2, mega2, _ = gpu.r1cs_verify_batch(g16, circ, nb2, 64, 6, 1, p2, s2, c2, want_mega=True)
+            assert ok2 == ok + ok[:3] and mega2 == mega + mega[:3 * 64]
+        finally:
+            gpu.gens_destroy(g16)
     finally:
         gpu.gens_destroy(g)
         gpu.circuit_destroy(circ)
