@@ -1321,14 +1321,21 @@ static int ipp_fold_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *du, Words8 *dui) {
     g.sc[0] = (uint32_t *)dui; g.sc[1] = (uint32_t *)du; hh.sc[0] = (uint32_t *)du; hh.sc[1] = (uint32_t *)dui;
     for (int j = 0; j < 2; j++) { g.sc_stride[j] = hh.sc_stride[j] = 0; g.sc_outer[j] = hh.sc_outer[j] = 8; }
   }
-  void *dstr;
+  // the G and the H fold are independent 252-doubling chains: run them side by side on the context's two streams
+  void *dstr, *dstr2;
   CK(straus_ws(ctx, 2, nb * h, &dstr));
+  CK(ws_get(ctx, 12, straus_scratch_bytes(2, nb * h), &dstr2));
+  hipStream_t st2 = ctx->st2;
+  HIPCK(ctx, hipEventRecord(ctx->ev1, st));
+  HIPCK(ctx, hipStreamWaitEvent(st2, ctx->ev1, 0));
   straus(st, 2, g, fres, nb * h, dstr);
-  straus(st, 2, hh, fres + nb * h, nb * h, dstr);
+  straus(st2, 2, hh, fres + nb * h, nb * h, dstr2);
   // when the input generators are shared the folded ones become per-proof: write them to buffer nxt
   batch_normalize(st, fres, s->G[nxt], nb * h, 8);
-  batch_normalize(st, fres + nb * h, s->H[nxt], nb * h, 8);
+  batch_normalize(st2, fres + nb * h, s->H[nxt], nb * h, 8);
+  HIPCK(ctx, hipEventRecord(ctx->ev2, st2));
   fold_scalars_batched(st, nb, h, du, dui, s->a[cur], s->b[cur], s->a[nxt], s->b[nxt]);
+  HIPCK(ctx, hipStreamWaitEvent(st, ctx->ev2, 0));
   s->cur = nxt; s->n = h; s->first = false;
   return launch_ok(ctx);
 }

@@ -66,7 +66,7 @@ int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_le
                    uint8_t *commitments_out, size_t *m_out) {
   GUARD({
     PedersenGens pc_gens;
-    BulletproofGens bp_gens(gens_capacity, 1);
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);   // kept alive as a caller would (generators + tables)
     Transcript transcript = start_transcript(kind, param, label, label_len);
     Prover prover(pc_gens, transcript);
     Rng rng(seed);
@@ -111,7 +111,7 @@ int bph_r1cs_verify(int kind, size_t param, const uint8_t *label, size_t label_l
                     size_t gens_capacity, uint8_t mega_out[64]) {
   GUARD({
     PedersenGens pc_gens;
-    BulletproofGens bp_gens(gens_capacity, 1);
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);   // kept alive as a caller would (generators + tables)
     Transcript transcript = start_transcript(kind, param, label, label_len);
     Verifier verifier(pc_gens, transcript);
     std::vector<Variable> vars;
@@ -220,7 +220,7 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
     };
     const char *label = "ShuffleProofTest";
     PedersenGens pc_gens;
-    BulletproofGens bp_gens(gens_capacity, 1);
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);   // kept alive as a caller would (generators + tables)
     lap();
     Rng rng(seed);
     std::vector<Scalar> vs, bls;

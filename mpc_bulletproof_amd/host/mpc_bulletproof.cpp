@@ -545,6 +545,25 @@ InnerProductProof InnerProductProof::create(Transcript &transcript, const StarkP
   d.check(bpgpu_ipp_begin(d.ctx(), 1, n, Q.xy.data(), pgf.data(), phf.data(), pG.data(), pH.data(), 1, pa.data(), pb.data(), &s),
           "bpgpu_ipp_begin");
   try {
+    if (!getenv("BPH_HOST_IPP_TRANSCRIPT")) {   // all rounds on the device, hash chain included (bpgpu_ipp_run_fs)
+      size_t k = 0;
+      for (size_t t = n; t > 1; t >>= 1) k++;
+      std::vector<uint8_t> L(k * 64 + 1), R(k * 64 + 1);
+      uint8_t st_out[32], a[32], b[32];
+      d.check(bpgpu_ipp_run_fs(d.ctx(), s, transcript.state(), L.data(), R.data(), a, b, st_out), "bpgpu_ipp_run_fs");
+      transcript.set_state(st_out);
+      for (size_t r = 0; r < k; r++) {
+        StarkPoint Lp, Rp;
+        memcpy(Lp.xy.data(), &L[64 * r], 64);
+        memcpy(Rp.xy.data(), &R[64 * r], 64);
+        proof.L_vec.push_back(Lp);
+        proof.R_vec.push_back(Rp);
+      }
+      proof.a = Scalar::from_bytes_le(a);
+      proof.b = Scalar::from_bytes_le(b);
+      bpgpu_ipp_destroy(d.ctx(), s);
+      return proof;
+    }
     while (bpgpu_ipp_len(s) > 1) {
       StarkPoint L, R;
       d.check(bpgpu_ipp_round(d.ctx(), s, L.xy.data(), R.xy.data()), "bpgpu_ipp_round");
