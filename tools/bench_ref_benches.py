@@ -2,7 +2,8 @@
 """The reference's own criterion benches restated against the GPU path (SURVEY 8d "Micro"):
   * benches/inner_product.rs  "ipp-prover"  n = 2^1 .. 2^16: InnerProductProof::create with random generators and
     factors (the literal schedule: generators given per call, folded every round, transcript on the host);
-  * benches/r1cs.rs  "prover" / "verifier"  dummy circuit of n = 2^1 .. 2^10 multiplications (benches/r1cs.rs:24-33).
+  * benches/r1cs.rs  "prover" / "verifier"  dummy circuit of n = 2^1 .. 2^10 multiplications (benches/r1cs.rs:24-33);
+  * benches/generators.rs  "BulletproofGens::new"  sizes 2 << i, i < 10 (and 2^15 for the shuffle).
 Through the host C++ mirror over the C ABI; wall clock per call after one warm-up call.  The CPU column is the oracle's
 single-thread restatement on the smaller sizes."""
 import ctypes as C
@@ -76,3 +77,21 @@ for lg in range(1, 11):
     print(f"n=2^{lg:<2d} prove {tp * 1e3:8.2f} ms  verify {tv * 1e3:8.2f} ms   cpu-oracle prove 1T {tc * 1e3:8.1f} ms   proof bytes {'identical' if same else 'DIFFER'}")
     assert same
     sys.stdout.flush()
+
+print("== generators / BulletproofGens::new(size, 1)")
+for size in [2 << i for i in range(10)] + [1 << 15]:
+    out = (C.c_uint8 * (64 * size))()
+    assert host.bph_gens(ord("G"), 0, C.c_size_t(size), out) == 0
+    t0 = time.perf_counter()
+    for _ in range(3):
+        assert host.bph_gens(ord("G"), 0, C.c_size_t(size), out) == 0
+    tg = (time.perf_counter() - t0) / 3
+    line = f"size={size:6d} gpu {tg * 1e3:8.2f} ms (G and H chains of `size` generators each)"
+    if size <= 1024:
+        t0 = time.perf_counter()
+        ref = o.gens("G", size)
+        o.gens("H", size)
+        tc = time.perf_counter() - t0
+        assert bytes(out) == ref
+        line += f"   cpu-oracle 1T {tc * 1e3:8.1f} ms  x{tc / tg:6.1f}   (bytes identical)"
+    print(line)
