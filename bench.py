@@ -52,9 +52,13 @@ def _gen_workload(path, nb, seed0):
     arr = (C.c_uint64 * nb)(*vals)
     lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
     proofs, coms, plen = (C.c_uint8 * (nb * 4096))(), (C.c_uint8 * (nb * 64))(), C.c_size_t(0)
-    rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(1), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr,
-                                    C.c_uint64(seed0), C.c_size_t(N_BITS), proofs, C.byref(plen), coms)
-    assert rc == 0, f"bph_range_prove_batch rc={rc}"
+    prove_s = None
+    for rep in range(2):      # the second call has its workspaces and generator tables in place: that one is timed
+        t0 = time.perf_counter()
+        rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(1), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr,
+                                        C.c_uint64(seed0), C.c_size_t(N_BITS), proofs, C.byref(plen), coms)
+        prove_s = time.perf_counter() - t0
+        assert rc == 0, f"bph_range_prove_batch rc={rc}"
     pl = plen.value
     k = N_BITS.bit_length() - 1
     nvar = 11 + 1 + 2 * k
@@ -83,7 +87,7 @@ def _gen_workload(path, nb, seed0):
           "proofs": bytes(proofs)[:nb * pl], "proof_len": pl, "commitments": bytes(coms), "points": bytes(pts),
           "scalars": bytes(sc), "challenges": bytes(ch), "init_state": bytes(init), "dims": (n1, n - n1, k, m),
           "csr": (list(rp)[:q + 1], list(kind)[:nnz], list(idx)[:nnz], bytes(coeff)[:32 * nnz]),
-          "G": bytes(G), "H": bytes(H), "B": bytes(B)}
+          "G": bytes(G), "H": bytes(H), "B": bytes(B), "prove_seconds": prove_s}
     tmp = path + f".tmp{os.getpid()}"
     with open(tmp, "wb") as f:
         pickle.dump(wl, f)
@@ -422,6 +426,9 @@ def main():
             "from_wire_format": wire,
             "combined_batch_check": comb,
             "r1cs_prove": prove,
+            "range_prove": ({"value": nb / wl["prove_seconds"], "unit": "64-bit range proofs/s", "ms_per_batch": wl["prove_seconds"] * 1e3,
+                             "note": f"the {nb} proofs of this workload, proved in lock-step by the GPU prover while it was generated "
+                                     "(wall clock incl. host circuit building and transcripts)"} if wl.get("prove_seconds") else None),
         }
         print(json.dumps(out))
     if world > 1:
