@@ -1,0 +1,78 @@
+// fixed_body.cuh -- the small fixed-base MSM body shared by k_fixed.hip (stand-alone launches) and k_ec.hip (fused with
+// the proof-point kernels of a verification batch).
+#pragma once
+#include "ec_dev.cuh"
+
+namespace bpk {
+using namespace bp;
+
+// Many small MSMs (the 130-generator part of a range-proof verification): LPM lanes per MSM, 64/LPM MSMs per
+// wave, lanes combined with a wave-shuffle butterfly.  Against one 128-lane block per MSM this removes the LDS
+// tree (7 levels of full-wave point additions for ~16 table additions per lane).
+template <int C, int LPM>
+__device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                 size_t sc_stride, JacRaw *out, size_t nb, size_t blk) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const int lane = threadIdx.x & (LPM - 1);
+  size_t b = blk * (64 / LPM) + (threadIdx.x / LPM);
+  const bool live = b < nb;
+  if (!live) b = nb - 1;
+  const uint32_t *sc = scalars + b * sc_stride;
+  const size_t total = (2 + 2 * n) * W;
+  const size_t hshift = cap - n;
+  Jac acc = jac_inf();
+  uint32_t cur[16];
+  int dcur = 0;
+  size_t l = lane;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < total) {
+      size_t g = ll / W;
+      int w = (int)(ll - g * W);
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t row = (g < 2 + n ? g : g + hshift) * W + w;
+        const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int t = 0; t < 16; t++) dst[t] = e->w[t];
+      }
+    }
+  };
+  fetch(l, cur, dcur);
+  while (l < total) {
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + LPM, nxt, dnxt);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(cur);
+      q.y = unpack<FP>(cur + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
+    dcur = dnxt;
+    l += LPM;
+  }
+#pragma unroll 1
+  for (int off = LPM / 2; off > 0; off >>= 1) {
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
+    }
+    acc = jac_add(acc, q);
+  }
+  if (lane == 0 && live) raw_store(&out[b], acc);
+}
+struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
+
+}  // namespace bpk

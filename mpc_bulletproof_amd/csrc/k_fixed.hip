@@ -1,0 +1,240 @@
+// k_fixed.hip -- fixed-base (table-lookup) multi-scalar multiplication over the resident generators: no doublings,
+// ceil(253 / c) mixed additions per term.  SURVEY.md 8a rows a1 (generator part), a3, a10; split from k_ec.hip so that
+// the two translation units compile in parallel.
+#include <cstdlib>
+#include "fixed_body.cuh"
+
+using namespace bp;
+
+namespace bpk {
+
+// Block (chunk, msm): lane l walks the (generator, window) pairs l, l+TPB, ... of its chunk.  The MSM uses the
+// generators [B, Bb, G_0..G_{n-1}, H_0..H_{n-1}] of a table built for capacity cap >= n: used generator g lives
+// in table row block g (g < 2 + n) or g + (cap - n) (the H section); scalars are compact (2 + 2n per MSM).
+template <int C, int TPB>
+__global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                   size_t sc_stride, JacRaw *out, size_t pairs_per_chunk) {
+  __shared__ int32_t red[27 * (TPB / 2)];
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const int tid = threadIdx.x;
+  const uint32_t *sc = scalars + (size_t)blockIdx.y * sc_stride;
+  const size_t total = (2 + 2 * n) * W;
+  const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
+  const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
+  const size_t hshift = cap - n;
+  Jac acc = jac_inf();
+  // software prefetch of the next table row while the current madd runs.  The scalar words come from
+  // L1/L2 (the W lanes of one generator read the same 32 bytes) and are recoded on the fly: staging all
+  // recoded scalars in LDS needs 36 B per generator -- 81 KB at capacity 1024, past the 64 KB dynamic limit.
+  uint32_t cur[16];
+  int dcur = 0;
+  size_t l = lo + tid;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < hi) {
+      size_t g = ll / W;
+      int w = (int)(ll - g * W);
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t row = (g < 2 + n ? g : g + hshift) * W + w;
+        const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int t = 0; t < 16; t++) dst[t] = e->w[t];
+      }
+    }
+  };
+  fetch(l, cur, dcur);
+  while (l < hi) {
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + TPB, nxt, dnxt);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(cur);
+      q.y = unpack<FP>(cur + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
+    dcur = dnxt;
+    l += TPB;
+  }
+  acc = block_sum<TPB>(acc, red);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+template <int C, int LPM>
+__global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+                                                        size_t sc_stride, JacRaw *out, size_t nb) {
+  fixed_small_body<C, LPM>(table, n, cap, scalars, sc_stride, out, nb, blockIdx.x);
+}
+// out[i] = scalars[i] * P_0 by table lookups, one lane per scalar (GeneratorsChain::next, generators.rs:112-124:
+// every Bulletproofs generator is a hashed scalar times the curve generator -- SURVEY 8f N2)
+template <int C>
+__global__ void __launch_bounds__(64) k_fixed_single(const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t s[8], r[9];
+#pragma unroll
+  for (int t = 0; t < 8; t++) s[t] = scalars[i * 8 + t];
+  recode_add_k<C>(r, s);
+  Jac acc = jac_inf();
+#pragma unroll 1
+  for (int w = 0; w < W; w++) {
+    int dg = recode_digit<C>(r, w);
+    if (dg != 0) {
+      Aff q = aff_load(table + (size_t)w * HALF + ((dg < 0 ? -dg : dg) - 1));
+      if (dg < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+  }
+  raw_store(&out[i], acc);
+}
+void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars, JacRaw *out, size_t n) {
+  if (!n) return;
+  hipLaunchKernelGGL((k_fixed_single<16>), dim3((n + 63) / 64), dim3(64), 0, st, table, scalars, out, n);
+}
+
+// The L / R MSMs of an IPP round over resident generators (k_ipp_gens_scalars' compact layout: B, n0/2 G terms, n0/2 H
+// terms per MSM; MSM 2p = L_p, 2p + 1 = R_p).  Block (chunk, msm) as k_fixed_msm; only non-zero terms are walked.
+template <int C, int TPB>
+__global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size_t n0, size_t cap, size_t cur,
+                                                       const uint32_t *scalars, JacRaw *out, size_t pairs_per_chunk) {
+  __shared__ int32_t red[27 * (TPB / 2)];
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const int tid = threadIdx.x;
+  const size_t per = 1 + n0, half = n0 / 2, h = cur / 2;
+  const uint32_t *sc = scalars + (size_t)blockIdx.y * per * 8;
+  const bool is_R = (blockIdx.y & 1) != 0;
+  const size_t total = per * W;
+  const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
+  const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
+  Jac acc = jac_inf();
+  uint32_t curw[16];
+  int dcur = 0;
+  size_t l = lo + tid;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < hi) {
+      size_t t = ll / W;
+      int w = (int)(ll - t * W);
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = sc[t * 8 + k];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t gen = 0;                                    // B
+        if (t > 0) {
+          const bool isH = t - 1 >= half;
+          const size_t j = isH ? t - 1 - half : t - 1;
+          const bool use_hi = is_R ? isH : !isH;           // L: G_hi, H_lo;  R: G_lo, H_hi
+          const size_t i = (j / h) * cur + (use_hi ? h : 0) + j % h;
+          gen = (isH ? 2 + cap : 2) + i;
+        }
+        const AffDev *e = table + (gen * W + w) * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[k] = e->w[k];
+      }
+    }
+  };
+  fetch(l, curw, dcur);
+  while (l < hi) {
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + TPB, nxt, dnxt);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(curw);
+      q.y = unpack<FP>(curw + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd(acc, q);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) curw[k] = nxt[k];
+    dcur = dnxt;
+    l += TPB;
+  }
+  acc = block_sum<TPB>(acc, red);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+}
+size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
+  size_t total = (1 + n0) * (252 / c + 1);
+  size_t by_work = (total + 511) / 512, by_fill = (2048 + nmsm - 1) / (nmsm ? nmsm : 1);
+  size_t ch = by_work < by_fill ? by_work : by_fill;
+  return ch ? ch : 1;
+}
+template <int C>
+static void launch_fixed_ipp(hipStream_t st, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                             JacRaw *dst, size_t nmsm, size_t chunks) {
+  size_t total = (1 + n0) * num_windows<C>();
+  size_t per = (total + chunks - 1) / chunks;
+  hipLaunchKernelGGL((k_fixed_msm_ipp<C, 128>), dim3(chunks, nmsm), dim3(128), 0, st, table, n0, cap, cur, scalars, dst, per);
+}
+// partials: nmsm * fixed_msm_ipp_chunks(c, n0, nmsm) points (unused when that is 1)
+void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                   JacRaw *out, size_t nmsm, JacRaw *partials) {
+  if (!nmsm) return;
+  size_t chunks = partials ? fixed_msm_ipp_chunks(c, n0, nmsm) : 1;
+  JacRaw *dst = chunks > 1 ? partials : out;
+  switch (c) {
+    case 4: launch_fixed_ipp<4>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 8: launch_fixed_ipp<8>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 10: launch_fixed_ipp<10>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 12: launch_fixed_ipp<12>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 14: launch_fixed_ipp<14>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 16: launch_fixed_ipp<16>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    case 20: launch_fixed_ipp<20>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
+    default: return;
+  }
+  if (chunks > 1) segmented_sum(st, partials, out, nmsm, chunks);
+}
+
+// chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
+size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
+  size_t total = (2 + 2 * n) * (252 / c + 1);
+  size_t by_work = (total + 511) / 512, by_fill = (1024 + nb - 1) / (nb ? nb : 1);
+  size_t ch = by_work < by_fill ? by_work : by_fill;
+  return ch ? ch : 1;
+}
+template <int C>
+static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t stride,
+                         JacRaw *out, size_t nb, size_t chunks) {
+  constexpr int TPB = 128;
+  size_t total = (2 + 2 * n) * num_windows<C>();
+  static const int small_env = getenv("BPGPU_FIXED_SMALL") ? atoi(getenv("BPGPU_FIXED_SMALL")) : 1;
+  if (small_env && chunks == 1 && nb >= 64 && total <= 16384) {
+    if (nb >= 1024) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    else hipLaunchKernelGGL((k_fixed_msm_small<C, 32>), dim3((nb + 1) / 2), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    return;
+  }
+  size_t per = (total + chunks - 1) / chunks;
+  hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(chunks, nb), dim3(TPB), 0, st, table, n, cap, scalars, stride, out, per);
+}
+void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
+               size_t stride, JacRaw *out, size_t nb, JacRaw *partials) {
+  if (!nb) return;
+  size_t chunks = partials ? fixed_msm_chunks(c, n, nb) : 1;
+  JacRaw *dst = chunks > 1 ? partials : out;
+  switch (c) {
+    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    default: return;   // rejected by the C-ABI before reaching here
+  }
+  if (chunks > 1) segmented_sum(st, partials, out, nb, chunks);
+}
+
+}  // namespace bpk
