@@ -104,9 +104,11 @@ def _cpu_verify_chunk(args):
 
 
 def main():
-    # deep step pipelining needs hardware queues (ROCm default: 4; measured: 16 queues/16 steps in flight 2.88 M/s,
-    # 24/24 3.08 M/s, 32/32 3.12 M/s, 32/48 2.71 M/s, 64/64 2.89 M/s) and is better with one stream per context
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    # deep step pipelining needs hardware queues (ROCm default: 4) and is better with one stream per context.  16 queues /
+    # 16 steps in flight: bursts start at full speed (tools/burst_probe.py: 32 steps after a device sync take 15 ms,
+    # 4096 steps run at 3.00 M/s).  With 32 / 32 the steady state is the same within noise (3.03 M/s) but every burst
+    # pays ~60 ms first (32 steps: 73 ms) -- the hardware queues are oversubscribed -- so short runs under-report.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -116,7 +118,7 @@ def main():
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "20")),
                     help="window of the resident generator tables: 20 bits = 13 table additions per generator term, a 57 GB "
                          "table for the 130 generators of the 64-bit gadget (16 bits: 16 additions, 4.5 GB)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "32")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,20 +211,37 @@ def main():
         ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[i])
 
     def sync_all():
-        for c in ctxs:
-            c.sync()
+        # one device-wide synchronisation (the contexts' streams are ordinary blocking HIP streams of this device);
+        # a hipStreamSynchronize per context costs ~0.15 ms each on an idle stream: ~10 ms for 32 contexts
+        torch.cuda.synchronize()
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    # warm-up: at least one step per context, with the per-kernel HIP-event timing already on (the first event
+    # records on a stream cost milliseconds) -- its timings are read and discarded before the timed region
+    for c in ctxs:
+        c.profile_enable(not os.environ.get("BPGPU_BENCH_NOPROF"))
     for _ in range(max(a.warmup, len(ctxs))):
         step()
     sync_all()
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb and c.input_flag() == 0, "GPU verification disagrees"
-        c.profile_enable(True)
+        c.profile_read()
+    # the checks above leave the GPU idle for milliseconds
+    # ... so the warm-up keeps submitting steps (untimed) for BPGPU_WARM_SECONDS of wall time right up to the fence that
+    # starts the timed region.
+    warm_s = float(os.environ.get("BPGPU_WARM_SECONDS", "0.3"))
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < warm_s:
+        for _ in range(2 * len(ctxs)):
+            step()
+    sync_all()
+    for c in ctxs:
+        c.profile_read()
+    counter[0] = 0
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
@@ -383,7 +402,7 @@ def main():
         ms, cnt = prof[dom]
         avg_s = ms / max(cnt, 1) / 1e3
         alg_bytes = nb * bytes_per_proof[dom]
-        achieved = alg_bytes / avg_s / 1e9
+        achieved = alg_bytes / avg_s / 1e9 if avg_s else 0.0     # 0 only when event timing is switched off
         # integer roofline: algorithmic F_p multiplications x 94 limb MADs each (csrc/fe29.cuh), per step.
         # window-parallel: per non-identity proof point 7 table additions + 60 window additions (mixed, 11 mul), one
         # inversion per 8 points (~310), per proof 252 doublings (9) + 64 additions (16) in the Horner pass;

@@ -43,10 +43,18 @@ BP_HD Jac jac_from_aff(const Aff &a) {
 BP_HD Aff aff_neg(const Aff &a) { Aff r; r.x = a.x; r.y = neg(a.y); return r; }
 BP_HD Jac jac_neg(const Jac &a) { Jac r = a; r.Y = neg(a.Y); return r; }
 
+// The group law comes in two copies.  `*_full` is complete (P+P, P+(-P), order-2 input) and exact; on the device it
+// is ONE out-of-line function per code object, reached only when the one-limb filter fp_maybe_zero() fires
+// (probability 33 / 2^29 for an honest operand pair).  The inlined hot path below keeps just the filter: without the
+// canonicalisation and the nested doubling of the rare branch it is a third smaller and needs far fewer registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_COLD static __device__ __noinline__
+#else
+#define BP_COLD inline
+#endif
+
 // dbl-2007-bl with a = 1 and Z3 = 2*Y*Z: 7S + 2M
-BP_HD Jac jac_dbl(const Jac &p) {
-  if (jac_is_inf(p)) return jac_inf();
-  if (fp_maybe_zero(p.Y) && is_zero_exact(p.Y)) return jac_inf();   // order-2 points do not exist (odd order), kept for completeness
+BP_HD Jac jac_dbl_fast(const Jac &p) {
   Fp XX = fpsqr(p.X), YY = fpsqr(p.Y), YYYY = fpsqr(YY), ZZ = fpsqr(p.Z);
   Fp t = fpsqr(add(p.X, YY));
   Fp S = mul_small<2>(norm(sub_nr(sub_nr(t, XX), YYYY)));
@@ -58,47 +66,92 @@ BP_HD Jac jac_dbl(const Jac &p) {
   r.Z = mul_small<2>(fpmul(p.Y, p.Z));
   return r;
 }
+BP_COLD void jac_dbl_full(Jac *out, const Jac *pp) {
+  const Jac p = *pp;
+  if (jac_is_inf(p) || is_zero_exact(p.Y)) { *out = jac_inf(); return; }   // order-2 points do not exist (odd order), kept for completeness
+  *out = jac_dbl_fast(p);
+}
+BP_HD Jac jac_dbl(const Jac &p) {
+  if (jac_is_inf(p)) return jac_inf();
+  if (fp_maybe_zero(p.Y)) { Jac pc = p, r; jac_dbl_full(&r, &pc); return r; }
+  return jac_dbl_fast(p);
+}
 
 // mixed addition (Z2 = 1): 8M + 3S
-BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
-  if (aff_is_inf(q)) return p;
-  if (jac_is_inf(p)) { Jac r; r.X = q.x; r.Y = q.y; r.Z = fe_one<FP>(); return r; }
+struct MaddMid { Fp H, rr; };
+BP_HD MaddMid jac_madd_mid(const Jac &p, const Aff &q) {
+  MaddMid m;
   Fp Z1Z1 = fpsqr(p.Z);
   Fp U2 = fpmul(q.x, Z1Z1);
   Fp S2 = fpmul(q.y, fpmul(p.Z, Z1Z1));
-  Fp H = sub(U2, p.X);
-  Fp rr = sub(S2, p.Y);
-  if (fp_maybe_zero(H) && is_zero_exact(H)) {
-    if (is_zero_exact(rr)) { Jac t; t.X = q.x; t.Y = q.y; t.Z = fe_one<FP>(); return jac_dbl(t); }
-    return jac_inf();
-  }
-  Fp HH = fpsqr(H), HHH = fpmul(H, HH), V = fpmul(p.X, HH);
+  m.H = sub(U2, p.X);
+  m.rr = sub(S2, p.Y);
+  return m;
+}
+BP_HD Jac jac_madd_tail(const Jac &p, const MaddMid &m) {
+  Fp HH = fpsqr(m.H), HHH = fpmul(m.H, HH), V = fpmul(p.X, HH);
   Jac r;
-  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(rr), HHH), V), V));
-  r.Y = sub(fpmul(rr, sub(V, r.X)), fpmul(p.Y, HHH));
-  r.Z = fpmul(p.Z, H);
+  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(m.rr), HHH), V), V));
+  r.Y = sub(fpmul(m.rr, sub(V, r.X)), fpmul(p.Y, HHH));
+  r.Z = fpmul(p.Z, m.H);
   return r;
+}
+BP_COLD void jac_madd_full(Jac *out, const Jac *pp, const Aff *qq) {
+  const Jac p = *pp;
+  const Aff q = *qq;
+  MaddMid m = jac_madd_mid(p, q);
+  if (is_zero_exact(m.H)) {
+    if (is_zero_exact(m.rr)) { Jac t; t.X = q.x; t.Y = q.y; t.Z = fe_one<FP>(); *out = jac_dbl_fast(t); return; }   // y != 0: odd order
+    *out = jac_inf();
+    return;
+  }
+  *out = jac_madd_tail(p, m);
+}
+BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
+  if (aff_is_inf(q)) return p;
+  if (jac_is_inf(p)) { Jac r; r.X = q.x; r.Y = q.y; r.Z = fe_one<FP>(); return r; }
+  MaddMid m = jac_madd_mid(p, q);
+  if (fp_maybe_zero(m.H)) { Jac pc = p, r; Aff qc = q; jac_madd_full(&r, &pc, &qc); return r; }
+  return jac_madd_tail(p, m);
 }
 
 // general addition: 12M + 4S
+struct AddMid { Fp U1, S1, H, rr; };
+BP_HD AddMid jac_add_mid(const Jac &p, const Jac &q) {
+  AddMid m;
+  Fp Z1Z1 = fpsqr(p.Z), Z2Z2 = fpsqr(q.Z);
+  m.U1 = fpmul(p.X, Z2Z2);
+  Fp U2 = fpmul(q.X, Z1Z1);
+  m.S1 = fpmul(p.Y, fpmul(q.Z, Z2Z2));
+  Fp S2 = fpmul(q.Y, fpmul(p.Z, Z1Z1));
+  m.H = sub(U2, m.U1);
+  m.rr = sub(S2, m.S1);
+  return m;
+}
+BP_HD Jac jac_add_tail(const Jac &p, const Jac &q, const AddMid &m) {
+  Fp HH = fpsqr(m.H), HHH = fpmul(m.H, HH), V = fpmul(m.U1, HH);
+  Jac r;
+  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(m.rr), HHH), V), V));
+  r.Y = sub(fpmul(m.rr, sub(V, r.X)), fpmul(m.S1, HHH));
+  r.Z = fpmul(fpmul(p.Z, q.Z), m.H);
+  return r;
+}
+BP_COLD void jac_add_full(Jac *out, const Jac *pp, const Jac *qq) {
+  const Jac p = *pp, q = *qq;
+  AddMid m = jac_add_mid(p, q);
+  if (is_zero_exact(m.H)) {
+    if (is_zero_exact(m.rr)) { jac_dbl_full(out, pp); return; }
+    *out = jac_inf();
+    return;
+  }
+  *out = jac_add_tail(p, q, m);
+}
 BP_HD Jac jac_add(const Jac &p, const Jac &q) {
   if (jac_is_inf(p)) return q;
   if (jac_is_inf(q)) return p;
-  Fp Z1Z1 = fpsqr(p.Z), Z2Z2 = fpsqr(q.Z);
-  Fp U1 = fpmul(p.X, Z2Z2), U2 = fpmul(q.X, Z1Z1);
-  Fp S1 = fpmul(p.Y, fpmul(q.Z, Z2Z2)), S2 = fpmul(q.Y, fpmul(p.Z, Z1Z1));
-  Fp H = sub(U2, U1);
-  Fp rr = sub(S2, S1);
-  if (fp_maybe_zero(H) && is_zero_exact(H)) {
-    if (is_zero_exact(rr)) return jac_dbl(p);
-    return jac_inf();
-  }
-  Fp HH = fpsqr(H), HHH = fpmul(H, HH), V = fpmul(U1, HH);
-  Jac r;
-  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(rr), HHH), V), V));
-  r.Y = sub(fpmul(rr, sub(V, r.X)), fpmul(S1, HHH));
-  r.Z = fpmul(fpmul(p.Z, q.Z), H);
-  return r;
+  AddMid m = jac_add_mid(p, q);
+  if (fp_maybe_zero(m.H)) { Jac pc = p, qc = q, r; jac_add_full(&r, &pc, &qc); return r; }
+  return jac_add_tail(p, q, m);
 }
 
 // Jacobian -> affine with a known 1/Z
