@@ -185,6 +185,60 @@ BP_HD int32_t opaque(int32_t k) {
 #endif
   return k;
 }
+// A whole column as ONE asm statement of N chained v_mad_i64_i32 (device, F_p).  Written as separate C++ MADs with an
+// empty asm between them (chain(), below) the order is kept too, but every VALU instruction that reads a register
+// "defined" by an inline asm in the slot before it gets an s_nop from the hazard recognizer: ~100 per multiplication.
+#if defined(__HIP_DEVICE_COMPILE__)
+BP_HD void madchain1(int64_t &acc, int32_t x0, int32_t y0) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x0), "v"(y0) : "vcc");
+}
+BP_HD void madchain2(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1) : "vcc");
+}
+BP_HD void madchain3(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2) : "vcc");
+}
+BP_HD void madchain4(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3) : "vcc");
+}
+BP_HD void madchain5(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4) : "vcc");
+}
+BP_HD void madchain6(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5) : "vcc");
+}
+BP_HD void madchain7(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5, int32_t x6, int32_t y6) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6) : "vcc");
+}
+BP_HD void madchain8(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5, int32_t x6, int32_t y6, int32_t x7, int32_t y7) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7) : "vcc");
+}
+BP_HD void madchain9(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5, int32_t x6, int32_t y6, int32_t x7, int32_t y7, int32_t x8, int32_t y8) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\tv_mad_i64_i32 %0, vcc, %17, %18, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7), "v"(x8), "v"(y8) : "vcc");
+}
+BP_HD void madchain10(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5, int32_t x6, int32_t y6, int32_t x7, int32_t y7, int32_t x8, int32_t y8, int32_t x9, int32_t y9) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\tv_mad_i64_i32 %0, vcc, %17, %18, %0\n\tv_mad_i64_i32 %0, vcc, %19, %20, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7), "v"(x8), "v"(y8), "v"(x9), "v"(y9) : "vcc");
+}
+BP_HD void madchain11(int64_t &acc, int32_t x0, int32_t y0, int32_t x1, int32_t y1, int32_t x2, int32_t y2, int32_t x3, int32_t y3, int32_t x4, int32_t y4, int32_t x5, int32_t y5, int32_t x6, int32_t y6, int32_t x7, int32_t y7, int32_t x8, int32_t y8, int32_t x9, int32_t y9, int32_t x10, int32_t y10) {
+  asm("v_mad_i64_i32 %0, vcc, %1, %2, %0\n\tv_mad_i64_i32 %0, vcc, %3, %4, %0\n\tv_mad_i64_i32 %0, vcc, %5, %6, %0\n\tv_mad_i64_i32 %0, vcc, %7, %8, %0\n\tv_mad_i64_i32 %0, vcc, %9, %10, %0\n\tv_mad_i64_i32 %0, vcc, %11, %12, %0\n\tv_mad_i64_i32 %0, vcc, %13, %14, %0\n\tv_mad_i64_i32 %0, vcc, %15, %16, %0\n\tv_mad_i64_i32 %0, vcc, %17, %18, %0\n\tv_mad_i64_i32 %0, vcc, %19, %20, %0\n\tv_mad_i64_i32 %0, vcc, %21, %22, %0" : "+v"(acc) : "v"(x0), "v"(y0), "v"(x1), "v"(y1), "v"(x2), "v"(y2), "v"(x3), "v"(y3), "v"(x4), "v"(y4), "v"(x5), "v"(y5), "v"(x6), "v"(y6), "v"(x7), "v"(y7), "v"(x8), "v"(y8), "v"(x9), "v"(y9), "v"(x10), "v"(y10) : "vcc");
+}
+BP_HD void madchain(int64_t &acc, int n, const int32_t *x, const int32_t *y) {
+  switch (n) {
+    case 1: madchain1(acc, x[0], y[0]); break;
+    case 2: madchain2(acc, x[0], y[0], x[1], y[1]); break;
+    case 3: madchain3(acc, x[0], y[0], x[1], y[1], x[2], y[2]); break;
+    case 4: madchain4(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3]); break;
+    case 5: madchain5(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4]); break;
+    case 6: madchain6(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5]); break;
+    case 7: madchain7(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5], x[6], y[6]); break;
+    case 8: madchain8(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5], x[6], y[6], x[7], y[7]); break;
+    case 9: madchain9(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5], x[6], y[6], x[7], y[7], x[8], y[8]); break;
+    case 10: madchain10(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5], x[6], y[6], x[7], y[7], x[8], y[8], x[9], y[9]); break;
+    case 11: madchain11(acc, x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3], x[4], y[4], x[5], y[5], x[6], y[6], x[7], y[7], x[8], y[8], x[9], y[9], x[10], y[10]); break;
+    default: break;
+  }
+}
+#endif
 template <class F> BP_HD void mont_column(int64_t &acc, int32_t *m, int k) {
   if constexpr (F::sparse) {
     if (k >= 6 && k - 6 < NL) { acc += (int64_t)m[k - 6] * (int64_t)(-4456448); chain(acc); }   // -p[6] = -(17 << 18)
@@ -208,6 +262,21 @@ template <class F> BP_HD Fe<F> mul_cols(const Fe<F> &a, const Fe<F> &b) {
   fence();
 #pragma unroll
   for (int k = 0; k < 2 * NL - 1; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (F::sparse) {
+      int32_t x[11], y[11];
+      int n = 0;
+#pragma unroll
+      for (int j = (k >= NL ? k - NL + 1 : 0); j <= k && j < NL; j++) { x[n] = a.v[j]; y[n] = b.v[k - j]; n++; }
+      if (k >= 6 && k - 6 < NL) { x[n] = m[k - 6]; y[n] = -4456448; n++; }   // -p[6] = -(17 << 18)
+      if (k >= 8 && k - 8 < NL) { x[n] = m[k - 8]; y[n] = -524288; n++; }    // -p[8] = -(1 << 19)
+      madchain(acc, n, x, y);
+      if (k < NL) m[k] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      else r.v[k - NL] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      acc >>= LB;
+      continue;
+    }
+#endif
 #pragma unroll
     for (int j = (k >= NL ? k - NL + 1 : 0); j <= k && j < NL; j++) { acc += (int64_t)a.v[j] * (int64_t)b.v[k - j]; chain(acc); }
     mont_column<F>(acc, m, k);
@@ -228,6 +297,22 @@ template <class F> BP_HD Fe<F> sqr_cols(const Fe<F> &a) {
   for (int j = 0; j < NL; j++) a2[j] = 2 * a.v[j];
 #pragma unroll
   for (int k = 0; k < 2 * NL - 1; k++) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (F::sparse) {
+      int32_t x[11], y[11];
+      int n = 0;
+#pragma unroll
+      for (int j = (k >= NL ? k - NL + 1 : 0); 2 * j < k; j++) { x[n] = a.v[j]; y[n] = a2[k - j]; n++; }
+      if ((k & 1) == 0) { x[n] = a.v[k / 2]; y[n] = a.v[k / 2]; n++; }
+      if (k >= 6 && k - 6 < NL) { x[n] = m[k - 6]; y[n] = -4456448; n++; }
+      if (k >= 8 && k - 8 < NL) { x[n] = m[k - 8]; y[n] = -524288; n++; }
+      madchain(acc, n, x, y);
+      if (k < NL) m[k] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      else r.v[k - NL] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      acc >>= LB;
+      continue;
+    }
+#endif
 #pragma unroll
     for (int j = (k >= NL ? k - NL + 1 : 0); 2 * j < k; j++) { acc += (int64_t)a.v[j] * (int64_t)a2[k - j]; chain(acc); }
     if ((k & 1) == 0) { acc += (int64_t)a.v[k / 2] * (int64_t)a.v[k / 2]; chain(acc); }
