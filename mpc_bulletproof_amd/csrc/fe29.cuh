@@ -276,6 +276,24 @@ template <class F> BP_HD Fe<F> mul_cols(const Fe<F> &a, const Fe<F> &b) {
       acc >>= LB;
       continue;
     }
+    if constexpr (!F::sparse) {
+      constexpr int32_t MOD[NL] = FN_MOD;
+      int32_t x[11], y[11];
+      int n = 0;
+#pragma unroll
+      for (int j = (k >= NL ? k - NL + 1 : 0); j <= k && j < NL; j++) { x[n] = a.v[j]; y[n] = b.v[k - j]; n++; }
+      madchain(acc, n, x, y);
+      n = 0;
+#pragma unroll
+      for (int i = (k >= NL ? k - NL + 1 : 0); i < k && i < NL; i++) if (MOD[k - i] != 0) { x[n] = m[i]; y[n] = MOD[k - i]; n++; }
+      madchain(acc, n, x, y);
+      if (k < NL) {
+        m[k] = (int32_t)(((uint32_t)acc * FN_N0) & (uint32_t)LMASK);
+        madchain1(acc, m[k], MOD[0]);
+      } else r.v[k - NL] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      acc >>= LB;
+      continue;
+    }
 #endif
 #pragma unroll
     for (int j = (k >= NL ? k - NL + 1 : 0); j <= k && j < NL; j++) { acc += (int64_t)a.v[j] * (int64_t)b.v[k - j]; chain(acc); }
@@ -312,6 +330,25 @@ template <class F> BP_HD Fe<F> sqr_cols(const Fe<F> &a) {
       acc >>= LB;
       continue;
     }
+    if constexpr (!F::sparse) {
+      constexpr int32_t MOD[NL] = FN_MOD;
+      int32_t x[11], y[11];
+      int n = 0;
+#pragma unroll
+      for (int j = (k >= NL ? k - NL + 1 : 0); 2 * j < k; j++) { x[n] = a.v[j]; y[n] = a2[k - j]; n++; }
+      if ((k & 1) == 0) { x[n] = a.v[k / 2]; y[n] = a.v[k / 2]; n++; }
+      madchain(acc, n, x, y);
+      n = 0;
+#pragma unroll
+      for (int i = (k >= NL ? k - NL + 1 : 0); i < k && i < NL; i++) if (MOD[k - i] != 0) { x[n] = m[i]; y[n] = MOD[k - i]; n++; }
+      madchain(acc, n, x, y);
+      if (k < NL) {
+        m[k] = (int32_t)(((uint32_t)acc * FN_N0) & (uint32_t)LMASK);
+        madchain1(acc, m[k], MOD[0]);
+      } else r.v[k - NL] = (int32_t)((uint32_t)acc & (uint32_t)LMASK);
+      acc >>= LB;
+      continue;
+    }
 #endif
 #pragma unroll
     for (int j = (k >= NL ? k - NL + 1 : 0); 2 * j < k; j++) { acc += (int64_t)a.v[j] * (int64_t)a2[k - j]; chain(acc); }
@@ -325,16 +362,23 @@ template <class F> BP_HD Fe<F> sqr_cols(const Fe<F> &a) {
   return r;
 }
 
-// F_p (every elliptic-curve kernel) takes the column form.  F_n keeps the row form: its kernels are branchy scalar
-// assembly code where the serial MAD chains of the column form cost registers (k_verify_scalars: 177 -> 512 + spills)
-// for a 10 % shorter multiplication.
+// Device code takes the column form for both fields (asm MAD chains).  On the host (CPU tests of these headers) F_n
+// keeps the row form, which doubles as an independent statement of the same product for the tests.
 template <class F> BP_HD Fe<F> mul(const Fe<F> &a, const Fe<F> &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return mul_cols(a, b);
+#else
   if constexpr (F::sparse) return mul_cols(a, b);
   else return mul_rows(a, b);
+#endif
 }
 template <class F> BP_HD Fe<F> sqr(const Fe<F> &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return sqr_cols(a);
+#else
   if constexpr (F::sparse) return sqr_cols(a);
   else return sqr_rows(a);
+#endif
 }
 
 // unique representative in [0, m): all limbs in [0, 2^29).  Accepts |value| < 16m.
