@@ -1,14 +1,16 @@
 // fe29.cuh -- F_p / F_n arithmetic for gfx950: 9 signed limbs of 29 bits, lazy Montgomery (R = 2^261).
 //
 // Why this shape (CDNA4 has no carry-chained multiply-add; v_mad_i64_i32 gives a full 32x32+64):
-//   * limbs |x_j| <~ 2^29 in int32 registers; a 9x9 schoolbook product is exactly 81 v_mad_i64_i32
-//     into int64 column accumulators with NO carry handling (9 * 2^58 < 2^63);
+//   * limbs |x_j| <~ 2^29 in int32 registers; a 9x9 schoolbook product is exactly 81 v_mad_i64_i32 whose
+//     64-bit column sums need NO carry handling (9 * 2^58 < 2^63);
+//   * the product is taken column by column, each column one chain of MADs that starts from the carry of the
+//     column before it (no 64-bit additions at all; F_p multiply = 134 VALU instructions, 99 of them MADs);
 //   * add / sub are 9 independent VALU ops (no v_addc chains) + a 3-op/limb parallel carry;
 //   * R = 2^261 is 2^10 larger than the 252-bit moduli, so a product of two values < 2^256
-//     reduces to (-eps*m, (1+eps)*m) without any conditional subtraction: values stay lazy
+//     reduces to within one modulus of zero without any conditional subtraction: values stay lazy
 //     (small signed multiples of m) until `canon()` at an output / equality test;
-//   * p = 2^251 + 17*2^192 + 1 has limbs [1,0,0,0,0,0,17<<18,0,1<<19] and -p^-1 = -1 mod 2^29:
-//     one Montgomery step for F_p is a negate, an add and two MADs.
+//   * p = 2^251 + 17*2^192 + 1 has limbs [1,0,0,0,0,0,17<<18,0,1<<19] and p = 1 (mod 2^29):
+//     one Montgomery step for F_p is a mask and two MADs.
 //
 // Representation invariants ("T" = tight): lower limbs in [0, 2^29), top limb small signed.
 // "T'" (after norm()): lower limbs in [-8, 2^29 + 8).  mul/sqr accept T' x T' and limbs up to
