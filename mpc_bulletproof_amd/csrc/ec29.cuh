@@ -78,7 +78,7 @@ BP_HD Jac jac_dbl_fast(const Jac &p) {
   Fp T = norm(sub_nr(sub_nr(fpsqr(M), S), S));
   Jac r;
   r.X = T;
-  r.Y = sub(fpmul(M, sub(S, T)), mul_small<8>(YYYY));
+  r.Y = sub(fpmul(M, sub_nr(S, T)), mul_small<8>(YYYY));   // S, T tight: the difference has limbs in (-2^29, 2^29), fine for ONE product
   r.Z = mul_small<2>(fpmul(p.Y, p.Z));
   return r;
 }
@@ -99,15 +99,17 @@ BP_HD MaddMid jac_madd_mid(const Jac &p, const Aff &q) {
   Fp Z1Z1 = fpsqr(p.Z);
   Fp U2 = fpmul(q.x, Z1Z1);
   Fp S2 = fpmul(q.y, fpmul(p.Z, Z1Z1));
-  m.H = sub(U2, p.X);
-  m.rr = sub(S2, p.Y);
+  // differences of two tight values (coordinates are always stored normalised) are left un-normalised: limbs in
+  // (-2^29 - 8, 2^29 + 8), which products and squares accept on both sides -- three carry passes less per addition
+  m.H = sub_nr(U2, p.X);
+  m.rr = sub_nr(S2, p.Y);
   return m;
 }
 BP_HD Jac jac_madd_tail(const Jac &p, const MaddMid &m) {
   Fp HH = fpsqr(m.H), HHH = fpmul(m.H, HH), V = fpmul(p.X, HH);
   Jac r;
   r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(m.rr), HHH), V), V));
-  r.Y = sub(fpmul(m.rr, sub(V, r.X)), fpmul(p.Y, HHH));
+  r.Y = sub(fpmul(m.rr, sub_nr(V, r.X)), fpmul(p.Y, HHH));
   r.Z = fpmul(p.Z, m.H);
   return r;
 }
@@ -151,15 +153,15 @@ BP_HD AddMid jac_add_mid(const Jac &p, const Jac &q) {
   Fp U2 = fpmul(q.X, Z1Z1);
   m.S1 = fpmul(p.Y, fpmul(q.Z, Z2Z2));
   Fp S2 = fpmul(q.Y, fpmul(p.Z, Z1Z1));
-  m.H = sub(U2, m.U1);
-  m.rr = sub(S2, m.S1);
+  m.H = sub_nr(U2, m.U1);      // products on both sides: see jac_madd_mid
+  m.rr = sub_nr(S2, m.S1);
   return m;
 }
 BP_HD Jac jac_add_tail(const Jac &p, const Jac &q, const AddMid &m) {
   Fp HH = fpsqr(m.H), HHH = fpmul(m.H, HH), V = fpmul(m.U1, HH);
   Jac r;
   r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(m.rr), HHH), V), V));
-  r.Y = sub(fpmul(m.rr, sub(V, r.X)), fpmul(m.S1, HHH));
+  r.Y = sub(fpmul(m.rr, sub_nr(V, r.X)), fpmul(m.S1, HHH));
   r.Z = fpmul(fpmul(p.Z, q.Z), m.H);
   return r;
 }
