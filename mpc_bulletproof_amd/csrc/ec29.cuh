@@ -69,11 +69,12 @@ BP_HD Fp fp_hide(const Fp &a) {
 BP_HD Jac jac_hide(const Jac &a) { Jac r; r.X = fp_hide(a.X); r.Y = fp_hide(a.Y); r.Z = fp_hide(a.Z); return r; }
 BP_HD Aff aff_hide(const Aff &a) { Aff r; r.x = fp_hide(a.x); r.y = fp_hide(a.y); return r; }
 
-// dbl-2007-bl with a = 1 and Z3 = 2*Y*Z: 7S + 2M
+// dbl-2007-bl with a = 1, Z3 = 2*Y*Z and S by a product: 6S + 3M
 BP_HD Jac jac_dbl_fast(const Jac &p) {
   Fp XX = fpsqr(p.X), YY = fpsqr(p.Y), YYYY = fpsqr(YY), ZZ = fpsqr(p.Z);
-  Fp t = fpsqr(add(p.X, YY));
-  Fp S = mul_small<2>(norm(sub_nr(sub_nr(t, XX), YYYY)));
+  // S = 4 X Y^2 as ONE product: the (X + YY)^2 - XX - YYYY form of dbl-2007-bl trades it for a square, which here is
+  // only 27 instructions cheaper than a product (107 / 134) and costs an addition, two subtractions and a carry pass
+  Fp S = mul_small<4>(fpmul(p.X, YY));
   Fp M = add(norm(add_nr(add_nr(XX, XX), XX)), fpsqr(ZZ));           // 3 XX + a ZZ^2, a = 1
   Fp T = norm(sub_nr(sub_nr(fpsqr(M), S), S));
   Jac r;
