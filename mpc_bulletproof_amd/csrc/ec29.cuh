@@ -75,7 +75,7 @@ BP_HD Jac jac_dbl_fast(const Jac &p) {
   // S = 4 X Y^2 as ONE product: the (X + YY)^2 - XX - YYYY form of dbl-2007-bl trades it for a square, which here is
   // only 27 instructions cheaper than a product (107 / 134) and costs an addition, two subtractions and a carry pass
   Fp S = mul_small<4>(fpmul(p.X, YY));
-  Fp M = add(norm(add_nr(add_nr(XX, XX), XX)), fpsqr(ZZ));           // 3 XX + a ZZ^2, a = 1
+  Fp M = norm(add_nr(add_nr(add_nr(XX, XX), XX), fpsqr(ZZ)));        // 3 XX + a ZZ^2, a = 1: four tight terms, limbs < 2^31
   Fp T = norm(sub_nr(sub_nr(fpsqr(M), S), S));
   Jac r;
   r.X = T;
@@ -143,6 +143,15 @@ BP_HD Jac jac_madd(const Jac &p, const Aff &q) {
   Jac qj; qj.X = q.x; qj.Y = q.y; qj.Z = fe_one<FP>();
   r = jac_select(jac_is_inf(p), qj, r);
   return jac_select(aff_is_inf(q), p, r);
+}
+
+// the same when the caller has already excluded q = identity
+BP_HD Jac jac_madd_nzq(const Jac &p, const Aff &q) {
+  MaddMid m = jac_madd_mid(p, q);
+  if (fp_maybe_zero(m.H)) { Jac pc = jac_hide(p), r; Aff qc = aff_hide(q); jac_madd_full(&r, &pc, &qc); return jac_hide(r); }
+  Jac r = jac_madd_tail(p, m);
+  Jac qj; qj.X = q.x; qj.Y = q.y; qj.Z = fe_one<FP>();
+  return jac_select(jac_is_inf(p), qj, r);
 }
 
 // general addition: 12M + 4S

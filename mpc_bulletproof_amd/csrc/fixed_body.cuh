@@ -38,8 +38,10 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
       if (dg != 0) {
         size_t row = (g < 2 + n ? g : g + hshift) * W + w;
         const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+        uint32_t any = 0;
 #pragma unroll
-        for (int t = 0; t < 16; t++) dst[t] = e->w[t];
+        for (int t = 0; t < 16; t++) { dst[t] = e->w[t]; any |= dst[t]; }
+        if (any == 0) dg = 0;   // rows of an identity generator (the ABI accepts one) are the identity: nothing to add
       }
     }
   };
@@ -53,7 +55,7 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
       q.x = unpack<FP>(cur);
       q.y = unpack<FP>(cur + 8);
       if (dcur < 0) q.y = neg(q.y);
-      acc = jac_madd(acc, q);
+      acc = jac_madd_nzq(acc, q);   // identity rows were dropped in fetch()
     }
 #pragma unroll
     for (int t = 0; t < 16; t++) cur[t] = nxt[t];

@@ -121,7 +121,7 @@ __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, si
           q.x = ld(src, 0);
           q.y = ld(src, NL);
           if (dg < 0) q.y = neg(q.y);
-          acc = jac_madd(acc, q);
+          acc = jac_madd_nzq(acc, q);   // entries of a point that is not the identity (pinf is checked above)
         } else {
           Jac q;
           q.X = ld(src, 0); q.Y = ld(src, NL); q.Z = ld(src, 2 * NL);
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
       for (int t = 0; t < NL; t++) { q.x.v[t] = e->v[t]; q.y.v[t] = e->v[NL + t]; }
       if (!aff_is_inf(q)) {
         if (dg < 0) q.y = neg(q.y);
-        acc = jac_madd(acc, q);
+        acc = jac_madd_nzq(acc, q);
       }
     }
   }
