@@ -148,6 +148,26 @@ def test_msm_gens(gpu, c):
         gpu.gens_destroy(g)
 
 
+def test_msm_gens_with_identity_generators(gpu):
+    """The ABI accepts the identity (64 zero bytes) as a generator: its table rows are the identity and must
+    contribute nothing, whatever the scalar (the fixed-base lanes drop such rows before the mixed addition that
+    assumes a non-identity operand)."""
+    cap = 8
+    Gp, Hp, B = bytearray(o.gens("G", cap)), bytearray(o.gens("H", cap)), o.generator()
+    Gp[64 * 2:64 * 3] = bytes(64)            # G_2 = identity
+    Hp[0:64] = bytes(64)                     # H_0 = identity
+    Gp, Hp = bytes(Gp), bytes(Hp)
+    for c in (8, 16):
+        g = gpu.gens_create(Gp, Hp, B, bytes(64), c)      # B_blinding = identity as well
+        try:
+            for nb in (1, 5):
+                sc = o.random_scalars(700 + nb + c, nb * (2 + 2 * cap))
+                want = o.msm_batch(sc, (B + bytes(64) + Gp + Hp) * nb, nb, 2 + 2 * cap)
+                assert gpu.msm_gens(g, nb, cap, sc) == want
+        finally:
+            gpu.gens_destroy(g)
+
+
 # ------------------------------------------------------------------ IPP
 def test_fold_witness(gpu, golden_ipp):
     for c in golden_ipp["fold"]:
