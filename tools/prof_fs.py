@@ -38,8 +38,9 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for i in range(steps):
     fstep(i)
+t_submit = time.perf_counter() - t0
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 for c, d in zip(ctxs, d_oks):
     assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
-print(f"{steps} steps, {inflight} in flight: {dt / steps * 1e3:.4f} ms/step = {nb * steps / dt / 1e6:.3f} M verifications/s")
+print(f"{steps} steps, {inflight} in flight: {dt / steps * 1e3:.4f} ms/step = {nb * steps / dt / 1e6:.3f} M verifications/s (host submission {t_submit / steps * 1e3:.4f} ms/step)")
