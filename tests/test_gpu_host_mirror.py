@@ -121,3 +121,68 @@ def test_prove_batch_lockstep_matches_oracle(host):
         assert o.r1cs_verify(o.K_RANGE_MULTI, param, b"RangeProofTest", [], com_o, proof_o, cap) == 0
         assert _verify(host, o.K_RANGE_MULTI, param, b"RangeProofTest", [], com_o, proof_o, cap)[0] == 0
     assert n == 32
+
+
+# ------------------------------------------------------------------ BASELINE full sizes (configs[2], configs[3])
+def test_config2_full_size_256_provers_16x64bit(host):
+    """BASELINE.json configs[2]: 256 provers in lock-step, each range-proving 16 values of 64 bits in one constraint
+    system (n = 1024 multipliers, q = 2064 constraints, m = 16).  Checked at full size through properties that do not
+    need the oracle for every proof: a sample of proofs verifies (GPU verifier), a tampered proof and a proof checked
+    against another prover's commitments are rejected; the first and the last prover's proofs are byte-identical to
+    the CPU oracle's (1 s each)."""
+    nb, nvals, n_bits = 256, 16, 64
+    n = nvals * n_bits
+    label = b"RangeProofTest"
+    vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(nb) for i in range(nvals)]
+    arr = (C.c_uint64 * len(vals))(*vals)
+    proofs = (C.c_uint8 * (nb * 4096))()
+    plen = C.c_size_t(0)
+    com = (C.c_uint8 * (nb * nvals * 64))()
+    rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(nvals), C.c_size_t(n_bits), o._buf(label), C.c_size_t(len(label)),
+                                    arr, C.c_uint64(900), C.c_size_t(n), proofs, C.byref(plen), com)
+    assert rc == 0
+    L = plen.value
+    assert L == 8 + 11 * 64 + 3 * 32 + 2 * 10 * 64 + 2 * 32      # 10 IPP rounds for n = 1024
+    pb, cb = bytes(proofs), bytes(com)
+    param = n_bits | (nvals << 16)
+    proof_of = lambda p: pb[p * L:(p + 1) * L]                      # noqa: E731
+    com_of = lambda p: cb[p * nvals * 64:(p + 1) * nvals * 64]      # noqa: E731
+    assert len({proof_of(p) for p in range(nb)}) == nb              # 256 distinct proofs
+    for p in (0, 1, 77, 128, 254, 255):
+        assert _verify(host, o.K_RANGE_MULTI, param, label, [], com_of(p), proof_of(p), n)[0] == 0, p
+    bad = bytearray(proof_of(77))
+    bad[L // 2] ^= 1
+    assert _verify(host, o.K_RANGE_MULTI, param, label, [], com_of(77), bytes(bad), n)[0] != 0
+    assert _verify(host, o.K_RANGE_MULTI, param, label, [], com_of(78), proof_of(77), n)[0] != 0
+    for p in (0, nb - 1):
+        rc_o, proof_o, com_o = o.r1cs_prove(o.K_RANGE_MULTI, param, label, vals[p * nvals:(p + 1) * nvals], 900 + p, n)
+        assert rc_o == 0 and proof_of(p) == proof_o and com_of(p) == com_o, p
+
+
+def test_config3_full_size_shuffle_2e14(host):
+    """BASELINE.json configs[3]: the k-shuffle gadget at k = 2^14 (n = 32 766 multipliers, q = 65 533 constraints,
+    m = 32 768 commitments, a 98 347-term mega_check): prove and verify on the GPU through the host mirror (two-phase
+    circuit: the randomized constraints are built on the host from the transcript challenge); a proof of a
+    non-permutation must not verify.  (The oracle proves this size in minutes: byte parity is pinned at k = 2^8 in
+    tools/bench_shuffle.py and at the golden sizes in test_prover_bytes_identical_to_oracle.)"""
+    k = 1 << 14
+    cap = 1 << 15
+    xs = [((0x9E3779B97F4A7C15 * (i + 1)) & ((1 << 64) - 1)) for i in range(k)]
+    ys = xs[1:] + xs[:1]                                    # a rotation: a valid shuffle
+    ms = (C.c_double * 6)()
+
+    def run(values):
+        arr = (C.c_uint64 * (2 * k))(*values)
+        proof = (C.c_uint8 * 8192)()
+        plen = C.c_size_t(0)
+        com = (C.c_uint8 * (2 * k * 64))()
+        rc = host.bph_shuffle_prove_verify(C.c_size_t(k), arr, C.c_uint64(4242), C.c_size_t(cap), proof, C.byref(plen), com, ms)
+        return rc, plen.value
+
+    rc, L = run(xs + ys)
+    assert rc == 0                                          # proved and accepted
+    assert L == 8 + 11 * 64 + 3 * 32 + 2 * 15 * 64 + 2 * 32      # flat proof: 11 points, 3 scalars, 15 IPP rounds, a, b
+    ys_bad = list(ys)
+    ys_bad[5] ^= 1                                          # no longer a permutation of xs
+    rc_bad, _ = run(xs + ys_bad)
+    assert rc_bad != 0
