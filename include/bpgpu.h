@@ -64,6 +64,12 @@ int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);
 int bpgpu_free(bpgpu_ctx *ctx, void *dptr);
 int bpgpu_upload(bpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int bpgpu_download(bpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Page-locked host memory for staging.  Operands handed over from such a buffer reach the device by DMA at PCIe
+ * speed; pageable buffers go through the runtime's bounce buffers (3-10 GB/s measured).  Optional -- every entry point
+ * accepts ordinary host pointers (the Rust side would keep its packed scalar / point staging Vec in one of these).
+ * The memory belongs to the process, not to a context.  BPGPU_E_DEVICE without a HIP device, BPGPU_E_OOM. */
+int bpgpu_host_alloc(size_t bytes, void **out);
+void bpgpu_host_free(void *p);
 
 /* ---- scalar field --------------------------------------------------------------------------
  * Scalar::batch_inverse(&mut [Scalar])   -- src/inner_product_proof.rs:283

@@ -235,6 +235,18 @@ int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad) {
   HIPCK(ctx, hipStreamSynchronize(ctx->st2));
   return flag_read(ctx, bad);
 }
+int bpgpu_host_alloc(size_t bytes, void **out) {
+  if (!out) return BPGPU_E_ARG;
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return BPGPU_E_DEVICE;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault);
+  if (e != hipSuccess) { *out = nullptr; return e == hipErrorOutOfMemory ? BPGPU_E_OOM : BPGPU_E_DEVICE; }
+  return BPGPU_OK;
+}
+void bpgpu_host_free(void *p) {
+  if (p) (void)hipHostFree(p);
+}
 int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr) {
   if (!ctx || !dptr) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);

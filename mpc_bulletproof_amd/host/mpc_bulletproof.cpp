@@ -77,6 +77,9 @@ Scalar Scalar::from_le_bytes_mod_order_wide(const uint8_t b[64]) {
   return l + h;
 }
 void Scalar::to_bytes_le(uint8_t out[32]) const {
+  // witness vectors of R1CS gadgets are mostly 0 and 1 (bits, a_O of a range proof): no reduction for those
+  if ((v_[0] | v_[1] | v_[2] | v_[3]) == 0) { memset(out, 0, 32); return; }
+  if (memcmp(v_, RONE, 32) == 0) { memset(out, 0, 32); out[0] = 1; return; }
   uint64_t one[4] = {1, 0, 0, 0}, t[4];
   mont_mul(t, v_, one);
   for (int i = 0; i < 4; i++) for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(t[i] >> (8 * j));
@@ -162,12 +165,24 @@ void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t min_n) 
 namespace {
 // grow-only uninitialised byte buffers for the big scalar uploads (a zero-initialised std::vector costs a
 // single-threaded memset + page faults of tens of MB per call)
+// grow-only staging buffer for the large packed operands (50 MB of commitment scalars for 256 provers): page-locked
+// through the C ABI when it can be, so that the copy to the device is one DMA at PCIe speed
 struct RawBuf {
   uint8_t *p = nullptr;
   size_t cap = 0;
-  ~RawBuf() { free(p); }
+  bool pinned = false;
+  void release() { if (pinned) bpgpu_host_free(p); else free(p); p = nullptr; cap = 0; }
+  ~RawBuf() { if (!pinned) free(p); }   // a pinned buffer of a thread that outlives the HIP runtime is left to the process exit
   uint8_t *ensure(size_t n) {
-    if (n > cap) { free(p); p = (uint8_t *)malloc(n ? n : 1); cap = p ? n : 0; if (!p) throw std::bad_alloc(); }
+    if (n > cap) {
+      release();
+      size_t want = n + n / 4 + 1;                       // grow-only with head room: pinning is not cheap
+      void *q = nullptr;
+      if (!getenv("BPH_PAGEABLE_STAGING") && bpgpu_host_alloc(want, &q) == BPGPU_OK && q) { p = (uint8_t *)q; pinned = true; }
+      else { p = (uint8_t *)malloc(want); pinned = false; }
+      if (!p) throw std::bad_alloc();
+      cap = want;
+    }
     return p;
   }
 };

@@ -115,6 +115,34 @@ def test_msm_batch_device_resident(gpu):
         gpu.free(d)
 
 
+def test_msm_from_page_locked_staging(gpu):
+    """bpgpu_host_alloc / bpgpu_host_free: operands handed over from page-locked staging memory give the same result
+    as from ordinary buffers (the fast hand-over path of INTEGRATION.md)."""
+    import ctypes as C
+    import mpc_bulletproof_amd as m
+    lib = C.CDLL(m.lib.SO_PATH)
+    lib.bpgpu_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.bpgpu_host_free.argtypes = [C.c_void_p]
+    n = 3000
+    sc, pts = o.random_scalars(4711, n), (o.gens("G", 1024) * 3)[:64 * n]
+    want = gpu.msm(sc, pts)
+    assert want == o.msm(sc, pts)
+    ps, pp = C.c_void_p(), C.c_void_p()
+    assert lib.bpgpu_host_alloc(C.c_size_t(32 * n), C.byref(ps)) == 0 and ps.value
+    assert lib.bpgpu_host_alloc(C.c_size_t(64 * n), C.byref(pp)) == 0 and pp.value
+    try:
+        C.memmove(ps, sc, 32 * n)
+        C.memmove(pp, pts, 64 * n)
+        out = (C.c_uint8 * 64)()
+        lib.bpgpu_msm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        assert lib.bpgpu_msm(gpu.ctx, ps, pp, C.c_size_t(n), out) == 0
+        assert bytes(out) == want
+    finally:
+        lib.bpgpu_host_free(ps)
+        lib.bpgpu_host_free(pp)
+    lib.bpgpu_host_free(None)     # freeing nothing is allowed
+
+
 def test_msm_rejects_bad_input(gpu):
     import mpc_bulletproof_amd as m
     G = o.generator()
