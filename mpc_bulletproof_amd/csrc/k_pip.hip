@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_pip_digits(PipParams pp, const uint32_t
     if (d != 0) {
       uint32_t b = (uint32_t)((inst * pp.W + w) * pp.half) + (uint32_t)((d < 0 ? -d : d) - 1);
       key = b | (d < 0 ? 0x80000000u : 0u);
-      atomicAdd(&counts[b], 1u);
+      if (counts) atomicAdd(&counts[b], 1u);
     }
     keys[((size_t)inst * pp.W + w) * n + r] = key;
   }
@@ -123,6 +123,74 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_
   size_t inst = t / (n * (size_t)pp.W), r = t % n;
   sorted[pos] = (uint32_t)(inst * n + r) | (key & 0x80000000u);   // global term index
 }
+// ---- LDS-staged two-level counting sort (large MSMs) ------------------------------------------------------------------
+// The scatter above issues one global atomic and one random 4-byte write per (term, window): 1.5 ms of a 5 ms 2^20-term
+// MSM, plus 0.4 ms of histogram atomics in k_pip_digits.  Here the keys of a (instance, window) segment are first split
+// into 256 coarse bins (top 8 bits of the bucket id) with per-tile histograms and ranks kept in LDS -- a tile writes
+// ~8 consecutive entries per bin -- and every (segment, bin) is then counting-sorted by one block entirely in LDS
+// (<= 128 fine buckets), which also yields the per-bucket counts.  Order inside a bucket is irrelevant (the sum commutes).
+constexpr int RS_BINS = 256, RS_TPB = 256, RS_PER = 8, RS_TILE = RS_TPB * RS_PER;
+__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys, size_t n, int half, int shift, size_t tiles,
+                                                            uint32_t *gh) {
+  __shared__ uint32_t h[RS_BINS];
+  const size_t seg = blockIdx.y, tile = blockIdx.x;
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t base = (uint32_t)(seg * (size_t)half);
+#pragma unroll
+  for (int j = 0; j < RS_PER; j++) {
+    size_t r = tile * RS_TILE + (size_t)j * RS_TPB + threadIdx.x;
+    if (r < n) {
+      uint32_t key = keys[seg * n + r];
+      if (key != 0xFFFFFFFFu) atomicAdd(&h[((key & 0x7FFFFFFFu) - base) >> shift], 1u);
+    }
+  }
+  __syncthreads();
+  gh[(seg * RS_BINS + threadIdx.x) * tiles + tile] = h[threadIdx.x];
+}
+__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *keys, size_t n, int W, int half, int shift, size_t tiles,
+                                                               const uint32_t *goff, uint32_t *cval, uint8_t *cfine) {
+  __shared__ uint32_t cur[RS_BINS];
+  const size_t seg = blockIdx.y, tile = blockIdx.x;
+  cur[threadIdx.x] = goff[(seg * RS_BINS + threadIdx.x) * tiles + tile];
+  __syncthreads();
+  const uint32_t base = (uint32_t)(seg * (size_t)half), fmask = (1u << shift) - 1;
+#pragma unroll
+  for (int j = 0; j < RS_PER; j++) {
+    size_t r = tile * RS_TILE + (size_t)j * RS_TPB + threadIdx.x;
+    if (r < n) {
+      uint32_t key = keys[seg * n + r];
+      if (key != 0xFFFFFFFFu) {
+        uint32_t lb = (key & 0x7FFFFFFFu) - base;
+        uint32_t pos = atomicAdd(&cur[lb >> shift], 1u);
+        cval[pos] = (uint32_t)((seg / (size_t)W) * n + r) | (key & 0x80000000u);   // global term index | sign (as k_pip_scatter)
+        cfine[pos] = (uint8_t)(lb & fmask);
+      }
+    }
+  }
+}
+// one block per (segment, bin): counts of its 2^shift buckets and the entries placed bucket by bucket
+__global__ void __launch_bounds__(RS_TPB) k_pip_fine_sort(const uint32_t *goff, size_t tiles, size_t nseg, int half, int shift,
+                                                          const uint32_t *cval, const uint8_t *cfine, uint32_t *counts,
+                                                          uint32_t *sorted) {
+  __shared__ uint32_t h[128], start[128];
+  const size_t seg = blockIdx.y, bin = blockIdx.x;
+  const int fb = 1 << shift;
+  const size_t gi = (seg * RS_BINS + bin) * tiles;
+  const uint32_t lo = goff[gi], hi = goff[gi + tiles];     // goff has nseg * RS_BINS * tiles + 1 entries
+  if (threadIdx.x < 128) h[threadIdx.x] = 0;
+  __syncthreads();
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += RS_TPB) atomicAdd(&h[cfine[e]], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = lo;
+    for (int f = 0; f < fb; f++) { start[f] = run; run += h[f]; }
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < fb) counts[seg * (size_t)half + bin * (size_t)fb + threadIdx.x] = h[threadIdx.x];
+  for (uint32_t e = lo + threadIdx.x; e < hi; e += RS_TPB) sorted[atomicAdd(&start[cfine[e]], 1u)] = cval[e];
+}
+
 // Load balance: a bucket list is cut into tasks of at most PIP_TASK entries (the partial top window
 // has only 2^(252 mod c) non-empty buckets holding n / 2^(252 mod c) points each; equal or
 // low-entropy scalars are worse).  tcount[b] = max(1, ceil(len / PIP_TASK)); its scan gives task ids.
@@ -146,11 +214,31 @@ __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, co
   uint32_t b = task_bucket[t], slice = (uint32_t)t - toffsets[b];
   uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1], hi = lo + PIP_TASK < end ? lo + PIP_TASK : end;
   Jac acc = jac_inf();
+  // the point of entry e + 1 is requested before the addition of entry e starts (two dependent loads -- index, then a
+  // random 64-byte row -- per ~1 650-instruction addition; unpipelined the launch ran at half the addition rate)
+  uint32_t cur[16], vcur = 0;
+  if (lo < hi) {
+    vcur = sorted[lo];
+    const AffDev *src = &pts[vcur & 0x7FFFFFFFu];
+#pragma unroll
+    for (int j = 0; j < 16; j++) cur[j] = src->w[j];
+  }
   for (uint32_t e = lo; e < hi; e++) {
-    uint32_t v = sorted[e];
-    Aff q = aff_load(&pts[v & 0x7FFFFFFFu]);
-    if (v & 0x80000000u) q.y = neg(q.y);
+    uint32_t nxt[16], vnxt = 0;
+    if (e + 1 < hi) {
+      vnxt = sorted[e + 1];
+      const AffDev *src = &pts[vnxt & 0x7FFFFFFFu];
+#pragma unroll
+      for (int j = 0; j < 16; j++) nxt[j] = src->w[j];
+    }
+    Aff q;
+    q.x = unpack<FP>(cur);
+    q.y = unpack<FP>(cur + 8);
+    if (vcur & 0x80000000u) q.y = neg(q.y);
     acc = jac_madd(acc, q);
+#pragma unroll
+    for (int j = 0; j < 16; j++) cur[j] = nxt[j];
+    vcur = vnxt;
   }
   raw_store(&partial[t], acc);
 }
@@ -237,11 +325,23 @@ int pippenger_window(size_t n) {
   return best;
 }
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+// the two-level sort pays from ~2^15 terms per instance on (fixed cost: two more scans and launches) and needs
+// >= 256 buckets per coarse split; BPGPU_PIP_TWO_LEVEL=0 keeps the atomic scatter
+static bool pip_two_level(size_t ninst, size_t n, int c) {
+  static const int env = getenv("BPGPU_PIP_TWO_LEVEL") ? atoi(getenv("BPGPU_PIP_TWO_LEVEL")) : 1;
+  (void)ninst;
+  return env != 0 && c >= 12 && c <= 16 && n >= ((size_t)1 << 15);
+}
 static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP_TASK + nbk + 1; }
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
-  return al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-         al(ninst * W * sizeof(JacRaw)) * 65 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4);
+  size_t base = al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
+                al(ninst * W * sizeof(JacRaw)) * 65 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4);
+  if (pip_two_level(ninst, n, c)) {
+    size_t ngh = ninst * W * RS_BINS * ((n + RS_TILE - 1) / RS_TILE);
+    base += al((ngh + 1) * 4) * 2 + al((ngh / SCAN_TILE + 2) * 4) + al(tot * W * 4) + al(tot * W);
+  }
+  return base;
 }
 size_t pippenger_scratch_bytes(size_t n, int c) { return pippenger_scratch_bytes_batch(1, n, c); }
 // ninst instances of n terms: pts / scalars hold instance-major arrays; out[inst * out_stride]
@@ -268,11 +368,30 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   JacRaw *win = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw));
   JacRaw *win_part = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw)) * 64;     // <= 64 chunks per window
   uint32_t *heavy = (uint32_t *)p; p += al(mt / PIP_HEAVY * 4 + 8);              // [0] = count, [2..] = bucket ids
-  uint32_t *tile_tmp = (uint32_t *)p;
-  (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
-  if (tot) hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, counts);
-  pip_scan(st, counts, offsets, cursor, nbk, tile_tmp);
-  if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
+  uint32_t *tile_tmp = (uint32_t *)p; p += al((nbk / SCAN_TILE + 2) * 4);
+  if (pip_two_level(ninst, n, c)) {
+    // LDS-staged two-level counting sort: digits (no atomics) -> coarse histograms per tile -> scan -> coarse scatter ->
+    // per-(segment, bin) fine sort, which also produces the bucket counts
+    const int shift = c - 1 - 8;
+    const size_t nseg = ninst * W, tiles = (n + RS_TILE - 1) / RS_TILE, ngh = nseg * RS_BINS * tiles;
+    uint32_t *gh = (uint32_t *)p; p += al((ngh + 1) * 4);
+    uint32_t *goff = (uint32_t *)p; p += al((ngh + 1) * 4);
+    uint32_t *gtile = (uint32_t *)p; p += al((ngh / SCAN_TILE + 2) * 4);
+    uint32_t *cval = (uint32_t *)p; p += al(tot * W * 4);
+    uint8_t *cfine = p; p += al(tot * W);
+    hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_pip_coarse_hist, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.half, shift, tiles, gh);
+    pip_scan(st, gh, goff, nullptr, ngh, gtile);
+    hipLaunchKernelGGL(k_pip_coarse_scatter, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, tiles, goff, cval, cfine);
+    hipLaunchKernelGGL(k_pip_fine_sort, dim3(RS_BINS, nseg), dim3(RS_TPB), 0, st, goff, tiles, nseg, pp.half, shift, cval, cfine, counts, sorted);
+    (void)hipMemsetAsync(counts + nbk, 0, 4, st);
+    pip_scan(st, counts, offsets, nullptr, nbk, tile_tmp);
+  } else {
+    (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
+    if (tot) hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, counts);
+    pip_scan(st, counts, offsets, cursor, nbk, tile_tmp);
+    if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
+  }
   hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
   pip_scan(st, tcount, toffsets, nullptr, nbk, tile_tmp);
   hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);

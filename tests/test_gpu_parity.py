@@ -541,6 +541,52 @@ def test_msm_pippenger_sizes(gpu, n):
         assert got == o.msm(sc, Gp, 2)
 
 
+def test_msm_pippenger_two_level_sort_edge_cases(gpu):
+    """n >= 2^15 takes the LDS-staged two-level counting sort (coarse bins per tile, fine sort per bin): skewed and
+    degenerate key distributions -- all scalars equal (one bucket per window holds everything), 0 / 1 / n-1 scalars,
+    bit-valued scalars, identity points, duplicate and opposite points, a ragged last tile -- against the oracle-free
+    identity MSM(s_i, k_i G) = (sum s_i k_i) G."""
+    n = 40000 + 37                                                  # not a multiple of the 2048-key tile
+    Gp, Gd = o.gens("G", n, dlogs=True)
+    G = o.generator()
+    ks = o.unscalars(Gd)
+
+    def check(sc_list, pts=Gp, dl=ks):
+        sc = o.scalars(sc_list)
+        want = o.point_mul(o.s2b(sum(a * b for a, b in zip(sc_list, dl)) % N), G)
+        assert gpu.msm(sc, pts) == want
+
+    rnd = o.unscalars(o.random_scalars(31337, n))
+    check([rnd[0]] * n)                                             # every key of a window in ONE bucket
+    check([i & 1 for i in range(n)])                                # bits: digit 1 in window 0 only
+    check([[0, 1, N - 1, 2, N - 2, rnd[i]][i % 6] for i in range(n)])
+    check([rnd[i] >> 200 for i in range(n)])                        # small scalars: the upper windows are empty
+    # identity points, duplicates, opposite pairs
+    pts, dl = bytearray(Gp), list(ks)
+    for i in range(0, n, 13):
+        pts[64 * i:64 * i + 64] = bytes(64)
+        dl[i] = 0
+    for i in range(5, n - 1, 101):
+        pts[64 * (i + 1):64 * (i + 2)] = pts[64 * i:64 * i + 64]
+        dl[i + 1] = dl[i]
+    sc = list(rnd)
+    for i in range(7, n - 1, 211):                                  # s P + (n - s) P = 0 on a duplicated point
+        pts[64 * (i + 1):64 * (i + 2)] = pts[64 * i:64 * i + 64]
+        dl[i + 1] = dl[i]
+        sc[i + 1] = N - sc[i]
+    check(sc, bytes(pts), dl)
+
+
+def test_msm_batch_pippenger_two_level(gpu):
+    """two instances of 33 000 terms each through the batched entry point (segments = instance x window)"""
+    nb, n = 2, 33000
+    Gp, Gd = o.gens("H", n, dlogs=True)
+    sc = o.random_scalars(78, nb * n)
+    got = gpu.msm_batch(nb, n, sc, Gp * nb)
+    for b in range(nb):
+        assert got[64 * b:64 * b + 64] == o.point_mul(o.inner_product(sc[32 * n * b:32 * n * (b + 1)], Gd), o.generator())
+
+
 def test_msm_batch_pippenger(gpu):
     nb, n = 2, 700
     Gp = o.gens("H", n)
