@@ -330,7 +330,8 @@ static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 static bool pip_two_level(size_t ninst, size_t n, int c) {
   static const int env = getenv("BPGPU_PIP_TWO_LEVEL") ? atoi(getenv("BPGPU_PIP_TWO_LEVEL")) : 1;
   (void)ninst;
-  return env != 0 && c >= 12 && c <= 16 && n >= ((size_t)1 << 15);
+  static const size_t min_n = getenv("BPGPU_PIP_TWO_LEVEL_MIN") ? (size_t)atol(getenv("BPGPU_PIP_TWO_LEVEL_MIN")) : ((size_t)1 << 15);
+  return env != 0 && c >= 12 && c <= 16 && n >= min_n;
 }
 static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP_TASK + nbk + 1; }
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
