@@ -194,7 +194,7 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_fine_sort(const uint32_t *goff, 
 // Load balance: a bucket list is cut into tasks of at most PIP_TASK entries (the partial top window
 // has only 2^(252 mod c) non-empty buckets holding n / 2^(252 mod c) points each; equal or
 // low-entropy scalars are worse).  tcount[b] = max(1, ceil(len / PIP_TASK)); its scan gives task ids.
-constexpr uint32_t PIP_TASK = 32;
+constexpr uint32_t PIP_TASK = 16;
 __global__ void __launch_bounds__(256) k_pip_taskcount(const uint32_t *counts, uint32_t *tcount, size_t nb) {
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
