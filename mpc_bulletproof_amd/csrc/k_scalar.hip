@@ -520,6 +520,25 @@ __global__ void __launch_bounds__(64) k_vs_prep(VerifyDims d, const Words8 *chal
   raw_put(aux, ai);   // after the loop ai = val_0^-1 = y^-1
   raw_put(aux + NL, allinv);
 }
+// x^lane for the 64 lanes of a wave through two 8-entry tables in LDS: lanes 0..7 build x^0..x^7, lanes 8..15
+// (x^8)^0..(x^8)^7 -- three conditional products on per-lane bases --, then every lane multiplies one entry of each.
+// 4 products + 5 squares per wave instead of the 7 + 6 of per-lane square-and-multiply.  tab: 16 * NL ints.
+__device__ __forceinline__ Fn wave64_powers(const Fn &x, int tid, int32_t *tab) {
+  Fn x8 = sqr(sqr(sqr(x)));
+  Fn b = tid < 8 ? x : x8, acc = fe_one<FN>();
+  const int e = tid & 7;
+#pragma unroll
+  for (int bit = 0; bit < 3; bit++) {
+    Fn t = mul(acc, b);
+    if ((e >> bit) & 1) acc = t;
+    if (bit < 2) b = sqr(b);
+  }
+  if (tid < 16) raw_put(tab + tid * NL, acc);
+  __syncthreads();
+  Fn r = mul(raw_get(tab + (tid & 7) * NL), raw_get(tab + (8 + (tid >> 3)) * NL));
+  __syncthreads();   // tab may be reused
+  return r;
+}
 // k_verify_scalars, one wave per proof: z powers, g_i / h_i, delta, w_c and the remaining scalars.
 constexpr int VS_TPB = 64;
 __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
@@ -527,6 +546,7 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
                                                            Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all,
                                                            const int32_t *aux_all, int *bad) {
   __shared__ int32_t sm[(VS_AUX + 2) * NL];
+  __shared__ int32_t tab[16 * NL], stab[64 * NL];   // two-level power tables / the s_i of the wave (np == 64 path)
   __builtin_amdgcn_s_setprio(2);   // latency-critical link of the per-batch chain (see k_vs_prep)
   // sm slots (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[k], 34.. u_inv_sq[k], 66 delta, 67 wc
   int32_t *s_usq = sm + 2 * NL, *s_uinvsq = sm + 34 * NL, *s_part = sm + VS_AUX * NL;
@@ -549,7 +569,7 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
     }
   }
   {   // z^(r+1) table (verifier.rs:336,358): lane r starts at z^(r+1) and steps by z^64
-    Fn cur = fn_pow_u32(z, (uint32_t)tid + 1), z64 = z;
+    Fn cur = mul(z, wave64_powers(z, tid, tab)), z64 = z;        // z^(tid + 1)
     for (int t = 0; t < 6; t++) z64 = sqr(z64);
     for (size_t r = tid; r < c.q; r += VS_TPB) { raw_put(zpow + r * NL, cur); cur = mul(cur, z64); }
   }
@@ -564,16 +584,42 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
 
   Fn dpart = fe_zero<FN>();
   int dcnt = 0;
+  // one wave = one pass when the padded size is the wave size (the 64-bit range gadget): y^-i and s_i come from
+  // two-level tables shared through LDS, s_{63-i} is read back from the table of the s_i (16 of the ~100 wave-level
+  // products of this kernel less)
+  const bool wave_sized = np == (size_t)VS_TPB && k == 6;
+  Fn yi_w = fe_zero<FN>(), si_w = fe_zero<FN>(), sr_w = fe_zero<FN>();
+  if (wave_sized) {
+    yi_w = wave64_powers(y_inv, tid, tab);
+    // lanes 0..7: allinv * prod_{bit < 3} u_sq[5 - bit]^e_bit ; lanes 8..15: prod_{bit < 3} u_sq[2 - bit]^e_bit
+    Fn acc = tid < 8 ? allinv : fe_one<FN>();
+    const int e = tid & 7, hi = tid < 8 ? 0 : 3;
+#pragma unroll
+    for (int bit = 0; bit < 3; bit++) {
+      Fn t = mul(acc, raw_get(s_usq + (5 - (hi + bit)) * NL));
+      if ((e >> bit) & 1) acc = t;
+    }
+    if (tid < 16) raw_put(tab + tid * NL, acc);
+    __syncthreads();
+    si_w = mul(raw_get(tab + (tid & 7) * NL), raw_get(tab + (8 + (tid >> 3)) * NL));
+    raw_put(stab + tid * NL, si_w);
+    __syncthreads();
+    sr_w = raw_get(stab + (VS_TPB - 1 - tid) * NL);
+  }
   for (size_t i = tid; i < np; i += VS_TPB) {
     if ((++dcnt & 15) == 0) dpart = fn_reduce(dpart);
-    Fn yi = fn_pow_u32(y_inv, (uint32_t)i);                  // y^-i (verifier.rs:469-471)
-    // s_i and s_{np-1-i} (inner_product_proof.rs:298-307, closed form)
-    Fn si = allinv, sr = allinv;
-    size_t ir = np - 1 - i;
-    for (size_t bb = 0; bb < k; bb++) {
-      Fn us = raw_get(s_usq + (k - 1 - bb) * NL);
-      if ((i >> bb) & 1) si = mul(si, us);
-      if ((ir >> bb) & 1) sr = mul(sr, us);
+    Fn yi, si, sr;
+    if (wave_sized) { yi = yi_w; si = si_w; sr = sr_w; }
+    else {
+      yi = fn_pow_u32(y_inv, (uint32_t)i);                   // y^-i (verifier.rs:469-471)
+      // s_i and s_{np-1-i} (inner_product_proof.rs:298-307, closed form)
+      si = allinv; sr = allinv;
+      size_t ir = np - 1 - i;
+      for (size_t bb = 0; bb < k; bb++) {
+        Fn us = raw_get(s_usq + (k - 1 - bb) * NL);
+        if ((i >> bb) & 1) si = mul(si, us);
+        if ((ir >> bb) & 1) sr = mul(sr, us);
+      }
     }
     Fn wLi = fe_zero<FN>(), wRi = fe_zero<FN>(), wOi = fe_zero<FN>();
     if (i < n) {
