@@ -35,10 +35,10 @@ TRAFFIC_BYTES_PER_LAUNCH = {
     "verify_scalars": int((2 * 5006.0 + 9601.4) * 1024),
 }
 # VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_tabfix<20,16> 5.87e7 + k_verify_windows 3.52e7 + k_verify_scalars 2.20e7 + k_verify_horner_groups 6.45e6 +
+# k_verify_tabfix<20,16> 5.87e7 + k_verify_windows 3.52e7 + k_verify_scalars 1.93e7 + k_verify_horner_groups 6.45e6 +
 # k_verify_horner 4.71e6 + k_vs_prep 1.25e6
 # (9.53e7 + 5.49e7 + 2.08e7 + 1.23e7 + 1.6e6 = 1.85e8 before the column-form field multiplication)
-VALU_WAVE_INSTR_PER_STEP_1024 = 5.87e7 + 3.52e7 + 2.20e7 + 6.45e6 + 4.71e6 + 1.25e6
+VALU_WAVE_INSTR_PER_STEP_1024 = 5.87e7 + 3.52e7 + 1.93e7 + 6.45e6 + 4.71e6 + 1.25e6
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 
