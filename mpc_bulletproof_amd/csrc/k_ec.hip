@@ -72,7 +72,7 @@ __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, si
   // each lane only ever reads back its own stores (same thread, program order): no fence needed
   if constexpr (NP >= 2) {
     // Affine tables: one inversion per lane (Montgomery's trick over the Z of entries 2P..8P of every point) turns
-    // the 63 NP general additions of the main loop into mixed ones (~3 300 -> ~2 400 instructions each) for
+    // the 63 NP general additions of the main loop into mixed ones (~2 300 -> ~1 650 instructions each) for
     // ~80 k instructions of normalisation.  Entry 0 is affine already.  Identity points contribute Z = 1.
     Fp prod = fe_one<FP>();
 #pragma unroll 1
