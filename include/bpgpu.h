@@ -52,12 +52,15 @@ void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for e
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
- * bench.py's `roofline` uses).  kinds: 0 scalar assembly (prep + k_verify_scalars), 5 device transcript, 6 tables +
- * fixed-base MSMs (k_verify_tabfix; or the fused Straus launch), 7 window sums, 4 Horner + verdict (or the verify
- * tail); 1 fixed-base MSM, 2 point import, 3 Straus when launched separately.  read() synchronises, returns sums
+ * bench.py's `roofline` uses).  BPGPU_PROF_KINDS kinds.  Window-parallel verification chain (the default):
+ * 8 front (proof-point tables | inversion pass), 0 scalar assembly (k_verify_scalars), 7 window sums, 9 Horner
+ * groups, 10 back (Horner pass | fixed-base MSMs), 11 verdict; 5 device transcript; 12..15 the stages of the
+ * combined batch check (scalars + weights, proof-point MSM, generator MSM, tail).  Other launch paths: 6 fused Straus +
+ * fixed-base launch, 1 fixed-base MSM, 2 point import, 3 Straus, 4 verify tail.  read() synchronises, returns sums
  * since the last read. */
+#define BPGPU_PROF_KINDS 16
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
-int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]);
+int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t launches[BPGPU_PROF_KINDS]);
 
 /* device memory plumbing */
 int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);

@@ -30,10 +30,10 @@ struct bpgpu_ctx {
   int *d_flag = nullptr;          // device int: bad-input flag
   void *sqrt_tab = nullptr;       // F_p square-root tables of the point codec (built on first use)
   struct bpgpu_gens *gen_tab = nullptr;   // 16-bit-window table of the curve generator (bpgpu_generator_mul)
-  Slot ws[20];                    // grow-only workspace slots
+  Slot ws[24];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
-  std::vector<hipEvent_t> prof_ev[8];
+  std::vector<hipEvent_t> prof_ev[BPGPU_PROF_KINDS];
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
@@ -211,12 +211,12 @@ int bpgpu_profile_enable(bpgpu_ctx *ctx, int on) {
   ctx->prof = on != 0;
   return BPGPU_OK;
 }
-int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[8], uint64_t launches[8]) {
+int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t launches[BPGPU_PROF_KINDS]) {
   if (!ctx || !ms_sum || !launches) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   HIPCK(ctx, hipStreamSynchronize(ctx->st2));
-  for (int k = 0; k < 8; k++) {
+  for (int k = 0; k < BPGPU_PROF_KINDS; k++) {
     ms_sum[k] = 0;
     launches[k] = 0;
     auto &v = ctx->prof_ev[k];
@@ -233,7 +233,8 @@ int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad) {
   if (!ctx || !bad) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipStreamSynchronize(ctx->st2));
-  return flag_read(ctx, bad);
+  CK(flag_read(ctx, bad));
+  return flag_reset(ctx);   // read-and-clear: the verification entry points never reset it themselves
 }
 int bpgpu_host_alloc(size_t bytes, void **out) {
   if (!out) return BPGPU_E_ARG;
@@ -783,19 +784,48 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   void *dstr;
   CK(straus_ws(ctx, 4, nb * nvar, &dstr));
   VerifyDims d{nb, n1, n, np, k, m};
-  CK(flag_reset(ctx));
+  // per-proof canonicity bits of the scalar assembly (every entry is written by the kernel: no reset)
+  void *dbadsc;
+  CK(ws_get(ctx, 20, 2 * nb * sizeof(int32_t), &dbadsc));
+  int32_t *dbadpt = (int32_t *)dbadsc + nb;   // per-proof malformed-point bits of the Straus / separate-launch paths
+  // default: window-parallel variable-base part -- front [tables | inversion pass], scalars, windows, groups,
+  // back [Horner | fixed-base MSMs], verdict (k_ec.hip).  Every launch is on ctx->st.
+  const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
+  const bool no_wp = getenv("BPGPU_WINDOW_PARALLEL") && atoi(getenv("BPGPU_WINDOW_PARALLEL")) == 0;
+  if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
+    void *dwp;
+    CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
+    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc};
+    int32_t *aux = nullptr;
+    size_t aux_stride = 0;
+    const bool fuse_prep = verify_scalars_aux(circuit_dev(c), d, (int32_t *)dzp, &aux, &aux_stride);
+    { ProfScope ps(ctx, 8, ctx->st);
+      verify_wp_front_launch(ctx->st, v, d, (const Words8 *)challenges, aux, aux_stride, fuse_prep); }
+    { ProfScope ps(ctx, 0, ctx->st);
+      verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
+                     (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc, fuse_prep); }
+    { ProfScope ps(ctx, 7, ctx->st);
+      verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
+    { ProfScope ps(ctx, 9, ctx->st);
+      verify_wp_groups(ctx->st, v); }
+    { ProfScope ps(ctx, 10, ctx->st);
+      verify_wp_back(ctx->st, v, g->c, g->table, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
+    { ProfScope ps(ctx, 11, ctx->st);
+      verify_wp_verdict(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
+    return launch_ok(ctx);
+  }
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part
   // (canonicity of the scalars and challenges is checked inside verify_scalars)
+  HIPCK(ctx, hipMemsetAsync(dbadpt, 0, nb * sizeof(int32_t), ctx->st));
   {
     ProfScope ps(ctx, 0, ctx->st);
     verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
-                   (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag);
+                   (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc);
   }
   // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
   // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
   // so the identity points of 1-phase proofs (A_I2, A_O2, S2) are skipped wave-uniformly inside k_straus.
   const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 4;   // read per call: tests vary it
-  const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
   const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
   const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
   const size_t nres = lanes + rem;
@@ -808,26 +838,12 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   ar.pts[0] = (AffDev *)dpts + vnp * lanes; ar.pt_stride[0] = nvar; ar.pt_outer[0] = 1;
   ar.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; ar.sc_stride[0] = nvar * 8; ar.sc_outer[0] = 8;
   ar.inner = nb; ar.out_outer = 1; ar.out_stride = nres;
-  // default: window-parallel variable-base part (tables | windows | Horner + verdict), see k_ec.hip
-  const bool no_wp = getenv("BPGPU_WINDOW_PARALLEL") && atoi(getenv("BPGPU_WINDOW_PARALLEL")) == 0;
-  if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
-    void *dwp;
-    CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
-    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag};
-    { ProfScope ps(ctx, 6, ctx->st);
-      verify_wp_tabfix(ctx->st, v, g->c, g->table, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
-    { ProfScope ps(ctx, 7, ctx->st);
-      verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
-    { ProfScope ps(ctx, 4, ctx->st);
-      verify_wp_horner(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
-    return launch_ok(ctx);
-  }
   bool fused = false;
   if (!no_fuse && lanes && fixed_msm_chunks(g->c, np, nb) == 1) {
     // one launch for both halves of the MSM, reading the proof points straight from the ABI bytes
     StrausArgs af = am;
     for (int j = 0; j < vnp; j++) af.pts[j] = (const AffDev *)points + j * lanes;
-    af.from_boundary = 1; af.bad = ctx->d_flag;
+    af.from_boundary = 1; af.bad = ctx->d_flag; af.bad_inner = dbadpt;
     static const int sprio = getenv("BPGPU_STRAUS_PRIO") ? atoi(getenv("BPGPU_STRAUS_PRIO")) : 0;
     af.prio = sprio;
     ProfScope ps(ctx, 6, ctx->st);
@@ -836,7 +852,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     if (fused && rem) {
       StrausArgs bf = ar;
       bf.pts[0] = (const AffDev *)points + vnp * lanes;
-      bf.from_boundary = 1; bf.bad = ctx->d_flag;
+      bf.from_boundary = 1; bf.bad = ctx->d_flag; bf.bad_inner = dbadpt;
       void *dstr2;
       CK(ws_get(ctx, 12, straus_scratch_bytes(1, nb * rem), &dstr2));
       straus(ctx->st, 1, bf, (JacRaw *)dvres + lanes, nb * rem, dstr2);
@@ -852,7 +868,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
     {
       ProfScope ps(ctx, 2, ctx->st);
-      points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag);
+      points_from_boundary(ctx->st, (const Words8 *)points, (AffDev *)dpts, nb * nvar, ctx->d_flag, dbadpt, nvar);
     }
     {
       ProfScope ps(ctx, 3, ctx->st);
@@ -863,7 +879,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   }
   {
     ProfScope ps(ctx, 4, ctx->st);
-    verify_finalize(ctx->st, (JacRaw *)dvres, nres, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega);
+    verify_finalize(ctx->st, (JacRaw *)dvres, nres, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega, (const int32_t *)dbadsc, dbadpt);
   }
   return launch_ok(ctx);
 }
@@ -893,10 +909,9 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   CK(h2d(ctx, dP, points, nb * nvar * 64));
   CK(h2d(ctx, dS, scalars, nb * 5 * 32));
   CK(h2d(ctx, dC, challenges, nb * (6 + k) * 32));
+  // a malformed proof (off-curve / non-canonical point, non-canonical scalar or challenge) is rejected on its own:
+  // ok[p] = 0, the other verdicts stand (the reference's per-proof FormatError / VerificationError)
   CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, dP, dS, dC, dok, mega ? dmega : nullptr, dfull));
-  int bad = 0;
-  CK(flag_read(ctx, &bad));
-  if (bad) return BPGPU_E_ARG;
   CK(d2h(ctx, ok, dok, nb * 4));
   if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
   if (msm_scalars) CK(d2h(ctx, msm_scalars, dfull, nb * nterms * 32));
@@ -961,9 +976,6 @@ int bpgpu_r1cs_verify_batch_fs(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
   CK(h2d(ctx, dS, scalars, nb * 5 * 32));
   CK(h2d(ctx, dI, init_states, nb * 32));
   CK(verify_fs_locked(ctx, g, c, nb, n1, k, dI, dP, dS, dok, mega ? dmega : nullptr, dcho));
-  int bad = 0;
-  CK(flag_read(ctx, &bad));
-  if (bad) return BPGPU_E_ARG;
   CK(d2h(ctx, ok, dok, nb * 4));
   if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
   if (challenges_out) CK(d2h(ctx, challenges_out, dcho, nb * (6 + k) * 32));

@@ -7,6 +7,7 @@
 // kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
 #include <cstdlib>
 #include "fixed_body.cuh"
+#include "vs_prep.cuh"
 
 using namespace bp;
 
@@ -51,7 +52,7 @@ __device__ __forceinline__ void straus_body(const StrausArgs &a, JacRaw *out, si
 #pragma unroll
       for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
       if (!aff_from_boundary(P, w)) {
-        if (live) atomicOr(a.bad, 1);
+        if (live) { atomicOr(a.bad, 1); if (a.bad_inner) a.bad_inner[rr] = 1; }
         P.x = fe_zero<FP>();
         P.y = fe_zero<FP>();
       }
@@ -174,23 +175,32 @@ void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, siz
 }
 
 // ---- window-parallel variable-base part of the mega_check (the 11 + m + 2k proof points of every proof) -----------
-// Straus with a doubling chain per lane pays 252 doublings for every 4 points.  Here the three phases are split:
-//   tables   lane per 4 points (role-major): {1..8} P_j, normalised to affine with one inversion per lane,
-//            written as AffRaw rows tab[proof][point][entry]; the points come straight from the ABI bytes
+// Straus with a doubling chain per lane pays 252 doublings for every 4 points.  Here the phases are split, and every
+// launch carries whatever else of the batch is independent of it, so that one batch is a chain of six launches
+// none of which waits on a serial 16-wave kernel alone:
+//   front    [tables | prep]   tables: lane per TNP points (role-major): {1..8} P_j, normalised to affine with one
+//                              inversion per lane, written as AffRaw rows tab[proof][point][entry]; the points come
+//                              straight from the ABI bytes and are validated here (per-lane verdict in bad_lane).
+//                              prep: the inversion pass of the scalar assembly (vs_prep.cuh), lane per proof.
+//   scalars  k_verify_scalars (k_scalar.hip), wave per proof
 //   windows  one WAVE per proof, lane w = window w (64 signed 4-bit windows): S_w = sum_j d_{j,w} P_j by mixed
 //            additions from the tables -- no doublings
-//   horner   one LANE per proof: sum_w 16^w S_w with the proof's only 252 doublings, + the fixed-base partial,
-//            identity test (replaces k_verify_finalize)
-// ~80 k wave-instructions per proof against ~113 k for the per-lane Straus, and a shorter kernel chain.
+//   groups   lane per 8 windows: T_g = sum_{i<8} 16^i S_{8g+i}
+//   back     [horner | fixed]  horner: one LANE per proof: sum_g 2^(32 g) T_g (the proof's 224 remaining dependent
+//                              doublings: the longest link of the chain); fixed: the table-lookup MSMs over the
+//                              generators (fixed_body.cuh), which need nothing but the scalars and hide behind it
+//   verdict  lane per proof: variable-base sum + fixed-base partial, identity test, malformed-input bits, mega_check
+// ~80 k wave-instructions per proof against ~113 k for the per-lane Straus.
 struct AffRaw { int32_t v[2 * NL]; };   // raw Montgomery limbs x[9] y[9]; all zero = identity
 struct TablesArgs {
   const AffDev *points;     // ABI bytes, nb x nvar x 64 B
-  size_t nb, nvar, lanes;   // lanes = ceil(nvar / 4) per proof
+  size_t nb, nvar, lanes;   // lanes = ceil(nvar / TNP) per proof
   AffRaw *tab;              // nb x nvar x 8
-  int32_t *scratch;         // lane-strided staging: blocks x 4 x 8 x STE x 64 int32
-  int *bad;
+  int32_t *scratch;         // lane-strided staging: blocks x TNP x 8 x STE x 64 int32
+  int *bad;                 // context-wide diagnostic flag
+  int32_t *bad_lane;        // nb x lanes: 1 = one of the lane's points is malformed (every lane writes its entry)
 };
-constexpr int TNP = 8;
+template <int TNP>
 __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
   constexpr int TPB = 64;
   const int tid = threadIdx.x;
@@ -204,6 +214,7 @@ __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
   auto ld = [&](const int32_t *q, int off) { Fp x; for (int t = 0; t < NL; t++) x.v[t] = q[(off + t) * TPB]; return x; };
   auto st = [&](int32_t *q, int off, const Fp &x) { for (int t = 0; t < NL; t++) q[(off + t) * TPB] = x.v[t]; };
   unsigned skip = 0, pinf = 0;   // bit j: wave-uniform / per-lane "point j is the identity (or beyond nvar)"
+  bool malformed = false;
 #pragma unroll
   for (int j = 0; j < TNP; j++) {
     const size_t v = r + (size_t)j * a.lanes;
@@ -216,7 +227,7 @@ __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
 #pragma unroll
       for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
       if (!aff_from_boundary(P, w)) {
-        if (live) atomicOr(a.bad, 1);
+        malformed = true;
         P.x = fe_zero<FP>();
         P.y = fe_zero<FP>();
       }
@@ -231,6 +242,10 @@ __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
       st(dst, 0, m.X); st(dst, NL, m.Y); st(dst, 2 * NL, m.Z);
       if (e + 1 < SE) m = jac_madd(m, P);
     }
+  }
+  if (live) {
+    a.bad_lane[p * a.lanes + r] = malformed ? 1 : 0;
+    if (malformed) atomicOr(a.bad, 1);
   }
   // Montgomery's trick over the Z of entries 2P..8P of the lane's points (entry 0 is affine already)
   Fp prod = fe_one<FP>();
@@ -272,6 +287,12 @@ __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
     }
   }
 }
+// tables (blocks [0, table_blocks)) and the inversion pass of the scalar assembly in one launch
+template <int TNP>
+__global__ void __launch_bounds__(64) k_verify_front(TablesArgs t, unsigned table_blocks, VsPrepArgs prep) {
+  if (blockIdx.x < table_blocks) tables_body<TNP>(t, blockIdx.x);
+  else vs_prep_body(prep, blockIdx.x - table_blocks);
+}
 // one wave per proof, lane = window
 __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const uint32_t *scalars /* nb x nvar x 8 words */,
                                                        size_t nvar, JacRaw *winsum) {
@@ -301,10 +322,8 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
 }
 // Horner over the 64 window sums in two stages.  Stage 1, one lane per (proof, group of 8 windows):
 // T_g = sum_{i<8} 16^i S_{8g+i} (28 doublings, 7 additions), written over S_{8g}.  Stage 2, one lane per proof:
-// sum_g 2^(32 g) T_g (224 doublings, 7 additions) + the fixed-base partial, identity test.  The dependency chain of a
-// batch loses 49 of its 63 general additions for 8 x 28 extra doublings per proof (+3 % instructions): a single batch
-// takes 1.70 instead of 1.84 ms and bursts of 4 run at 1.58 instead of 1.27 M/s; the steady state is unchanged (it is
-// bound by instruction issue, not by the length of the chain).  BPGPU_HORNER_GROUPS=0 selects the one-stage pass.
+// sum_g 2^(32 g) T_g (224 doublings, 7 additions).  The dependency chain of a batch loses 49 of its 63 general
+// additions for 8 x 28 extra doublings per proof (+3 % instructions).  BPGPU_HORNER_GROUPS=0 selects the one-stage pass.
 constexpr int HG = 8;   // windows per group
 __global__ void __launch_bounds__(64) k_verify_horner_groups(JacRaw *winsum, size_t nb) {
   __builtin_amdgcn_s_setprio(2);
@@ -321,21 +340,37 @@ __global__ void __launch_bounds__(64) k_verify_horner_groups(JacRaw *winsum, siz
   raw_store(&s[0], acc);
 }
 // one lane per proof over `count` partial sums `stride` slots apart, `dbl` doublings between them
-__global__ void __launch_bounds__(64) k_verify_horner(const JacRaw *winsum, const JacRaw *fixed, size_t nb, int32_t *ok,
-                                                      Words8 *mega, int count, int stride, int dbl) {
+struct HornerArgs { const JacRaw *winsum; JacRaw *varsum; size_t nb; int count, stride, dbl; };
+__device__ __forceinline__ void horner_body(const HornerArgs &h, size_t blk) {
   __builtin_amdgcn_s_setprio(2);   // 16 waves carrying the longest link of the chain
+  size_t p = blk * 64 + threadIdx.x;
+  if (p >= h.nb) return;
+  Jac acc = raw_load(&h.winsum[p * 64 + (size_t)(h.count - 1) * h.stride]);
+#pragma unroll 1
+  for (int w = h.count - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int d = 0; d < h.dbl; d++) acc = jac_dbl(acc);
+    acc = jac_add(acc, raw_load(&h.winsum[p * 64 + (size_t)w * h.stride]));
+  }
+  raw_store(&h.varsum[p], acc);
+}
+// the Horner lanes (blocks [0, horner_blocks)) and the small fixed-base MSMs in one launch
+template <int C, int LPM>
+__global__ void __launch_bounds__(64) k_verify_back(HornerArgs h, unsigned horner_blocks, FixedSmallArgs f) {
+  if (blockIdx.x < horner_blocks) horner_body(h, blockIdx.x);
+  else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - horner_blocks);
+}
+// lane per proof: variable-base sum + fixed-base partial; ok = identity and every input of the proof well-formed
+__global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, const JacRaw *fixed, size_t nb, const int32_t *bad_lane,
+                                                       size_t lanes, const int32_t *bad_sc, int32_t *ok, Words8 *mega) {
+  __builtin_amdgcn_s_setprio(2);
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb) return;
-  Jac acc = raw_load(&winsum[p * 64 + (size_t)(count - 1) * stride]);
-#pragma unroll 1
-  for (int w = count - 2; w >= 0; w--) {
-#pragma unroll 1
-    for (int d = 0; d < dbl; d++) acc = jac_dbl(acc);
-    acc = jac_add(acc, raw_load(&winsum[p * 64 + (size_t)w * stride]));
-  }
-  acc = jac_add(acc, raw_load(&fixed[p]));
-  bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
-  ok[p] = inf ? 1 : 0;
+  Jac acc = jac_add(raw_load(&varsum[p]), raw_load(&fixed[p]));
+  const bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
+  int malformed = bad_sc ? bad_sc[p] : 0;
+  for (size_t l = 0; l < lanes; l++) malformed |= bad_lane[p * lanes + l];
+  ok[p] = (inf && !malformed) ? 1 : 0;
   if (mega) {
     uint32_t w[16];
     if (inf) {
@@ -348,67 +383,86 @@ __global__ void __launch_bounds__(64) k_verify_horner(const JacRaw *winsum, cons
     for (int j = 0; j < 8; j++) { mega[2 * p].w[j] = w[j]; mega[2 * p + 1].w[j] = w[8 + j]; }
   }
 }
-// tables (blocks [0, table_blocks)) and the small fixed-base MSMs in one launch
-template <int C, int LPM>
-__global__ void __launch_bounds__(64) k_verify_tabfix(TablesArgs t, unsigned table_blocks, FixedSmallArgs f) {
-  if (blockIdx.x < table_blocks) tables_body(t, blockIdx.x);
-  else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - table_blocks);
+// points per table lane: 8 = fewest instructions (one inversion per 8 points), 4 (default) = half the dependency chain of
+// the front launch for +1.3 % instructions per batch
+static int wp_tnp() {
+  static const int v = getenv("BPGPU_TABLE_NP") ? atoi(getenv("BPGPU_TABLE_NP")) : 4;
+  return v == 8 ? 8 : (v == 2 ? 2 : 4);
 }
+struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; };
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
-  size_t lanes = (nvar + TNP - 1) / TNP, blocks = (nb * lanes + 63) / 64;
-  return blocks * TNP * SE * STE * 64 * 4 + nb * nvar * SE * sizeof(AffRaw) + nb * 64 * sizeof(JacRaw) + 256;
+  const size_t tnp = wp_tnp(), lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
+  return al256(blocks * tnp * SE * STE * 64 * 4) + al256(nb * nvar * SE * sizeof(AffRaw)) + al256(nb * 64 * sizeof(JacRaw)) +
+         al256(nb * sizeof(JacRaw)) + al256(nb * lanes * 4);
 }
-template <int C>
-static void launch_tabfix(hipStream_t st, const TablesArgs &t, unsigned tb, const FixedSmallArgs &f) {
-  if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_tabfix<C, 16>), dim3(tb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, t, tb, f);
-  else hipLaunchKernelGGL((k_verify_tabfix<C, 32>), dim3(tb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, t, tb, f);
-}
-// The whole MSM + verdict of a batch in three launches (timed separately by the API's profile scopes).
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
   const size_t total = (2 + 2 * n) * (252 / c + 1);
   return nb >= 1 && total <= 16384 && nvar && (c == 8 || c == 16 || c == 20);
 }
-static TablesArgs wp_args(const VerifyWp &v, JacRaw **winsum, unsigned *blocks) {
-  TablesArgs t{};
-  t.points = v.points_abi; t.nb = v.nb; t.nvar = v.nvar; t.lanes = (v.nvar + TNP - 1) / TNP; t.bad = v.bad;
-  const size_t nblk = (v.nb * t.lanes + 63) / 64;
+static WpLayout wp_layout(const VerifyWp &v) {
+  WpLayout L{};
+  const size_t tnp = wp_tnp();
+  L.t.points = v.points_abi; L.t.nb = v.nb; L.t.nvar = v.nvar; L.t.lanes = (v.nvar + tnp - 1) / tnp; L.t.bad = v.bad;
+  const size_t nblk = (v.nb * L.t.lanes + 63) / 64;
   uint8_t *sp = (uint8_t *)v.scratch;
-  t.scratch = (int32_t *)sp; sp += nblk * TNP * SE * STE * 64 * 4;
-  t.tab = (AffRaw *)sp; sp += v.nb * v.nvar * SE * sizeof(AffRaw);
-  *winsum = (JacRaw *)(((uintptr_t)sp + 63) & ~(uintptr_t)63);
-  *blocks = (unsigned)nblk;
-  return t;
+  L.t.scratch = (int32_t *)sp; sp += al256(nblk * tnp * SE * STE * 64 * 4);
+  L.t.tab = (AffRaw *)sp; sp += al256(v.nb * v.nvar * SE * sizeof(AffRaw));
+  L.winsum = (JacRaw *)sp; sp += al256(v.nb * 64 * sizeof(JacRaw));
+  L.varsum = (JacRaw *)sp; sp += al256(v.nb * sizeof(JacRaw));
+  L.t.bad_lane = (int32_t *)sp;
+  L.blocks = (unsigned)nblk;
+  return L;
 }
-// tables of the proof points | table-lookup MSMs over the generators (fixed scalars as for fixed_msm)
-void verify_wp_tabfix(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
-                      const uint32_t *fixed_scalars, size_t sc_stride, JacRaw *out_fixed) {
-  JacRaw *winsum;
-  unsigned blocks;
-  TablesArgs t = wp_args(v, &winsum, &blocks);
-  FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
-  if (c == 8) launch_tabfix<8>(st, t, blocks, f);
-  else if (c == 16) launch_tabfix<16>(st, t, blocks, f);
-  else launch_tabfix<20>(st, t, blocks, f);
+// tables of the proof points | inversion pass of the scalar assembly (with_prep = false: tables only)
+void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
+                            size_t aux_stride, bool with_prep) {
+  VsPrepArgs prep{d, challenges, aux, aux_stride};
+  if (!with_prep) prep.d.nb = 0;
+  WpLayout L = wp_layout(v);
+  const unsigned pb = (unsigned)((prep.d.nb + 63) / 64);
+  switch (wp_tnp()) {
+    case 8: hipLaunchKernelGGL((k_verify_front<8>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
+    case 2: hipLaunchKernelGGL((k_verify_front<2>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
+    default: hipLaunchKernelGGL((k_verify_front<4>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
+  }
 }
 // var_scalars: nb x nvar x 8 words in operand order
 void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_scalars) {
-  JacRaw *winsum;
-  unsigned blocks;
-  TablesArgs t = wp_args(v, &winsum, &blocks);
-  hipLaunchKernelGGL(k_verify_windows, dim3(v.nb), dim3(64), 0, st, t.tab, var_scalars, v.nvar, winsum);
+  WpLayout L = wp_layout(v);
+  hipLaunchKernelGGL(k_verify_windows, dim3(v.nb), dim3(64), 0, st, L.t.tab, var_scalars, v.nvar, L.winsum);
 }
-void verify_wp_horner(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
-  JacRaw *winsum;
-  unsigned blocks;
-  (void)wp_args(v, &winsum, &blocks);
+static bool wp_grouped() {
+  static const bool g = !(getenv("BPGPU_HORNER_GROUPS") && atoi(getenv("BPGPU_HORNER_GROUPS")) == 0);
+  return g;
+}
+void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   static_assert(num_windows<SW>() == 64, "64 window sums per proof");
-  static const bool grouped = !(getenv("BPGPU_HORNER_GROUPS") && atoi(getenv("BPGPU_HORNER_GROUPS")) == 0);
-  if (grouped) {
-    hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, winsum, v.nb);
-    hipLaunchKernelGGL(k_verify_horner, dim3((v.nb + 63) / 64), dim3(64), 0, st, winsum, fixed, v.nb, ok, mega, 64 / HG, HG, SW * HG);
-  } else {
-    hipLaunchKernelGGL(k_verify_horner, dim3((v.nb + 63) / 64), dim3(64), 0, st, winsum, fixed, v.nb, ok, mega, 64, 1, SW);
-  }
+  if (!wp_grouped()) return;
+  WpLayout L = wp_layout(v);
+  hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
+}
+template <int C>
+static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f) {
+  if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_back<C, 16>), dim3(hb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, h, hb, f);
+  else hipLaunchKernelGGL((k_verify_back<C, 32>), dim3(hb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, h, hb, f);
+}
+// Horner pass over the window sums | table-lookup MSMs over the generators (fixed scalars as for fixed_msm)
+void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
+                    const uint32_t *fixed_scalars, size_t sc_stride, JacRaw *out_fixed) {
+  WpLayout L = wp_layout(v);
+  HornerArgs h{L.winsum, L.varsum, v.nb, 64, 1, SW};
+  if (wp_grouped()) { h.count = 64 / HG; h.stride = HG; h.dbl = SW * HG; }
+  const unsigned hb = (unsigned)((v.nb + 63) / 64);
+  FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
+  if (c == 8) launch_back<8>(st, h, hb, f);
+  else if (c == 16) launch_back<16>(st, h, hb, f);
+  else launch_back<20>(st, h, hb, f);
+}
+void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
+  WpLayout L = wp_layout(v);
+  hipLaunchKernelGGL(k_verify_verdict, dim3((v.nb + 63) / 64), dim3(64), 0, st, L.varsum, fixed, v.nb, L.t.bad_lane, L.t.lanes,
+                     v.bad_sc, ok, mega);
 }
 
 // Both halves of a batch's mega_check MSM in ONE launch: blocks [0, straus_blocks) run the per-lane Straus over the

@@ -15,7 +15,8 @@ using namespace bp;
 namespace bpk {
 
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, AffDev *out, size_t n, int *bad) {
+__global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, AffDev *out, size_t n, int *bad, int32_t *bad_unit,
+                                                              size_t per_unit) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   uint32_t w[16];
@@ -25,14 +26,15 @@ __global__ void __launch_bounds__(256) k_points_from_boundary(const Words8 *xy, 
   bool ok = aff_from_boundary(a, w);
   if (!ok) {
     atomicOr(bad, 1);
+    if (bad_unit) bad_unit[i / per_unit] = 1;
     a.x = fe_zero<FP>();
     a.y = fe_zero<FP>();
   }
   aff_store(&out[i], a);
 }
-void points_from_boundary(hipStream_t st, const Words8 *xy, AffDev *out, size_t n, int *bad) {
+void points_from_boundary(hipStream_t st, const Words8 *xy, AffDev *out, size_t n, int *bad, int32_t *bad_unit, size_t per_unit) {
   if (!n) return;
-  hipLaunchKernelGGL(k_points_from_boundary, dim3((n + 255) / 256), dim3(256), 0, st, xy, out, n, bad);
+  hipLaunchKernelGGL(k_points_from_boundary, dim3((n + 255) / 256), dim3(256), 0, st, xy, out, n, bad, bad_unit, per_unit ? per_unit : 1);
 }
 
 __global__ void __launch_bounds__(64) k_jac_to_boundary(const JacRaw *in, Words8 *xy, size_t n) {
@@ -140,7 +142,8 @@ void fixed_table_build(hipStream_t st, int c, const AffDev *gens, size_t ngens, 
 // ------------------------------------------------------------------------------------------------
 // 32 lanes per proof (two proofs per wave): gather, butterfly-reduce with wave shuffles, test identity.
 __global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_t nvar, const JacRaw *fixed,
-                                                        size_t nb, int32_t *ok, Words8 *mega) {
+                                                        size_t nb, int32_t *ok, Words8 *mega, const int32_t *bad_sc,
+                                                        const int32_t *bad_pt) {
   __builtin_amdgcn_s_setprio(2);   // last link of the per-batch chain: finish ahead of other batches' bulk MSM waves
   const int lane = threadIdx.x & 31;
   size_t p = (size_t)blockIdx.x * 2 + (threadIdx.x >> 5);
@@ -164,7 +167,8 @@ __global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_
   }
   if (lane == 0 && live) {
     bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
-    ok[p] = inf ? 1 : 0;
+    const bool malformed = (bad_sc && bad_sc[p]) || (bad_pt && bad_pt[p]);
+    ok[p] = (inf && !malformed) ? 1 : 0;
     if (mega) {
       uint32_t w[16];
       if (inf) {
@@ -179,9 +183,9 @@ __global__ void __launch_bounds__(64) k_verify_finalize(const JacRaw *var, size_
   }
 }
 void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRaw *fixed, size_t nb,
-                     int32_t *ok, Words8 *mega) {
+                     int32_t *ok, Words8 *mega, const int32_t *bad_sc, const int32_t *bad_pt) {
   if (!nb) return;
-  hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega);
+  hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega, bad_sc, bad_pt);
 }
 
 // dst[p * dst_outer + i] = src[p * src_outer + i], i < cnt (16-byte vector copies)

@@ -3,67 +3,13 @@
 //
 // Hot-path rows: a2 (scalar half of fold_witness), a4 inner_product, a5
 // verification_scalars, a6 batch_inverse, a7 flattened_constraints, a9 verifier scalar assembly.
-#include "fe29.cuh"
 #include <cstdlib>
-#include "kernels.h"
+#include "fn_dev.cuh"
+#include "vs_prep.cuh"
 
 using namespace bp;
 
 namespace bpk {
-
-__device__ __forceinline__ Fn load_plain(const Words8 *p) {   // plain canonical words -> Montgomery
-  uint32_t w[8];
-#pragma unroll
-  for (int j = 0; j < 8; j++) w[j] = p->w[j];
-  return to_mont(unpack<FN>(w));
-}
-__device__ __forceinline__ void store_plain(Words8 *p, const Fn &x) {   // Montgomery -> plain canonical words
-  uint32_t w[8];
-  pack(w, from_mont(x));
-#pragma unroll
-  for (int j = 0; j < 8; j++) p->w[j] = w[j];
-}
-__device__ __forceinline__ Fn fn_from_u32(uint32_t v) {
-  Fn t = fe_zero<FN>();
-  t.v[0] = (int32_t)(v & LMASK);
-  t.v[1] = (int32_t)(v >> LB);
-  return to_mont(t);
-}
-__device__ __forceinline__ Fn fn_pow_u32(Fn base, uint32_t e) {   // base^e, e >= 0
-  Fn acc = fe_one<FN>();
-  while (e) {
-    if (e & 1) acc = mul(acc, base);
-    e >>= 1;
-    if (e) base = sqr(base);
-  }
-  return acc;
-}
-// Lazy sums keep limbs small but let the VALUE grow (top limb has ~11 spare bits over a 252-bit
-// modulus): fold the value back into (-eps, (1+eps) n) with one Montgomery multiplication by R mod n.
-// Rule used below: never add more than ~64 reduced values (x 64 lanes of a wave sum) without it.
-__device__ __forceinline__ Fn fn_reduce(const Fn &x) { return mul(x, fe_one<FN>()); }
-// raw limb I/O for device scratch (zpow tables, partial sums)
-__device__ __forceinline__ void raw_put(int32_t *d, const Fn &x) {
-#pragma unroll
-  for (int j = 0; j < NL; j++) d[j] = x.v[j];
-}
-__device__ __forceinline__ Fn raw_get(const int32_t *s) {
-  Fn x;
-#pragma unroll
-  for (int j = 0; j < NL; j++) x.v[j] = s[j];
-  return x;
-}
-// wave-level sum of one Fn per lane (shuffle tree); result in every lane
-__device__ __forceinline__ Fn wave_sum(Fn x) {
-#pragma unroll 1
-  for (int off = 32; off > 0; off >>= 1) {
-    Fn o;
-#pragma unroll
-    for (int j = 0; j < NL; j++) o.v[j] = __shfl_xor(x.v[j], off, 64);
-    x = add(x, o);
-  }
-  return x;
-}
 
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_scalars_check(const Words8 *in, size_t n, int *bad) {
@@ -73,6 +19,15 @@ __global__ void __launch_bounds__(256) k_scalars_check(const Words8 *in, size_t 
 #pragma unroll
   for (int j = 0; j < 8; j++) w[j] = in[i].w[j];
   if (!words_lt_mod<FN>(w)) atomicOr(bad, 1);
+}
+// the same with the verdict attributed to a proof: element i belongs to proof i / per; writes 1 only (zero the array first)
+__global__ void __launch_bounds__(256) k_scalars_check_proof(const Words8 *in, size_t n, size_t per, int *bad, int32_t *bad_proof) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) w[j] = in[i].w[j];
+  if (!words_lt_mod<FN>(w)) { if (bad) atomicOr(bad, 1); bad_proof[i / per] = 1; }
 }
 void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad) {
   if (!n) return;
@@ -489,37 +444,7 @@ void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Wor
 // trick around one binary-GCD inversion, then u_j^2, u_j^-2, prod u_j^-1.  (Run by one lane of a per-proof block
 // this serial chain cost a full wave's issue slots per proof: a quarter of all instructions of a verification.)
 // aux per proof (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[32], 34.. u_inv_sq[32] (+ partials, large path)
-constexpr int VS_AUX = 66;
-__global__ void __launch_bounds__(64) k_vs_prep(VerifyDims d, const Words8 *challenges, int32_t *aux_all, size_t aux_stride) {
-  // a short, serial kernel on every batch's critical path that shares the chip with the bulk MSM waves of the
-  // other in-flight batches: raise its waves' issue priority (rocprofv3: 1.8 ms per launch overlapped vs 0.2 ms solo)
-  __builtin_amdgcn_s_setprio(3);
-  const size_t p = (size_t)blockIdx.x * 64 + threadIdx.x, k = d.k;
-  if (p >= d.nb) return;
-  const Words8 *ch = challenges + p * (6 + k);
-  int32_t *aux = aux_all + p * aux_stride * NL;
-  Fn acc = fe_one<FN>();
-  // prefix products live in aux (slots 2.. as scratch) to keep the lane's register footprint small
-  raw_put(aux + 2 * NL, acc);
-  acc = load_plain(&ch[0]);
-  for (size_t i = 0; i < k; i++) { raw_put(aux + (3 + i) * NL, acc); acc = mul(acc, load_plain(&ch[6 + i])); }
-  // Fermat here: with a different proof in every lane the binary GCD's data-dependent branches diverge (measured
-  // 315 k wave instructions, 1 ms of latency per launch) while the fixed exponent keeps the wave uniform (~125 k)
-  Fn ai = inv(acc);
-  Fn allinv = fe_one<FN>();
-  for (int i = (int)k; i >= 1; i--) {
-    Fn val = load_plain(&ch[6 + i - 1]);
-    Fn vi = mul(ai, raw_get(aux + (2 + i) * NL));   // (prod_{t<i} val_t)^-1 ... * prefix = val_i^-1
-    ai = mul(ai, val);
-    allinv = mul(allinv, vi);
-    raw_put(aux + (2 + i) * NL, sqr(val));          // slot 2 + i is free again: final home of u_sq[i-1] is 2 + (i-1)
-    raw_put(aux + (34 + i - 1) * NL, sqr(vi));
-  }
-  // shift u_sq down by one slot (slot 2 + i -> 2 + i - 1) and store y_inv, allinv
-  for (size_t i = 1; i <= k; i++) raw_put(aux + (2 + i - 1) * NL, raw_get(aux + (2 + i) * NL));
-  raw_put(aux, ai);   // after the loop ai = val_0^-1 = y^-1
-  raw_put(aux + NL, allinv);
-}
+__global__ void __launch_bounds__(64) k_vs_prep(VsPrepArgs a) { vs_prep_body(a, blockIdx.x); }
 // x^lane for the 64 lanes of a wave through two 8-entry tables in LDS: lanes 0..7 build x^0..x^7, lanes 8..15
 // (x^8)^0..(x^8)^7 -- three conditional products on per-lane bases --, then every lane multiplies one entry of each.
 // 4 products + 5 squares per wave instead of the 7 + 6 of per-lane square-and-multiply.  tab: 16 * NL ints.
@@ -544,7 +469,7 @@ constexpr int VS_TPB = 64;
 __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyDims d, const Words8 *challenges,
                                                            const Words8 *proof_scalars, Words8 *fixed_sc,
                                                            Words8 *var_sc, Words8 *full_sc, int32_t *zpow_all,
-                                                           const int32_t *aux_all, int *bad) {
+                                                           const int32_t *aux_all, int *bad, int32_t *bad_proof) {
   __shared__ int32_t sm[(VS_AUX + 2) * NL];
   __shared__ int32_t tab[16 * NL], stab[64 * NL];   // two-level power tables / the s_i of the wave (np == 64 path)
   __builtin_amdgcn_s_setprio(2);   // latency-critical link of the per-batch chain (see k_vs_prep)
@@ -559,13 +484,19 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
   (void)y;
   for (int t = tid; t < VS_AUX * NL; t += VS_TPB) sm[t] = aux_all[p * VS_AUX * NL + t];
-  if (bad) {   // canonical-encoding check of this proof's 6 + k challenges and 5 scalars (k_scalars_check)
+  if (bad || bad_proof) {   // canonical-encoding check of this proof's 6 + k challenges and 5 scalars (k_scalars_check)
+    bool mine = false;
     for (size_t t = tid; t < 11 + k; t += VS_TPB) {
       const Words8 *src = t < 6 + k ? &ch[t] : &ps[t - 6 - k];
       uint32_t w[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) w[j] = src->w[j];
-      if (!words_lt_mod<FN>(w)) atomicOr(bad, 1);
+      if (!words_lt_mod<FN>(w)) mine = true;
+    }
+    const bool any = __any(mine);          // VS_TPB == 64: the block is one wave
+    if (tid == 0) {
+      if (any && bad) atomicOr(bad, 1);
+      if (bad_proof) bad_proof[p] = any ? 1 : 0;   // the only writer of this proof's entry: no reset needed
     }
   }
   {   // z^(r+1) table (verifier.rs:336,358): lane r starts at z^(r+1) and steps by z^64
@@ -829,24 +760,34 @@ static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {
   return d.nb * ((c.q ? c.q : 1) + (vs_large(c, d) ? VSL_AUX : VS_AUX)) * NL;
 }
+bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_scratch, int32_t **aux, size_t *aux_stride) {
+  if (vs_large(c, d)) return false;
+  *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
+  *aux_stride = VS_AUX;
+  return true;
+}
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
-                    int32_t *zpow_scratch, int *bad) {
+                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof, bool prep_done) {
   if (!d.nb) return;
   int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
   if (!vs_large(c, d)) {
-    hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, d, challenges, aux, (size_t)VS_AUX);
+    if (!prep_done) hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, VsPrepArgs{d, challenges, aux, (size_t)VS_AUX});
     hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
-                       fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad);
+                       fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad, bad_proof);
     return;
   }
-  if (bad) { scalars_check(st, challenges, d.nb * (6 + d.k), bad); scalars_check(st, proof_scalars, d.nb * 5, bad); }
+  if (bad_proof) {
+    (void)hipMemsetAsync(bad_proof, 0, d.nb * sizeof(int32_t), st);
+    hipLaunchKernelGGL(k_scalars_check_proof, dim3((d.nb * (6 + d.k) + 255) / 256), dim3(256), 0, st, challenges, d.nb * (6 + d.k), 6 + d.k, bad, bad_proof);
+    hipLaunchKernelGGL(k_scalars_check_proof, dim3((d.nb * 5 + 255) / 256), dim3(256), 0, st, proof_scalars, d.nb * 5, (size_t)5, bad, bad_proof);
+  } else if (bad) { scalars_check(st, challenges, d.nb * (6 + d.k), bad); scalars_check(st, proof_scalars, d.nb * 5, bad); }
   auto parts = [](size_t work) { size_t b = (work + VSL_TPB - 1) / VSL_TPB; return (int)(b < 1 ? 1 : (b > VSL_PARTS ? VSL_PARTS : b)); };
   const size_t o = 3 * d.n + d.m;
   (void)o;
   // number of `One` terms is only known on the device (col_ptr); size its grid from the row count
   const int gh_parts = parts(d.padded_n), wc_parts = parts(c.q);
-  hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, d, challenges, aux, (size_t)VSL_AUX);
+  hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, VsPrepArgs{d, challenges, aux, (size_t)VSL_AUX});
   if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, d.nb), dim3(256), 0, st, challenges + 1, (6 + d.k) * 8, c.q, zpow_scratch);
   hipLaunchKernelGGL(k_vsl_gh, dim3(gh_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, challenges, proof_scalars, fixed_sc,
                      full_sc, zpow_scratch, aux);

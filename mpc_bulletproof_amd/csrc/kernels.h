@@ -13,7 +13,9 @@ struct Words8 { uint32_t w[8]; };   // one 256-bit field element (plain canonica
 
 // ---- points ------------------------------------------------------------------------------------
 // boundary bytes -> device affine; sets *bad (int) to 1 on a non-canonical / off-curve point
-void points_from_boundary(hipStream_t st, const Words8 *xy /*2 per point*/, AffDev *out, size_t n, int *bad);
+// bad_unit (optional, zeroed by the caller): [i / per_unit] = 1 for a malformed point i (per-proof attribution)
+void points_from_boundary(hipStream_t st, const Words8 *xy /*2 per point*/, AffDev *out, size_t n, int *bad,
+                          int32_t *bad_unit = nullptr, size_t per_unit = 1);
 // JacRaw -> boundary bytes (one inversion per point)
 void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy_out, size_t n);
 // JacRaw[n] -> device affine, Montgomery's trick in runs of `run` points per lane
@@ -37,6 +39,7 @@ struct StrausArgs {
   size_t out_stride;  // 0 = 1
   int from_boundary;  // pts are ABI bytes (x || y canonical LE words): validate + convert in the kernel, *bad |= 1 on failure
   int *bad;
+  int32_t *bad_inner; // optional (zeroed by the caller): [r] = 1 when a point of inner index r (the proof, role-major) is malformed
   int prio;           // fused launch: raise the Straus waves' issue priority
 };
 // scratch: straus_scratch_bytes(np, n) bytes of device memory private to this launch until it completes
@@ -49,15 +52,22 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
                       const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride_words,
                       JacRaw *out_fixed, size_t nb);
 
-// Window-parallel variant of the same (k_ec.hip): tables | windows | Horner + verdict in three launches; the last one
-// writes ok / mega itself (no verify_finalize).
-struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; };
+// Window-parallel variant of the same (k_ec.hip): front [tables | inversion pass] -> (k_verify_scalars) -> windows -> groups ->
+// back [Horner | fixed-base MSMs] -> verdict, which writes ok / mega itself (no verify_finalize).
+// bad_sc: the per-proof canonicity bits written by verify_scalars (nullable)
+struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; };
+struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
+struct VsPrepArgs;
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n);
-void verify_wp_tabfix(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
-                      const uint32_t *fixed_scalars, size_t sc_stride_words, JacRaw *out_fixed);
+// prep_* describe the inversion pass to fuse (vs_prep.cuh; prep_nb == 0: tables only)
+void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
+                            size_t aux_stride, bool with_prep);
 void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_scalars);
-void verify_wp_horner(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega);
+void verify_wp_groups(hipStream_t st, const VerifyWp &v);
+void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
+                    const uint32_t *fixed_scalars, size_t sc_stride_words, JacRaw *out_fixed);
+void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega);
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
 int pippenger_window(size_t n);
@@ -95,8 +105,9 @@ void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap,
 // ---- verification tail -------------------------------------------------------------------------
 // per proof: sum of nvar variable-base results + the fixed-base partial; ok = is_identity;
 // mega (optional) = boundary affine of the sum
+// bad_sc / bad_pt (optional): per-proof malformed-input bits; a proof with one set gets ok = 0
 void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRaw *fixed, size_t nb,
-                     int32_t *ok, Words8 *mega_xy);
+                     int32_t *ok, Words8 *mega_xy, const int32_t *bad_sc = nullptr, const int32_t *bad_pt = nullptr);
 
 // ---- scalar field (k_scalar.hip) ---------------------------------------------------------------
 void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad);   // canonical (< n)?
@@ -162,7 +173,6 @@ void verify_transcript(hipStream_t st, size_t nb, size_t m, size_t k, const TrSt
                        const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad);
 void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n);
 
-struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 // Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]
 //   (A_I1 A_O1 S1 A_I2 A_O2 S2 V.. T_1 T_3 T_4 T_5 T_6 L.. R..), plain canonical words;
@@ -170,9 +180,14 @@ struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 //   bad (optional): set to 1 when a challenge or proof scalar is not canonical (< n)
 //   zpow_scratch: verify_scalars_scratch_ints(c, d) int32 (z powers + the large-proof path's partials)
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d);
+//   bad_proof (optional): nb int32, [p] = 1 when one of proof p's challenges / scalars is not canonical, else 0
+//   prep_done: the inversion pass (vs_prep.cuh) has already run into the aux area of zpow_scratch (verify_scalars_aux)
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
-                    int32_t *zpow_scratch, int *bad);
+                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof = nullptr, bool prep_done = false);
+// where the inversion pass writes (inside zpow_scratch) and its per-proof stride in field elements; false = the large-proof
+// path, which runs its own inversion pass
+bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_scratch, int32_t **aux, size_t *aux_stride);
 
 // one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);

@@ -23,6 +23,15 @@ static std::vector<StarkPoint> unpack_points_pub(const uint8_t *b, size_t n) {
 
 enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4 };
 
+// `seed` of the proving entry points: BPH_SEED_OS_ENTROPY (all ones) = blinding factors from OsRng (getrandom(2)-keyed DRBG,
+// what a deployment must use); any other value = the replayable SeededRng stream -- TEST / BENCH ONLY, such proofs are
+// not zero-knowledge (the parity tests and bench.py need proofs they can replay against the CPU oracle).
+static const uint64_t BPH_SEED_OS_ENTROPY = ~(uint64_t)0;
+static std::unique_ptr<Rng> make_rng(uint64_t seed) {
+  if (seed == BPH_SEED_OS_ENTROPY) return std::unique_ptr<Rng>(new OsRng());
+  return std::unique_ptr<Rng>(new SeededRng(seed));
+}
+
 // BulletproofGens are created once and reused by a real caller (generators.rs:182); the flat batch entry points
 // keep one instance per capacity so that repeated calls do not rebuild generators and device tables
 static const BulletproofGens &cached_gens(size_t capacity) {
@@ -69,7 +78,8 @@ int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_le
     const BulletproofGens &bp_gens = cached_gens(gens_capacity);   // kept alive as a caller would (generators + tables)
     Transcript transcript = start_transcript(kind, param, label, label_len);
     Prover prover(pc_gens, transcript);
-    Rng rng(seed);
+    std::unique_ptr<Rng> rng_owner = make_rng(seed);
+    Rng &rng = *rng_owner;
     std::vector<StarkPoint> commitments;
     std::vector<Variable> vars;
     auto commit = [&](uint64_t v) {
@@ -169,7 +179,7 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
     // the order tests/r1cs.rs:684 draws them)
     std::vector<Scalar> vs, bls;
     vs.resize(nb * nvals); bls.resize(nb * nvals);
-    for (size_t p = 0; p < nb; p++) rngs.emplace_back(new Rng(seed0 + p));
+    for (size_t p = 0; p < nb; p++) rngs.emplace_back(seed0 == BPH_SEED_OS_ENTROPY ? make_rng(seed0) : make_rng(seed0 + p));
     parallel_for(nb, [&](size_t p) {
       for (size_t j = 0; j < nvals; j++) { vs[p * nvals + j] = Scalar::from(values[p * nvals + j]); bls[p * nvals + j] = rngs[p]->scalar(); }
     });
@@ -222,7 +232,8 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
     PedersenGens pc_gens;
     const BulletproofGens &bp_gens = cached_gens(gens_capacity);   // kept alive as a caller would (generators + tables)
     lap();
-    Rng rng(seed);
+    std::unique_ptr<Rng> rng_owner = make_rng(seed);
+    Rng &rng = *rng_owner;
     std::vector<Scalar> vs, bls;
     for (size_t i = 0; i < 2 * k; i++) { vs.push_back(Scalar::from(values[i])); bls.push_back(rng.scalar()); }
     auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);

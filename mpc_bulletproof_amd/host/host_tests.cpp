@@ -15,7 +15,7 @@ static int failures = 0;
 static bool kshuffle_helper(size_t k, bool corrupt = false) {
   PedersenGens pc_gens;
   BulletproofGens bp_gens(std::max<size_t>(1, 2 * k) == 1 ? 1 : (size_t)1 << (64 - __builtin_clzll(2 * k - 1)), 1);
-  Rng rng(1000 + k);
+  SeededRng rng(1000 + k);
   std::vector<Scalar> input, output;
   for (size_t i = 0; i < k; i++) input.push_back(Scalar::from(rng.next_u64()));
   output.assign(input.rbegin(), input.rend());
@@ -49,7 +49,7 @@ static bool kshuffle_helper(size_t k, bool corrupt = false) {
 static bool example_gadget_roundtrip(uint64_t a1, uint64_t a2, uint64_t b1, uint64_t b2, uint64_t c1, uint64_t c2, bool serialize) {
   PedersenGens pc_gens;
   BulletproofGens bp_gens(128, 1);
-  Rng rng(7);
+  SeededRng rng(7);
   std::vector<StarkPoint> commitments;
   R1CSProof proof;
   {
@@ -74,7 +74,7 @@ static bool example_gadget_roundtrip(uint64_t a1, uint64_t a2, uint64_t b1, uint
 static bool range_proof_helper(uint64_t v_val, size_t n) {
   PedersenGens pc_gens;
   BulletproofGens bp_gens(128, 1);
-  Rng rng(99 + n);
+  SeededRng rng(99 + n);
   R1CSProof proof;
   StarkPoint commitment;
   {
@@ -95,7 +95,7 @@ static bool range_proof_helper(uint64_t v_val, size_t n) {
 
 // ---- src/inner_product_proof.rs:507-583 test_helper_create
 static void ipp_test_helper_create(size_t n) {
-  Rng rng(5 + n);
+  SeededRng rng(5 + n);
   BulletproofGens bp_gens(n, 1);
   auto G = bp_gens.share(0).G(n), H = bp_gens.share(0).H(n);
   StarkPoint Q = Device::default_device().msm({rng.scalar()}, {StarkPoint::generator()});

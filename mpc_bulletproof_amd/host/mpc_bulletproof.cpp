@@ -1,6 +1,8 @@
 // mpc_bulletproof.cpp -- host-side orchestration of the reference's API over the bpgpu C ABI.
 // Citations are to renegade-fi/mpc-bulletproof (paths relative to its root).
 #include "mpc_bulletproof.hpp"
+#include <sys/random.h>
+#include <cerrno>
 #include <chrono>
 #include <exception>
 #include <thread>
@@ -120,12 +122,52 @@ Scalar Scalar::inverse() const {
   return acc;
 }
 
-uint64_t Rng::next_u64() {
+uint64_t SeededRng::next_u64() {
   s_ += 0x9E3779B97F4A7C15ULL;
   uint64_t z = s_;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
+}
+// keccak-256 hash-DRBG: block_i = H(key || 0x00 || counter), then key = H(key || 0x01 || counter) (ratchet)
+OsRng::OsRng() {
+  size_t got = 0;
+  while (got < sizeof key_) {
+    ssize_t r = getrandom(key_ + got, sizeof key_ - got, 0);
+    if (r < 0) { if (errno == EINTR) continue; break; }
+    got += (size_t)r;
+  }
+  if (got < sizeof key_) {   // kernels without getrandom(2)
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    if (f) { got += std::fread(key_ + got, 1, sizeof key_ - got, f); std::fclose(f); }
+  }
+  if (got < sizeof key_) throw std::runtime_error("OsRng: no entropy from getrandom(2) or /dev/urandom");
+}
+void OsRng::refill() {
+  uint8_t buf[32 + 1 + 8];
+  memcpy(buf, key_, 32);
+  for (int j = 0; j < 8; j++) buf[33 + j] = (uint8_t)(counter_ >> (8 * j));
+  buf[32] = 0x00;
+  keccak256(buf, sizeof buf, block_);
+  buf[32] = 0x01;
+  keccak256(buf, sizeof buf, key_);
+  counter_++;
+  used_ = 0;
+}
+uint64_t OsRng::next_u64() {
+  if (used_ + 8 > 32) refill();
+  uint64_t w = 0;
+  for (int j = 0; j < 8; j++) w |= (uint64_t)block_[used_ + j] << (8 * j);
+  used_ += 8;
+  return w;
+}
+void OsRng::rekey(const uint8_t *material, size_t len) {
+  std::vector<uint8_t> buf(32 + 1 + len);
+  memcpy(buf.data(), key_, 32);
+  buf[32] = 0x02;
+  if (len) memcpy(buf.data() + 33, material, len);
+  keccak256(buf.data(), buf.size(), key_);
+  used_ = 32;   // drop what is left of the old block
 }
 Scalar Rng::scalar() {
   uint8_t b[64] = {0};
@@ -862,6 +904,10 @@ Variable Prover::commit_precomputed(const Scalar &v, const Scalar &v_blinding, c
   return Variable{Variable::Committed, i};
 }
 
+R1CSProof Prover::prove(const BulletproofGens &bp_gens) {
+  OsRng rng;
+  return prove(bp_gens, rng);
+}
 R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {
   std::vector<Prover *> ps{this};
   std::vector<Rng *> rs{&rng};
@@ -890,6 +936,12 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   Lap lap;
   std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
   std::vector<std::vector<Scalar>> s_L(nb), s_R(nb);
+  // prover.rs:435-445: the blinding RNG is bound to the transcript state and to the witness blindings
+  // (build_rng().rekey_with_witness_bytes("v_blinding", ..)); the OS entropy is already in an OsRng's key
+  for (size_t p = 0; p < nb; p++) {
+    rngs[p]->rekey(cs[p]->tr.state(), 32);
+    for (const Scalar &vb : cs[p]->v_blinding) { auto b = vb.to_bytes(); rngs[p]->rekey(b.data(), b.size()); }
+  }
   parallel_for(nb, [&](size_t p) {                                                       // :457-462
     i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
     s_L[p].resize(n1); s_R[p].resize(n1);

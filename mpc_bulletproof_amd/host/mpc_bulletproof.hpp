@@ -59,12 +59,38 @@ class Scalar {
   uint64_t v_[4];             // Montgomery form, R = 2^256
 };
 
-// injectable randomness (the reference draws from thread_rng(): src/r1cs/prover.rs:435-445)
+// Randomness of the prover (blinding factors).  The reference builds it from the transcript, re-keyed with the
+// witness blindings and finalized with thread_rng() (src/r1cs/prover.rs:435-445): Prover::prove re-keys whatever Rng
+// it is given the same way (rekey() with the transcript state and every v_blinding) before the first draw.
+//   OsRng      -- the default and the only one for production use: a keccak-256 hash-DRBG keyed with 32 bytes from
+//                 getrandom(2) (/dev/urandom as the fallback), forward-secure (the key is ratcheted after every block),
+//                 rekey() mixes caller material into the key.
+//   SeededRng  -- TEST / BENCH ONLY: the splitmix64 stream of a 64-bit seed, so that proofs can be replayed and
+//                 compared byte for byte with the CPU oracle; rekey() is a no-op.  Proofs made with it are NOT
+//                 zero-knowledge (64 bits of non-cryptographic state).
 class Rng {
  public:
-  explicit Rng(uint64_t seed) : s_(seed) {}
-  uint64_t next_u64();
-  Scalar scalar();            // 4 x u64 little-endian limbs reduced mod n
+  virtual ~Rng() = default;
+  virtual uint64_t next_u64() = 0;
+  virtual void rekey(const uint8_t *material, size_t len) = 0;
+  Scalar scalar();            // 4 x u64 little-endian limbs (+ 4 zero limbs) reduced mod n
+};
+class OsRng final : public Rng {
+ public:
+  OsRng();                    // throws std::runtime_error if the OS gives no entropy
+  uint64_t next_u64() override;
+  void rekey(const uint8_t *material, size_t len) override;
+ private:
+  void refill();
+  uint8_t key_[32], block_[32];
+  uint64_t counter_ = 0;
+  int used_ = 32;
+};
+class SeededRng final : public Rng {
+ public:
+  explicit SeededRng(uint64_t seed) : s_(seed) {}
+  uint64_t next_u64() override;
+  void rekey(const uint8_t *, size_t) override {}
  private:
   uint64_t s_;
 };
@@ -281,7 +307,8 @@ class Prover : public RandomizedConstraintSystem {
   std::pair<StarkPoint, Variable> commit(const Scalar &v, const Scalar &v_blinding);   // :319-329
   // same, with the commitment V = commit(v, v_blinding) already computed (PedersenGens::commit_batch)
   Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const StarkPoint &V);
-  R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // :412-727 (RNG injected)
+  R1CSProof prove(const BulletproofGens &bp_gens);                 // :412-727, blinding factors from a fresh OsRng
+  R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // the same with the randomness injected (tests: SeededRng)
   // the same for nb provers of one circuit in lock-step (every device call batched over the provers)
   static std::vector<R1CSProof> prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
                                             std::vector<Rng *> &rngs);

@@ -41,6 +41,11 @@ def load():
 
 _lib = load()
 E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
+# bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
+PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
+              "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_scalars",
+              "combined_var_msm", "combined_fixed_msm", "combined_tail"]
+PROF_KINDS = len(PROF_NAMES)
 
 
 def _buf(b):
@@ -117,11 +122,10 @@ class BpGpu:
         self._ck(_lib.bpgpu_profile_enable(self.ctx, 1 if on else 0))
 
     def profile_read(self):
-        ms = (C.c_double * 8)()
-        cnt = (C.c_uint64 * 8)()
+        ms = (C.c_double * PROF_KINDS)()
+        cnt = (C.c_uint64 * PROF_KINDS)()
         self._ck(_lib.bpgpu_profile_read(self.ctx, ms, cnt))
-        names = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm", "verify_windows"]
-        return {n: (ms[i], int(cnt[i])) for i, n in enumerate(names)}
+        return {n: (ms[i], int(cnt[i])) for i, n in enumerate(PROF_NAMES)}
 
     # ---- scalar field
     def batch_inverse(self, scalars):

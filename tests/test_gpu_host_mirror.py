@@ -69,6 +69,28 @@ def test_verifier_matches_oracle(host, golden_r1cs):
         assert (rc == 0) == rec["ok"] and mega == H(rec["mega_check"])
 
 
+def test_prover_blinding_randomness_comes_from_the_os_by_default(host):
+    """seed = all ones selects OsRng (getrandom(2)-keyed keccak DRBG re-keyed with the transcript state and the witness
+    blindings, as prover.rs:435-445): two proofs of the same statement share no blinded element, both verify (GPU and
+    oracle).  A 64-bit seed -- the SeededRng of the parity tests -- replays byte for byte."""
+    OS = 2**64 - 1
+    rc1, p1, c1 = _prove(host, o.K_RANGE, 16, b"RangeProofTest", [40000], OS, 16)
+    rc2, p2, c2 = _prove(host, o.K_RANGE, 16, b"RangeProofTest", [40000], OS, 16)
+    assert rc1 == 0 and rc2 == 0 and len(p1) == len(p2)
+    assert c1 != c2                                     # Pedersen commitments hide the same value differently
+    k = int.from_bytes(p1[:4], "little")
+    chunks = [8 + 64 * i for i in range(11)] + [8 + 11 * 64 + 32 * i for i in range(3)]
+    for off in chunks:                                  # A_I1 A_O1 S1 ... T_6, t_x t_x_blinding e_blinding
+        w = 64 if off < 8 + 11 * 64 else 32
+        a, b = p1[off:off + w], p2[off:off + w]
+        assert a != b or a == bytes(w), off           # (identity phase-2 commitments of a 1-phase proof are equal)
+    for proof, com in ((p1, c1), (p2, c2)):
+        assert _verify(host, o.K_RANGE, 16, b"RangeProofTest", [], com, proof, 16)[0] == 0
+        assert o.r1cs_verify(o.K_RANGE, 16, b"RangeProofTest", [], com, proof, 16) == 0
+    assert _prove(host, o.K_RANGE, 16, b"RangeProofTest", [40000], 5, 16) == _prove(host, o.K_RANGE, 16, b"RangeProofTest", [40000], 5, 16)
+    assert k == 4
+
+
 def test_prove_verify_64bit_and_errors(host):
     rc, proof, com = _prove(host, o.K_RANGE, 64, b"RangeProofTest", [2**64 - 5], 77, 64)
     assert rc == 0
