@@ -7,13 +7,18 @@ batch of 1024 proofs of the 64-bit range gadget (tests/r1cs.rs:620-652, m = 1), 
 HBM (proof points/scalars + host-transcript challenges, boundary byte encodings of include/bpgpu.h).
 Multi-GPU: one process per GPU, each rank verifies its own 1024 proofs (independent units, no
 data-path collective) -> weak scaling; value = all ranks' proofs / max-over-ranks time.
+`python bench.py --gpus N` without a launcher starts the N rank processes itself (fresh children,
+before this process touches the GPU); under torch.distributed.run it reads RANK / WORLD_SIZE.
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline`.
 """
 import argparse
+import hashlib
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,23 +29,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 N_BITS = 64
 LABEL = b"RangeProofTest"
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-# HBM bytes per launch of the dominant kernels from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
-# runs; profiles/r01_pmc_*.csv; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)
-TRAFFIC_BYTES_PER_LAUNCH = {
-    # (2 * FETCH_SIZE + WRITE_SIZE) KB * 1024, batch 1024, window-parallel path, c = 20 tables (profiles/r01_pmc_*.csv).
-    # k_verify_tabfix: fetches = 1024 x 1690 random 64-byte rows of the 57 GB c = 20 generator table (108 MB of
-    # gathers that replace 20 doublings each) + the proof points; writes = the affine tables of the proof points
-    "verify_msm": int((2 * 125867.9 + 41791.7) * 1024),
-    "verify_windows": int((2 * 7410.5 + 6912.0) * 1024),
-    "verify_scalars": int((2 * 5006.0 + 9601.4) * 1024),
-}
-# VALU wave-instructions per 1024-proof step (rocprofv3 --pmc SQ_INSTS_VALU, profiles/r01_pmc_sq_summary.txt):
-# k_verify_tabfix<20,16> 5.87e7 + k_verify_windows 3.52e7 + k_verify_scalars 1.93e7 + k_verify_horner_groups 6.45e6 +
-# k_verify_horner 4.71e6 + k_vs_prep 1.25e6
-# (9.53e7 + 5.49e7 + 2.08e7 + 1.23e7 + 1.6e6 = 1.85e8 before the column-form field multiplication)
-VALU_WAVE_INSTR_PER_STEP_1024 = 5.87e7 + 3.52e7 + 1.93e7 + 6.45e6 + 4.71e6 + 1.25e6
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4       # 1024 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+# Mix-weighted VALU issue peak: 74 % of the instructions of the elliptic-curve kernels are v_mad_i64_i32, which holds a
+# SIMD for 4.6 cycles per wave64 instruction (33.9 T lane-MAD/s measured chip-wide, profiles/r01_microbench_primitives.log);
+# the doubling / mixed-addition micro-benchmarks, which ARE this mix, issue one wave64 instruction per 4.25 cycles per
+# SIMD at 8 waves/SIMD.  1024 SIMDs x 2.4 GHz / 4.25.  (A kernel of plain 2-cycle VALU instructions would exceed it.)
+VALU_ISSUE_PEAK_MIX = 256 * 4 * 2.4e9 / 4.25
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
 
 
 def _gen_workload(path, nb, seed0):
@@ -49,7 +44,7 @@ def _gen_workload(path, nb, seed0):
     transcripts on the host and write the operands of bpgpu_r1cs_verify_batch to `path`."""
     import ctypes as C
     import pickle
-    host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+    host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
     vals = [(0x9E3779B97F4A7C15 * (i + 1) + seed0) & ((1 << N_BITS) - 1) for i in range(nb)]
     arr = (C.c_uint64 * nb)(*vals)
     lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
@@ -105,12 +100,75 @@ def _cpu_verify_chunk(args):
     return sum(ok), time.perf_counter() - t0
 
 
+def _cpu_baseline(wl, nb, ncpu):
+    """The CPU oracle's Verifier::verify restatement (transcript replay + scalar assembly + 154-term Pippenger MSM) on a
+    bounded sample of the same workload: all host cores, then ONE thread.  Fork pools, before any GPU initialisation."""
+    plen = wl["proof_len"]
+    per = (nb + ncpu - 1) // ncpu
+    chunks = []
+    for c in range(ncpu):
+        lo, hi = c * per, min(nb, (c + 1) * per)
+        if hi > lo:
+            chunks.append((wl["proofs"][lo * plen:hi * plen], wl["commitments"][64 * lo:64 * hi], plen))
+    with mp.get_context("fork").Pool(len(chunks)) as pool:
+        pool.map(_cpu_verify_chunk, [(b"", b"", plen)] * len(chunks))     # start the workers, load the library
+        t0 = time.perf_counter()
+        res = pool.map(_cpu_verify_chunk, chunks, chunksize=1)
+        wall = time.perf_counter() - t0
+    assert sum(r[0] for r in res) == nb, "the CPU oracle rejects proofs made by the GPU prover"
+    allc = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
+            "sample": f"{nb} proofs of the same workload, oracle cs_verify = the WHOLE of Verifier::verify (transcript replay "
+                      f"+ scalar assembly + 154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU; "
+                      "the like-for-like GPU figure is `with_device_transcript`, not `value` (whose challenges are inputs)"}
+    n1 = min(nb, 128)
+    with mp.get_context("fork").Pool(1) as pool:
+        pool.map(_cpu_verify_chunk, [(b"", b"", plen)])
+        t0 = time.perf_counter()
+        r1 = pool.map(_cpu_verify_chunk, [(wl["proofs"][:n1 * plen], wl["commitments"][:64 * n1], plen)])
+        wall1 = time.perf_counter() - t0
+    assert r1[0][0] == n1
+    one = {"value": n1 / wall1, "unit": "verifications/s", "cores": 1, "kind": "port",
+           "sample": f"the first {n1} proofs of the same workload, one process (BASELINE.md's single-thread column)"}
+    return allc, one
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes (fresh interpreters; this parent never
+    initialises the GPU) with the rendezvous environment torch.distributed.run would give them, relay rank 0's stdout."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    sys.exit(rc)
+
+
+def _lib_hash():
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "mpc_bulletproof_amd", "libbpgpu.so"), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
 def main():
-    # deep step pipelining needs hardware queues (ROCm default: 4) and is better with one stream per context.  16 queues /
-    # 16 steps in flight: bursts start at full speed (tools/burst_probe.py: 32 steps after a device sync take 15 ms,
-    # 4096 steps run at 3.00 M/s).  With 32 / 32 the steady state is the same within noise (3.03 M/s) but every burst
-    # pays ~60 ms first (32 steps: 73 ms) -- the hardware queues are oversubscribed -- so short runs under-report.
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    # deep step pipelining needs hardware queues (ROCm default: 4) and one stream per context.  24 queues / 20 steps in
+    # flight: the best short-burst AND steady-state setting of tools/burst_sweep.sh (20 steps after a device sync
+    # 5.9 ms, 1024 steps 4.2 M/s); more than ~22 ACTIVE queues makes bursts erratic (24 / 24: 6 - 50 ms for 20 steps).
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,32 +178,38 @@ def main():
     ap.add_argument("--window-bits", type=int, default=int(os.environ.get("BPGPU_WINDOW_BITS", "20")),
                     help="window of the resident generator tables: 20 bits = 13 table additions per generator term, a 57 GB "
                          "table for the 130 generators of the 64-bit gadget (16 bits: 16 additions, 4.5 GB)")
-    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "16")),
+    ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "20")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
-                         "(streams + workspaces), so step i+1's scalar assembly overlaps step i's MSM")
+                         "(streams + workspaces), so the kernels of several batches overlap on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-combined", action="store_true", help="skip the secondary combined-batch-check measurement")
+    ap.add_argument("--no-combined", action="store_true", help="skip the secondary measurements (device transcript, wire format, "
+                                                               "combined batch check, H2D-inclusive, single batch)")
     ap.add_argument("--no-prover", action="store_true", help="skip the secondary R1CS prover measurement (N = 1 only)")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus} "
+              f"or let bench.py start the ranks itself (no WORLD_SIZE in the environment)", file=sys.stderr)
+        sys.exit(2)
     nb = a.batch
 
     # ---- synthetic workload (setup, untimed), generated by the product path itself in a child process forked before
     # this process touches the GPU.  Every rank verifies the same batch (weak scaling): local rank 0 generates it
     # once and publishes it through a file, the other ranks wait for the file.  The CPU baseline (the oracle's
-    # restatement, timed on all host cores) runs in a fork pool, also before any GPU initialisation here.
+    # restatement) runs in fork pools on rank 0, also before any GPU initialisation here.
     import pickle
     import tempfile
     ncpu = max(1, min(os.cpu_count() or 1, 32))
     seed0 = 0xB0117E7
     cache = f"{a.workload_cache}.{nb}" if a.workload_cache else os.path.join(
         tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}.pkl")
-    cpu = None
     if not os.path.exists(cache) and local_rank == 0:
         child = mp.get_context("fork").Process(target=_gen_workload, args=(cache, nb, seed0))
         child.start()
@@ -160,24 +224,9 @@ def main():
         time.sleep(0.5)
     with open(cache, "rb") as f:
         wl = pickle.load(f)
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        # CPU baseline: the oracle's Verifier::verify restatement on the same proofs, all host cores
-        plen = wl["proof_len"]
-        per = (nb + ncpu - 1) // ncpu
-        chunks = []
-        for c in range(ncpu):
-            lo, hi = c * per, min(nb, (c + 1) * per)
-            if hi > lo:
-                chunks.append((wl["proofs"][lo * plen:hi * plen], wl["commitments"][64 * lo:64 * hi], plen))
-        with mp.get_context("fork").Pool(len(chunks)) as pool:
-            pool.map(_cpu_verify_chunk, [(b"", b"", plen)] * len(chunks))     # start the workers, load the library
-            t0 = time.perf_counter()
-            res = pool.map(_cpu_verify_chunk, chunks, chunksize=1)
-            wall = time.perf_counter() - t0
-        assert sum(r[0] for r in res) == nb, "the CPU oracle rejects proofs made by the GPU prover"
-        cpu = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
-               "sample": f"{nb} proofs of the same workload, oracle cs_verify (transcript + scalars + "
-                         f"154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU"}
+    cpu = cpu1 = None
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu, cpu1 = _cpu_baseline(wl, nb, ncpu)
     n1, n2, k, m = wl["dims"]
     rp, kind, idx, coeff = wl["csr"]
     pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
@@ -206,6 +255,7 @@ def main():
     d_pts, d_sc, d_ch = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch)
     d_oks = [gpu.malloc(4 * nb) for _ in ctxs]
     counter = [0]
+    all_ok = (1).to_bytes(4, "little") * nb
 
     def step():
         i = counter[0] % len(ctxs)
@@ -214,7 +264,7 @@ def main():
 
     def sync_all():
         # one device-wide synchronisation (the contexts' streams are ordinary blocking HIP streams of this device);
-        # a hipStreamSynchronize per context costs ~0.15 ms each on an idle stream: ~10 ms for 32 contexts
+        # a hipStreamSynchronize per context costs ~0.15 ms each on an idle stream
         torch.cuda.synchronize()
 
     def fence():
@@ -222,23 +272,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up: at least one step per context, with the per-kernel HIP-event timing already on (the first event
-    # records on a stream cost milliseconds) -- its timings are read and discarded before the timed region
-    # the event pairs cost ~6 % of the throughput when every launch carries them (3.59 vs 3.82 M/s): the kernels of
-    # ONE context in BPGPU_PROF_EVERY (default: of context 0 only, 1 step in 16) are timed -- same kernels, same
-    # overlap, 128 timed launches per kernel in the default run
+    def timed(fn, steps):
+        """EXACTLY `steps` calls of fn(i) between two fences; max over ranks"""
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            fn(i)
+        sync_all()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            from mpc_bulletproof_amd import sharding
+            dt = sharding.max_over_ranks(dt)
+        return dt
+
+    # Per-kernel HIP-event timing (event pairs on the stream each kernel is launched on, recycled from a per-context pool).
+    # In the timed region the launches of ONE context in `inflight` carry events (an event pair per launch on every context
+    # costs a short run a quarter of its throughput: ~12 barrier packets per step in each queue); right after it the same
+    # K steps are REPLAYED with event pairs around every launch of every context: `roofline` is computed from the replay
+    # (>= K launches per kernel) and quotes the timed region's own sample beside it.  BPGPU_PROF_EVERY overrides the sampling.
     prof_every = max(1, int(os.environ.get("BPGPU_PROF_EVERY", str(len(ctxs)))))
+    noprof = bool(os.environ.get("BPGPU_BENCH_NOPROF"))
     for i, c in enumerate(ctxs):
-        c.profile_enable(not os.environ.get("BPGPU_BENCH_NOPROF") and i % prof_every == 0)
+        c.profile_enable(not noprof and i % prof_every == 0)
     for _ in range(max(a.warmup, len(ctxs))):
         step()
     sync_all()
     for c, d in zip(ctxs, d_oks):
-        assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb and c.input_flag() == 0, "GPU verification disagrees"
+        assert c.download(d, 4 * nb) == all_ok and c.input_flag() == 0, "GPU verification disagrees"
         c.profile_read()
-    # the checks above leave the GPU idle for milliseconds
-    # ... so the warm-up keeps submitting steps (untimed) for BPGPU_WARM_SECONDS of wall time right up to the fence that
-    # starts the timed region.
+    # the checks above leave the GPU idle for milliseconds: the warm-up keeps submitting steps (untimed) for
+    # BPGPU_WARM_SECONDS of wall time right up to the fence that starts the timed region
     warm_s = float(os.environ.get("BPGPU_WARM_SECONDS", "0.3"))
     tw = time.perf_counter()
     while time.perf_counter() - tw < warm_s:
@@ -248,29 +312,79 @@ def main():
     for c in ctxs:
         c.profile_read()
     counter[0] = 0
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    sync_all()
-    fence()
-    dt = time.perf_counter() - t0
-    prof = {}
-    for c in ctxs:
-        for name, (ms, cnt) in c.profile_read().items():
-            pm, pc = prof.get(name, (0.0, 0))
-            prof[name] = (pm + ms, pc + cnt)
-        c.profile_enable(False)
-    if world > 1:
-        from mpc_bulletproof_amd import sharding
-        dt = sharding.max_over_ranks(dt)
-    for c, d in zip(ctxs, d_oks):
-        assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
+    dt = timed(lambda i: step(), a.steps)
 
-    # ---- secondary: the same per-proof verification with the Fiat-Shamir transcript replayed on the device
-    # (SURVEY 8f N1): inputs are the proofs + one 32-byte initial chain state per proof, no host challenges
-    fs = None
+    def collect():
+        acc = {}
+        for c in ctxs:
+            for name, (ms, cnt) in c.profile_read().items():
+                pm, pc = acc.get(name, (0.0, 0))
+                acc[name] = (pm + ms, pc + cnt)
+        return acc
+
+    prof_sample = collect()
+    for c, d in zip(ctxs, d_oks):
+        assert c.download(d, 4 * nb) == all_ok
+    # instrumented replay of the same K steps (capped at 256): every launch of every context timed
+    prof, replay_dt, replay_steps = prof_sample, None, 0
+    if not noprof:
+        for c in ctxs:
+            c.profile_enable(True)
+        for _ in range(len(ctxs)):
+            step()
+        sync_all()
+        collect()
+        counter[0] = 0
+        replay_steps = min(a.steps, 256)
+        replay_dt = timed(lambda i: step(), replay_steps)
+        prof = collect()
+    for c in ctxs:
+        c.profile_enable(False)
+
+    fs = wire = comb = h2d = single = None
     if not a.no_combined:
+        # ---- secondary: ONE batch at a time (no pipelining): the latency of a batch's kernel chain
+        lat = []
+        ctxs[0].set_latency_mode(True)      # the context-level hint for un-pipelined callers (include/bpgpu.h)
+        for _ in range(9):
+            sync_all()
+            t0 = time.perf_counter()
+            ctxs[0].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[0])
+            ctxs[0].sync()
+            lat.append(time.perf_counter() - t0)
+        ctxs[0].set_latency_mode(False)
+        assert ctxs[0].download(d_oks[0], 4 * nb) == all_ok
+        lat = sorted(lat[2:])
+        single = {"value": nb / lat[len(lat) // 2], "unit": "verifications/s", "ms_per_batch": lat[len(lat) // 2] * 1e3,
+                  "min_ms": lat[0] * 1e3, "note": "one un-pipelined 1024-proof batch on an idle GPU, submit to host-visible completion "
+                                                  "(median of 7, context in latency mode: bpgpu_set_latency_mode): front | scalars | windows | groups | back | verdict"}
+
+        # ---- secondary: SURVEY 8d's metric as written -- the proof points, proof scalars and challenges of every step are
+        # uploaded from page-locked host memory inside the timed region (asynchronous copies on the step's stream)
+        h_pts, h_sc, h_ch = mb.lib.host_alloc(len(pts), pts), mb.lib.host_alloc(len(sc), sc), mb.lib.host_alloc(len(ch), ch)
+        d_in = [(c.malloc(len(pts)), c.malloc(len(sc)), c.malloc(len(ch))) for c in ctxs]
+
+        def hstep(i):
+            j = i % len(ctxs)
+            c, (dp, ds, dc) = ctxs[j], d_in[j]
+            c.upload_async(dp, h_pts, len(pts))
+            c.upload_async(ds, h_sc, len(sc))
+            c.upload_async(dc, h_ch, len(ch))
+            c.r1cs_verify_batch_dev(gens, circ, nb, n1, k, dp, ds, dc, d_oks[j])
+
+        for i in range(len(ctxs)):
+            hstep(i)
+        sync_all()
+        for c, d in zip(ctxs, d_oks):
+            assert c.download(d, 4 * nb) == all_ok
+        hdt = timed(hstep, a.steps)
+        h2d = {"value": world * nb * a.steps / hdt, "unit": "verifications/s", "ms_per_step": hdt / a.steps * 1e3,
+               "bytes_per_step": len(pts) + len(sc) + len(ch),
+               "note": "as `value`, plus the upload of every step's proof points, proof scalars and challenges from page-locked "
+                       "host memory inside the timed region (SURVEY 8d: 'incl. H2D of proof scalars + points'); never the headline"}
+
+        # ---- secondary: the same per-proof verification with the Fiat-Shamir transcript replayed on the device
+        # (SURVEY 8f N1): inputs are the proofs + one 32-byte initial chain state per proof, no host challenges
         d_init = gpu.to_device(wl["init_state"] * nb)
 
         def fstep(i):
@@ -281,25 +395,14 @@ def main():
             fstep(i)
         sync_all()
         for c, d in zip(ctxs, d_oks):
-            assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
-        fence()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            fstep(i)
-        sync_all()
-        fence()
-        fdt = time.perf_counter() - t0
-        if world > 1:
-            from mpc_bulletproof_amd import sharding
-            fdt = sharding.max_over_ranks(fdt)
+            assert c.download(d, 4 * nb) == all_ok
+        fdt = timed(fstep, a.steps)
         fs = {"value": world * nb * a.steps / fdt, "unit": "verifications/s", "ms_per_step": fdt / a.steps * 1e3,
               "note": "whole Verifier::verify incl. the transcript replay (keccak256 chain, hash_to_scalar) on the GPU; "
-                      "per-proof accept bits"}
+                      "per-proof accept bits.  This is the figure to hold against cpu_baseline (same work)"}
 
-    # ---- secondary: the same proofs taken in the reference's WIRE format (SURVEY 8f N3 + N1): unpack, decompress the
-    # 25 points of every proof (a square root in F_p each), transcript, verification -- all on the device
-    wire = None
-    if not a.no_combined:
+        # ---- secondary: the same proofs taken in the reference's WIRE format (SURVEY 8f N3 + N1): unpack, decompress the
+        # 25 points of every proof (a square root in F_p each), transcript, verification -- all on the device
         d_wp, d_wc = gpu.to_device(wl["wire_proofs"]), gpu.to_device(wl["wire_commitments"])
 
         def wstep(i):
@@ -310,25 +413,14 @@ def main():
             wstep(i)
         sync_all()
         for c, d in zip(ctxs, d_oks):
-            assert c.download(d, 4 * nb) == (1).to_bytes(4, "little") * nb
-        fence()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            wstep(i)
-        sync_all()
-        fence()
-        wdt = time.perf_counter() - t0
-        if world > 1:
-            from mpc_bulletproof_amd import sharding
-            wdt = sharding.max_over_ranks(wdt)
+            assert c.download(d, 4 * nb) == all_ok
+        wdt = timed(wstep, a.steps)
         wire = {"value": world * nb * a.steps / wdt, "unit": "verifications/s", "ms_per_step": wdt / a.steps * 1e3,
                 "note": f"from {wl['wire_len']}-byte wire-format proofs + 32-byte compressed commitments: R1CSProof::from_bytes, point "
                         "decompression, transcript replay and verification on the GPU; per-proof accept bits"}
 
-    # ---- secondary: combined batch check (sum_p rho_p * check_p, one point per GPU; RCCL all-gather of
-    # the 64-byte partials + local add).  Not the headline (the reference verifies proof by proof).
-    comb = None
-    if not a.no_combined:
+        # ---- secondary: combined batch check (BASELINE configs[1] 'single big MSM': sum_p rho_p * check_p as ONE point per
+        # GPU; RCCL all-gather of the 64-byte partials + local add when n_gpus > 1).
         import random
         rnd = random.Random(0xC0B1 + rank)   # verifier-chosen weights: any scalars < 2^250 < n
         d_rho = gpu.to_device(b"".join(rnd.getrandbits(250).to_bytes(32, "little") for _ in range(nb)))
@@ -340,23 +432,28 @@ def main():
         for i in range(len(ctxs)):
             cstep(i)
         sync_all()
-        fence()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
-            cstep(i)
-        sync_all()
-        fence()
-        cdt = time.perf_counter() - t0
+        for c in ctxs:
+            c.profile_read()
+            c.profile_enable(not os.environ.get("BPGPU_BENCH_NOPROF"))
+        cdt = timed(cstep, a.steps)
+        cprof = {}
+        for c in ctxs:
+            for name, (ms, cnt) in c.profile_read().items():
+                if name.startswith("combined") and cnt:
+                    pm, pc = cprof.get(name, (0.0, 0))
+                    cprof[name] = (pm + ms, pc + cnt)
+            c.profile_enable(False)
         part = ctxs[0].download(d_parts[0], 64)
         if world > 1:
             from mpc_bulletproof_amd import sharding
-            cdt = sharding.max_over_ranks(cdt)
-            ones = (1).to_bytes(32, "little")
-            part = sharding.combine_partial_points(part, lambda x, y: gpu.msm(ones + ones, x + y))
+            part = sharding.combine_partial_points(part, gpu.points_sum)
         assert part == bytes(64), "combined batch check must be the identity for valid proofs"
         comb = {"value": world * nb * a.steps / cdt, "unit": "verifications/s", "ms_per_step": cdt / a.steps * 1e3,
-                "note": "sum_p rho_p*mega_check_p == identity (single accept bit per batch; one fixed-base MSM + one "
-                        f"{nb * (11 + m + 2 * k)}-term bucket-method MSM per GPU; partial points all-gathered over RCCL when n_gpus > 1)"}
+                "vs_per_proof_value": (world * nb * a.steps / cdt) / (world * nb * a.steps / dt),
+                "stage_ms_per_step": {n_: v[0] / max(v[1], 1) for n_, v in cprof.items()},
+                "note": "sum_p rho_p*mega_check_p == identity (single accept bit per batch; one fixed-base MSM over the 130 "
+                        f"generators + one {nb * (11 + m + 2 * k)}-term bucket-method MSM per GPU; partial points all-gathered "
+                        "over RCCL when n_gpus > 1)"}
 
     # ---- secondary: the other half of BASELINE.json's metric, R1CS constraints/s of the prover, on configs[2]'s
     # shape: 256 provers in lock-step, each range-proving 16 x 64-bit values in one constraint system (n = 1024
@@ -365,7 +462,7 @@ def main():
     prove = None
     if world == 1 and not a.no_prover:
         import ctypes as C
-        host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+        host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
         pnb, nvals = 256, 16
         pq, pn = nvals * (2 * N_BITS + 1), nvals * N_BITS
         vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(pnb) for i in range(nvals)]
@@ -387,42 +484,55 @@ def main():
     if rank == 0:
         nvar = 11 + m + 2 * k
         nterms = 13 + m + 2 * (1 << k) + 2 * k
-        # Which launch path ran: window-parallel (k_verify_tabfix | k_verify_windows | k_verify_horner), the fused Straus
-        # launch (k_verify_msm) or separate launches.  The roofline's dominant kernel = the one with the largest summed
-        # duration among the kernels that consume algorithmic bytes (96 B per MSM term = 64 B point +
-        # 32 B scalar; the Horner pass only reads intermediates).
-        wp = prof.get("verify_windows", (0.0, 0))[1] > 0
-        vnp = max(1, min(4, int(os.environ.get("BPGPU_STRAUS_NP", "4"))))
         W = 252 // a.window_bits + 1
-        if wp:
-            names = {"verify_msm": f"k_verify_tabfix<{a.window_bits},16>", "verify_windows": "k_verify_windows",
-                     "verify_scalars": "k_verify_scalars"}
-            bytes_per_proof = {"verify_msm": nvar * 64 + (nterms - nvar) * 96, "verify_windows": nvar * 32,
-                               "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
-        else:
-            names = {"verify_msm": f"k_verify_msm<{vnp},{a.window_bits},16>", "straus": f"k_straus<{vnp},64>",
-                     "fixed_msm": f"k_fixed_msm_small<{a.window_bits},16>", "verify_scalars": "k_verify_scalars"}
-            bytes_per_proof = {"verify_msm": nterms * 96, "straus": nvar * 96, "fixed_msm": (nterms - nvar) * 96,
-                               "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
-        dom = max(names, key=lambda n_: prof.get(n_, (0.0, 0))[0])
-        ms, cnt = prof[dom]
-        avg_s = ms / max(cnt, 1) / 1e3
-        alg_bytes = nb * bytes_per_proof[dom]
-        achieved = alg_bytes / avg_s / 1e9 if avg_s else 0.0     # 0 only when event timing is switched off
-        # integer roofline: algorithmic F_p multiplications x 94 limb MADs each (csrc/fe29.cuh), per step.
-        # window-parallel: per non-identity proof point 7 table additions + 60 window additions (mixed, 11 mul), one
-        # inversion per 8 points (~310), per proof 252 doublings (9) + 64 additions (16) in the Horner pass;
-        # fixed-base: one mixed addition per (generator, window) + the 16-lane butterfly.  A_I2, A_O2, S2 are the
-        # identity in 1-phase proofs and are skipped.
-        if wp:
-            fp_var = nb * ((nvar - 3) * (7 + 60) * 11 + ((nvar + 7) // 8) * 310 + 252 * 9 + 64 * 16)
-        else:
-            lanes = nvar // vnp + nvar % vnp
-            fp_var = nb * (lanes * 252 * 9 + (nvar - 3) * (63 * 16 + 7 * 11))
-        fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
-        fpmul = {"verify_msm": fp_fixed + (0 if wp else fp_var), "straus": fp_var, "fixed_msm": fp_fixed}.get(dom, 0)
-        fp_straus = fp_var
+        # The kernels of the window-parallel chain that consume algorithmic bytes (96 B per MSM term = 64 B point +
+        # 32 B scalar) and what each reads of them; the dominant kernel = the one with the largest summed duration.
+        lpm = 16 if nb >= 1024 else 32
+        names = {"verify_back": f"k_verify_back<{a.window_bits},{lpm}>", "verify_front": "k_verify_front<4>",
+                 "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars"}
+        bytes_per_proof = {"verify_back": (nterms - nvar) * 96, "verify_front": nvar * 64, "verify_windows": nvar * 32,
+                           "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
+        timed_names = [n_ for n_ in names if prof.get(n_, (0.0, 0))[1] > 0]
+        pmc = None
+        if os.path.exists(PMC_FILE):
+            with open(PMC_FILE) as f:
+                pmc = json.load(f)
+        lib_hash = _lib_hash()
+        roof = None
+        if timed_names:
+            dom = max(timed_names, key=lambda n_: prof[n_][0])
+            ms, cnt = prof[dom]
+            avg_s = ms / cnt / 1e3
+            alg_bytes = nb * bytes_per_proof[dom]
+            achieved = alg_bytes / avg_s / 1e9
+            traffic = (pmc or {}).get("traffic_bytes_per_launch", {}).get(dom)
+            roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
+                    "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
+                    "timed": f"HIP-event pairs around every launch of every context in a replay of {replay_steps} steps right after the "
+                             f"timed region (replay: {replay_dt / replay_steps * 1e3:.3f} ms/step)" if replay_dt else "timed-region sample",
+                    "timed_region_sample": ({"avg_launch_ms": prof_sample[dom][0] / prof_sample[dom][1], "launches": prof_sample[dom][1],
+                                             "contexts_sampled": f"1 in {prof_every}"} if prof_sample.get(dom, (0, 0))[1] else None),
+                    "note": "achieved = algorithmic bytes of the dominant kernel / its average launch duration (HIP events on the "
+                            "launch stream, steps overlapping on the GPU).  The path is VALU-integer bound, not HBM bound: 252-bit "
+                            "modular arithmetic spends ~1 650 instructions per 96 algorithmic bytes; see roofline_valu_issue"}
         step_s = dt / a.steps
+        # integer roofline: algorithmic F_p multiplications x 94 limb MADs each (csrc/fe29.cuh), per step.  Per non-identity proof
+        # point 7 table additions + 60 window additions (mixed, 11 mul), one inversion per 4 points (~310), per proof 252
+        # doublings (9) + 64 additions (16) in the Horner passes; fixed-base: one mixed addition per (generator, window) + the
+        # 16-lane butterfly.  A_I2, A_O2, S2 are the identity in 1-phase proofs and are skipped.
+        fp_var = nb * ((nvar - 3) * (7 + 60) * 11 + ((nvar + 3) // 4) * 310 + 252 * 9 + 64 * 16)
+        fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
+        valu = None
+        if pmc and nb == 1024 and a.window_bits == 20:
+            instr = pmc["valu_wave_instr_per_step_1024"]
+            valu = {"bound": "VALU issue slots (mix-weighted)", "achieved": instr / step_s, "peak": VALU_ISSUE_PEAK_MIX,
+                    "unit": "wave-instr/s", "frac": instr / step_s / VALU_ISSUE_PEAK_MIX,
+                    "valu_wave_instr_per_step": instr, "measured_on_lib_sha256_16": pmc.get("lib_sha256_16"),
+                    "this_lib_sha256_16": lib_hash, "binary_matches": pmc.get("lib_sha256_16") == lib_hash,
+                    "note": "instructions per step: rocprofv3 --pmc SQ_INSTS_VALU of a solo run (" + pmc.get("source", "profiles/") +
+                            "); peak = 1024 SIMDs x 2.4 GHz / 4.25 cycles per wave64 instruction, the issue rate of THIS instruction "
+                            "mix (74 % v_mad_i64_i32) in the doubling / addition micro-benchmarks"}
         out = {
             "metric": "range-proof verifications/sec (64-bit, m=1)",
             "value": world * nb * a.steps / dt, "unit": "verifications/s", "n_gpus": world, "steps": a.steps,
@@ -430,25 +540,19 @@ def main():
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 252-bit prime fields)", "data": "synthetic",
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
-                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs)},
-            "roofline": {"bound": "hbm", "kernel": names[dom],
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": TRAFFIC_BYTES_PER_LAUNCH.get(dom), "avg_launch_ms": avg_s * 1e3,
-                         "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
-                         "note": "avg launch duration: HIP events around the launches of one of the steps_in_flight contexts "
-                                 "(every launch of that context in the timed region), measured with the steps overlapping "
-                                 "on the GPU; solo launch times are in DESIGN.md.  The path is VALU-integer bound: see "
-                                 "roofline_int / roofline_valu_issue"},
+                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs),
+                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"])},
+            "roofline": roof,
             "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "variable-base + fixed-base halves of one step's mega_check MSMs / wall time per step",
-                             "achieved": (fp_straus + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
-                             "frac": (fp_straus + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS,
-                             "dominant_kernel_frac_at_its_avg_launch": fpmul * 94 / avg_s / 1e12 / MAD_PEAK_TOPS if avg_s else None},
-            "roofline_valu_issue": ({"bound": "VALU issue slots", "achieved": VALU_WAVE_INSTR_PER_STEP_1024 / step_s,
-                                     "peak": VALU_ISSUE_PEAK, "unit": "wave-instr/s", "frac": VALU_WAVE_INSTR_PER_STEP_1024 / step_s / VALU_ISSUE_PEAK,
-                                     "note": "instructions per step from the PMC pass of the default configuration (profiles/r01_pmc_sq_summary.txt)"}
-                                    if nb == 1024 and wp and a.window_bits == 20 else None),
-            "kernel_ms_per_step": {n_: (v[0] / max(v[1], 1)) for n_, v in prof.items()},
+                             "achieved": (fp_var + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
+                             "frac": (fp_var + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS},
+            "roofline_valu_issue": valu,
+            "kernel_ms_per_launch": {n_: (v[0] / v[1]) for n_, v in prof.items() if v[1]},
+            "kernel_launches_timed": {n_: v[1] for n_, v in prof.items() if v[1]},
             "cpu_baseline": cpu,
+            "cpu_baseline_1t": cpu1,
+            "single_batch": single,
+            "h2d_inclusive": h2d,
             "with_device_transcript": fs,
             "from_wire_format": wire,
             "combined_batch_check": comb,
@@ -457,8 +561,11 @@ def main():
                              "note": f"the {nb} proofs of this workload, proved in lock-step by the GPU prover while it was generated "
                                      "(wall clock incl. host circuit building and transcripts)"} if wl.get("prove_seconds") else None),
         }
-        print(json.dumps(out))
+        if cpu is None:
+            out["cpu_baseline_reason"] = "--no-cpu-baseline"
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     gpu.gens_destroy(gens)
     gpu.circuit_destroy(circ)

@@ -48,7 +48,13 @@ const char *bpgpu_strerror(int code);
 const char *bpgpu_last_error(bpgpu_ctx *ctx);   /* text of the last HIP failure on this ctx */
 int bpgpu_sync(bpgpu_ctx *ctx);
 void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for event timing) */
-/* after a `_dev` call: synchronise and report whether any input of it was malformed (1) */
+/* Tuning hint for the batch-verification entry points of this context.  0 (default): fewest instructions -- right for a
+ * caller that keeps several batches in flight (several contexts / streams), where throughput is bound by instruction issue.
+ * 1: more, shorter lanes in the two longest launches of a batch's kernel chain -- one batch alone completes ~25 % sooner
+ * (0.8 instead of 1.05 ms for 1024 x 64-bit range proofs), a saturated pipeline runs ~5 % slower.  Results are identical. */
+int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
+/* synchronise and report whether any input since the last read was malformed (1); reading clears the flag.  A diagnostic:
+ * the verification entry points reject a malformed proof on its own (ok[p] = 0) and never fail the call for it. */
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers
@@ -67,6 +73,11 @@ int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);
 int bpgpu_free(bpgpu_ctx *ctx, void *dptr);
 int bpgpu_upload(bpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int bpgpu_download(bpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* the same, enqueued on the context's stream without waiting: the host buffer must stay alive (and should be page-locked:
+ * bpgpu_host_alloc) until bpgpu_sync.  A caller streaming batches through `_dev` entry points overlaps the upload of
+ * batch i+1 with the kernels of batch i this way (bench.py `h2d_inclusive`). */
+int bpgpu_upload_async(bpgpu_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int bpgpu_download_async(bpgpu_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 /* Page-locked host memory for staging.  Operands handed over from such a buffer reach the device by DMA at PCIe
  * speed; pageable buffers go through the runtime's bounce buffers (3-10 GB/s measured).  Optional -- every entry point
  * accepts ordinary host pointers (the Rust side would keep its packed scalar / point staging Vec in one of these).
@@ -97,6 +108,10 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
  * instead of an error code.  For callers that keep points resident between MSMs. */
 int bpgpu_msm_batch_dev(bpgpu_ctx *ctx, size_t nb, size_t n, const void *scalars_dev, const void *points_dev,
                         void *out_dev);
+/* sum of n points, no scalars (StarkPoint + StarkPoint): the local reduction of the <= 8 partial results that the GPUs of
+ * a node all-gather after a term-range-sharded MSM or a combined batch check -- one launch instead of an
+ * MSM with unit scalars (whose 252-doubling chain costs ~1 ms however few the terms). */
+int bpgpu_points_sum(bpgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t out[64]);
 /* nsets MSMs over ONE point vector: out[s] = sum_i scalars[s*n + i] * points[i].  This is the local work of
  * StarkPoint::msm_authenticated_iter in the two-party prover -- one MSM each over the secret shares, the MACs and
  * the public modifiers of the same authenticated scalars against the same points (r1cs_mpc/mpc_prover.rs:621-657,

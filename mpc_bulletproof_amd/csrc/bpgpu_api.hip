@@ -33,19 +33,24 @@ struct bpgpu_ctx {
   Slot ws[24];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
+  bool latency_mode = false;      // bpgpu_set_latency_mode
   std::vector<hipEvent_t> prof_ev[BPGPU_PROF_KINDS];
+  std::vector<hipEvent_t> prof_pool;   // recycled events
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
 };
-struct ProfScope {   // records start/stop events on `st` around a launch when profiling is on
+struct ProfScope {   // records start/stop events on `st` around a launch when profiling is on (events come from a per-context pool)
   bpgpu_ctx *c; int kind; hipStream_t st;
-  ProfScope(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) {
-    if (c->prof) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_ev[kind].push_back(e); } }
+  static void mark(bpgpu_ctx *c, int kind, hipStream_t st) {
+    hipEvent_t e = nullptr;
+    if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
+    else if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    c->prof_ev[kind].push_back(e);
   }
-  ~ProfScope() {
-    if (c->prof) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) { (void)hipEventRecord(e, st); c->prof_ev[kind].push_back(e); } }
-  }
+  ProfScope(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) { if (c->prof) mark(c, kind, st); }
+  ~ProfScope() { if (c->prof) mark(c, kind, st); }
 };
 struct bpgpu_gens {
   size_t cap = 0;
@@ -193,6 +198,8 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   if (ctx->gen_tab) { hipFree(ctx->gen_tab->points); hipFree(ctx->gen_tab->table); delete ctx->gen_tab; }
   hipEventDestroy(ctx->ev1);
   hipEventDestroy(ctx->ev2);
+  for (auto &v : ctx->prof_ev) for (auto e : v) hipEventDestroy(e);
+  for (auto e : ctx->prof_pool) hipEventDestroy(e);
   if (ctx->st2 != ctx->st) hipStreamDestroy(ctx->st2);
   hipStreamDestroy(ctx->st);
   delete ctx;
@@ -205,6 +212,12 @@ int bpgpu_sync(bpgpu_ctx *ctx) {
   return BPGPU_OK;
 }
 void *bpgpu_stream(bpgpu_ctx *ctx) { return ctx ? (void *)ctx->st : nullptr; }
+int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on) {
+  if (!ctx) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->latency_mode = on != 0;
+  return BPGPU_OK;
+}
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on) {
   if (!ctx) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -224,7 +237,7 @@ int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t
       float ms = 0;
       if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) { ms_sum[k] += ms; launches[k]++; }
     }
-    for (auto e : v) (void)hipEventDestroy(e);
+    for (auto e : v) ctx->prof_pool.push_back(e);
     v.clear();
   }
   return BPGPU_OK;
@@ -269,6 +282,18 @@ int bpgpu_upload(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
   CK(h2d(ctx, dst, src, bytes));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
+}
+// asynchronous on the context's stream: the caller keeps `src` / `dst` alive (and page-locked: bpgpu_host_alloc, for the
+// copy to overlap anything) until bpgpu_sync
+int bpgpu_upload_async(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return h2d(ctx, dst, src, bytes);
+}
+int bpgpu_download_async(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
+  if (!ctx || (bytes && (!dst || !src))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return d2h(ctx, dst, src, bytes);
 }
 int bpgpu_download(bpgpu_ctx *ctx, void *dst, const void *src, size_t bytes) {
   if (!ctx || (bytes && (!dst || !src))) return BPGPU_E_ARG;
@@ -399,6 +424,25 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
 }
 
 /* nsets MSMs over ONE point vector (the share / MAC / public-modifier MSMs of msm_authenticated_iter) */
+int bpgpu_points_sum(bpgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t out[64]) {
+  if (!ctx || !out || (n && !points)) return BPGPU_E_ARG;
+  if (!n) { memset(out, 0, 64); return BPGPU_OK; }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *dxy, *dout;
+  CK(ws_get(ctx, 0, n * 64, &dxy));
+  CK(ws_get(ctx, 4, 64, &dout));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dxy, points, n * 64));
+  points_sum(ctx->st, (const Words8 *)dxy, n, (Words8 *)dout, ctx->d_flag);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
 int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scalars, const uint8_t *points,
                      uint8_t *out) {
   if (!ctx || (nsets && !out) || (nsets && n && (!scalars || !points))) return BPGPU_E_ARG;
@@ -795,7 +839,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
     void *dwp;
     CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
-    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc};
+    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc, ctx->latency_mode};
     int32_t *aux = nullptr;
     size_t aux_stride = 0;
     const bool fuse_prep = verify_scalars_aux(circuit_dev(c), d, (int32_t *)dzp, &aux, &aux_stride);

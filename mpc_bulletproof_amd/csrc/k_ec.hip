@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include "fixed_body.cuh"
 #include "vs_prep.cuh"
+#include "ec29_quad.cuh"
 
 using namespace bp;
 
@@ -340,7 +341,7 @@ __global__ void __launch_bounds__(64) k_verify_horner_groups(JacRaw *winsum, siz
   raw_store(&s[0], acc);
 }
 // one lane per proof over `count` partial sums `stride` slots apart, `dbl` doublings between them
-struct HornerArgs { const JacRaw *winsum; JacRaw *varsum; size_t nb; int count, stride, dbl; };
+struct HornerArgs { const JacRaw *winsum; JacRaw *varsum; size_t nb; int count, stride, dbl, quad; };
 __device__ __forceinline__ void horner_body(const HornerArgs &h, size_t blk) {
   __builtin_amdgcn_s_setprio(2);   // 16 waves carrying the longest link of the chain
   size_t p = blk * 64 + threadIdx.x;
@@ -354,10 +355,28 @@ __device__ __forceinline__ void horner_body(const HornerArgs &h, size_t blk) {
   }
   raw_store(&h.varsum[p], acc);
 }
+// The same pass with the four lanes of a DPP quad per proof (ec29_quad.cuh): a doubling is 3 field multiplications
+// deep instead of 9, a general addition 5 instead of 16 -- the longest link of a batch's chain shortened ~1.7x for
+// 4x the lanes of a 16-wave kernel.  16 proofs per wave.
+__device__ __forceinline__ void horner4_body(const HornerArgs &h, size_t blk) {
+  __builtin_amdgcn_s_setprio(2);
+  const int role = threadIdx.x & 3;
+  size_t p = blk * 16 + (threadIdx.x >> 2);
+  const bool live = p < h.nb;
+  if (!live) p = h.nb - 1;             // whole quads stay active
+  JacT acc = jact_from_jac(raw_load(&h.winsum[p * 64 + (size_t)(h.count - 1) * h.stride]));
+#pragma unroll 1
+  for (int w = h.count - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int d = 0; d < h.dbl; d++) acc = q4_dbl(acc, role);
+    acc = q4_add(acc, jact_from_jac(raw_load(&h.winsum[p * 64 + (size_t)w * h.stride])), role);
+  }
+  if (live && role == 0) raw_store(&h.varsum[p], jact_to_jac(acc));
+}
 // the Horner lanes (blocks [0, horner_blocks)) and the small fixed-base MSMs in one launch
 template <int C, int LPM>
 __global__ void __launch_bounds__(64) k_verify_back(HornerArgs h, unsigned horner_blocks, FixedSmallArgs f) {
-  if (blockIdx.x < horner_blocks) horner_body(h, blockIdx.x);
+  if (blockIdx.x < horner_blocks) { if (h.quad) horner4_body(h, blockIdx.x); else horner_body(h, blockIdx.x); }
   else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - horner_blocks);
 }
 // lane per proof: variable-base sum + fixed-base partial; ok = identity and every input of the proof well-formed
@@ -384,15 +403,16 @@ __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, con
   }
 }
 // points per table lane: 8 = fewest instructions (one inversion per 8 points), 4 (default) = half the dependency chain of
-// the front launch for +1.3 % instructions per batch
-static int wp_tnp() {
-  static const int v = getenv("BPGPU_TABLE_NP") ? atoi(getenv("BPGPU_TABLE_NP")) : 4;
-  return v == 8 ? 8 : (v == 2 ? 2 : 4);
+// the front launch for +1.3 % instructions per batch, 2 (latency mode) = a quarter for +4 %.  BPGPU_TABLE_NP overrides.
+static int wp_tnp(const VerifyWp &v) {
+  static const int env = getenv("BPGPU_TABLE_NP") ? atoi(getenv("BPGPU_TABLE_NP")) : 0;
+  const int t = env ? env : (v.latency_mode ? 2 : 4);
+  return t == 8 ? 8 : (t == 2 ? 2 : 4);
 }
 struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
-  const size_t tnp = wp_tnp(), lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
+  const size_t tnp = 2, lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
   return al256(blocks * tnp * SE * STE * 64 * 4) + al256(nb * nvar * SE * sizeof(AffRaw)) + al256(nb * 64 * sizeof(JacRaw)) +
          al256(nb * sizeof(JacRaw)) + al256(nb * lanes * 4);
 }
@@ -402,7 +422,7 @@ bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
 }
 static WpLayout wp_layout(const VerifyWp &v) {
   WpLayout L{};
-  const size_t tnp = wp_tnp();
+  const size_t tnp = wp_tnp(v);
   L.t.points = v.points_abi; L.t.nb = v.nb; L.t.nvar = v.nvar; L.t.lanes = (v.nvar + tnp - 1) / tnp; L.t.bad = v.bad;
   const size_t nblk = (v.nb * L.t.lanes + 63) / 64;
   uint8_t *sp = (uint8_t *)v.scratch;
@@ -421,7 +441,7 @@ void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims 
   if (!with_prep) prep.d.nb = 0;
   WpLayout L = wp_layout(v);
   const unsigned pb = (unsigned)((prep.d.nb + 63) / 64);
-  switch (wp_tnp()) {
+  switch (wp_tnp(v)) {
     case 8: hipLaunchKernelGGL((k_verify_front<8>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
     case 2: hipLaunchKernelGGL((k_verify_front<2>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
     default: hipLaunchKernelGGL((k_verify_front<4>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
@@ -443,21 +463,27 @@ void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
 }
 template <int C>
-static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f) {
-  if (f.nb >= 1024) hipLaunchKernelGGL((k_verify_back<C, 16>), dim3(hb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, h, hb, f);
+static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode) {
+  // lanes per fixed-base MSM: 16 = fewest instructions (4 butterfly levels), 32 = half the serial additions per lane
+  // (the fixed-base lanes are the longest link of this launch once the Horner pass runs on quads); BPGPU_FIXED_LPM overrides
+  static const int lpm_env = getenv("BPGPU_FIXED_LPM") ? atoi(getenv("BPGPU_FIXED_LPM")) : 0;
+  const int lpm = lpm_env == 16 || lpm_env == 32 ? lpm_env : (f.nb >= 1024 && !latency_mode ? 16 : 32);
+  if (lpm == 16) hipLaunchKernelGGL((k_verify_back<C, 16>), dim3(hb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, h, hb, f);
   else hipLaunchKernelGGL((k_verify_back<C, 32>), dim3(hb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, h, hb, f);
 }
 // Horner pass over the window sums | table-lookup MSMs over the generators (fixed scalars as for fixed_msm)
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
                     const uint32_t *fixed_scalars, size_t sc_stride, JacRaw *out_fixed) {
   WpLayout L = wp_layout(v);
-  HornerArgs h{L.winsum, L.varsum, v.nb, 64, 1, SW};
+  // BPGPU_HORNER_QUAD=0: one lane per proof (ec29.cuh) instead of a DPP quad per proof (ec29_quad.cuh)
+  static const int quad = getenv("BPGPU_HORNER_QUAD") ? atoi(getenv("BPGPU_HORNER_QUAD")) != 0 : 1;
+  HornerArgs h{L.winsum, L.varsum, v.nb, 64, 1, SW, quad};
   if (wp_grouped()) { h.count = 64 / HG; h.stride = HG; h.dbl = SW * HG; }
-  const unsigned hb = (unsigned)((v.nb + 63) / 64);
+  const unsigned hb = (unsigned)(quad ? (v.nb + 15) / 16 : (v.nb + 63) / 64);
   FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
-  if (c == 8) launch_back<8>(st, h, hb, f);
-  else if (c == 16) launch_back<16>(st, h, hb, f);
-  else launch_back<20>(st, h, hb, f);
+  if (c == 8) launch_back<8>(st, h, hb, f, v.latency_mode);
+  else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode);
+  else launch_back<20>(st, h, hb, f, v.latency_mode);
 }
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
   WpLayout L = wp_layout(v);

@@ -188,6 +188,31 @@ void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRa
   hipLaunchKernelGGL(k_verify_finalize, dim3((nb + 1) / 2), dim3(64), 0, st, var, nvar, fixed, nb, ok, mega, bad_sc, bad_pt);
 }
 
+// sum of n boundary points (validated here), one block: lane-strided mixed additions, LDS tree, boundary bytes out
+__global__ void __launch_bounds__(128) k_points_sum(const Words8 *xy, size_t n, Words8 *out_xy, int *bad) {
+  __shared__ int32_t smem[27 * 64];
+  Jac acc = jac_inf();
+  for (size_t i = threadIdx.x; i < n; i += 128) {
+    uint32_t w[16];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { w[j] = xy[2 * i].w[j]; w[8 + j] = xy[2 * i + 1].w[j]; }
+    Aff a;
+    if (!aff_from_boundary(a, w)) { atomicOr(bad, 1); continue; }
+    acc = jac_madd(acc, a);
+  }
+  acc = block_sum<128>(acc, smem);
+  if (threadIdx.x == 0) {
+    if (!jac_is_inf(acc) && is_zero_exact(acc.Z)) acc = jac_inf();
+    uint32_t w[16];
+    aff_to_boundary(w, jac_to_aff(acc));
+#pragma unroll
+    for (int j = 0; j < 8; j++) { out_xy[0].w[j] = w[j]; out_xy[1].w[j] = w[8 + j]; }
+  }
+}
+void points_sum(hipStream_t st, const Words8 *xy, size_t n, Words8 *out_xy, int *bad) {
+  hipLaunchKernelGGL(k_points_sum, dim3(1), dim3(128), 0, st, xy, n, out_xy, bad);
+}
+
 // dst[p * dst_outer + i] = src[p * src_outer + i], i < cnt (16-byte vector copies)
 __global__ void __launch_bounds__(256) k_gather16(const uint4 *src, size_t src_outer, size_t cnt, uint4 *dst, size_t dst_outer, int vec) {
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;

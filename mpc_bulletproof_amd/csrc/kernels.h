@@ -16,6 +16,8 @@ struct Words8 { uint32_t w[8]; };   // one 256-bit field element (plain canonica
 // bad_unit (optional, zeroed by the caller): [i / per_unit] = 1 for a malformed point i (per-proof attribution)
 void points_from_boundary(hipStream_t st, const Words8 *xy /*2 per point*/, AffDev *out, size_t n, int *bad,
                           int32_t *bad_unit = nullptr, size_t per_unit = 1);
+// out = sum of n boundary points (validated; *bad |= 1 on a malformed one, which is skipped)
+void points_sum(hipStream_t st, const Words8 *xy, size_t n, Words8 *out_xy, int *bad);
 // JacRaw -> boundary bytes (one inversion per point)
 void jac_to_boundary(hipStream_t st, const JacRaw *in, Words8 *xy_out, size_t n);
 // JacRaw[n] -> device affine, Montgomery's trick in runs of `run` points per lane
@@ -55,7 +57,9 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
 // Window-parallel variant of the same (k_ec.hip): front [tables | inversion pass] -> (k_verify_scalars) -> windows -> groups ->
 // back [Horner | fixed-base MSMs] -> verdict, which writes ok / mega itself (no verify_finalize).
 // bad_sc: the per-proof canonicity bits written by verify_scalars (nullable)
-struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; };
+// latency_mode: more, shorter lanes in the two longest launches (2 points per table lane, 32 lanes per fixed-base MSM): one batch
+// alone finishes ~25 % sooner, a pipelined stream of batches runs ~5 % slower (more instructions)
+struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; };
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
 struct VsPrepArgs;
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);

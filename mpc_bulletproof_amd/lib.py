@@ -7,8 +7,8 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_host_alloc", "bpgpu_host_free",
-    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
+    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
+    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
@@ -40,6 +40,23 @@ def load():
 
 
 _lib = load()
+_lib.bpgpu_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+_lib.bpgpu_host_free.argtypes = [C.c_void_p]
+
+
+def host_alloc(nbytes, data=None):
+    """page-locked staging memory (bpgpu_host_alloc), optionally filled with `data`; returns a c_void_p"""
+    p = C.c_void_p()
+    rc = _lib.bpgpu_host_alloc(C.c_size_t(nbytes), C.byref(p))
+    if rc or not p.value:
+        raise BpGpuError(rc or E_OOM, "bpgpu_host_alloc")
+    if data is not None:
+        C.memmove(p, bytes(data), len(data))
+    return p
+
+
+def host_free(p):
+    _lib.bpgpu_host_free(p)
 E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
 # bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
 PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
@@ -103,6 +120,10 @@ class BpGpu:
     def upload(self, dptr, data):
         self._ck(_lib.bpgpu_upload(self.ctx, dptr, _buf(data), C.c_size_t(len(data))))
 
+    def upload_async(self, dptr, host_ptr, nbytes):
+        """enqueue a copy from (page-locked) host memory on the context's stream; host_ptr: integer address / c_void_p"""
+        self._ck(_lib.bpgpu_upload_async(self.ctx, dptr, C.c_void_p(host_ptr if isinstance(host_ptr, int) else host_ptr.value), C.c_size_t(nbytes)))
+
     def to_device(self, data):
         p = self.malloc(len(data))
         self.upload(p, data)
@@ -117,6 +138,9 @@ class BpGpu:
         v = C.c_int(0)
         self._ck(_lib.bpgpu_input_flag(self.ctx, C.byref(v)))
         return v.value
+
+    def set_latency_mode(self, on=True):
+        self._ck(_lib.bpgpu_set_latency_mode(self.ctx, 1 if on else 0))
 
     def profile_enable(self, on=True):
         self._ck(_lib.bpgpu_profile_enable(self.ctx, 1 if on else 0))
@@ -136,6 +160,13 @@ class BpGpu:
 
     def msm_batch_dev(self, nb, n, d_scalars, d_points, d_out):
         self._ck(_lib.bpgpu_msm_batch_dev(self.ctx, C.c_size_t(nb), C.c_size_t(n), d_scalars, d_points, d_out))
+
+    def points_sum(self, points):
+        """sum of the 64-byte points in `points` (no scalars) -> 64 bytes"""
+        n = len(points) // 64
+        out = _out(64)
+        self._ck(_lib.bpgpu_points_sum(self.ctx, _buf(points), C.c_size_t(n), out))
+        return bytes(out)
 
     def msm_shared(self, nsets, n, scalars, points):
         """nsets MSMs over one point vector (msm_authenticated_iter's share / MAC / modifier MSMs)."""

@@ -53,22 +53,34 @@ def gather_accept_bits(local_ok, total, group=None):
     return out
 
 
-def combine_partial_points(local_point: bytes, point_add, group=None) -> bytes:
-    """All-gather one partial MSM result (64-byte affine point, zeros = identity) per rank and add
-    them locally with `point_add(a, b) -> bytes` (RCCL has no elliptic-curve reduction op)."""
-    acc = bytes(64)
-    for p in allgather_bytes(local_point, group):
-        acc = point_add(acc, p)
-    return acc
+def combine_partial_points(local_point: bytes, points_sum, group=None) -> bytes:
+    """All-gather one partial MSM result (64-byte affine point, zeros = identity) per rank and add them locally with
+    `points_sum(points_bytes) -> 64 bytes` (BpGpu.points_sum: one launch; RCCL has no elliptic-curve reduction op)."""
+    return points_sum(b"".join(allgather_bytes(local_point, group)))
 
 
-def sharded_msm(scalars: bytes, points: bytes, msm_fn, point_add, group=None) -> bytes:
+def sharded_msm(scalars: bytes, points: bytes, msm_fn, points_sum, group=None) -> bytes:
     """One LARGE multi-scalar multiplication split by term range (the 98 347-term mega_check of
-    the 2^14-shuffle): rank r computes sum over its contiguous slice with `msm_fn(scalars, points) -> 64 B`
+    the 2^14-shuffle): rank r computes the sum over its contiguous slice with `msm_fn(scalars, points) -> 64 B`
     (BpGpu.msm on the GPU box), the <= 8 partial points are all-gathered and added locally.  Every rank
-    returns the same full result."""
+    returns the same full result.  Operands arrive as host byte strings: see sharded_msm_dev for resident ones."""
     n = len(scalars) // 32
     assert len(points) == 64 * n
     lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
     part = msm_fn(scalars[32 * lo:32 * hi], points[64 * lo:64 * hi]) if hi > lo else bytes(64)
-    return combine_partial_points(part, point_add, group)
+    return combine_partial_points(part, points_sum, group)
+
+
+def sharded_msm_dev(gpu, d_scalars, d_points, n, d_out, group=None) -> bytes:
+    """The same with the operands RESIDENT in this rank's HBM (every rank holds the full scalar / point vectors, e.g. the
+    generators and the scalars its own scalar-assembly kernels wrote): the rank's slice is addressed in place
+    (bpgpu_msm_batch_dev on a pointer offset), only the 64-byte partial crosses PCIe, and the partials are summed with one
+    point-sum launch.  gpu: BpGpu; d_*: device pointers (c_void_p); d_out: 64 B of device memory.  Returns the full sum."""
+    import ctypes as C
+    lo, hi = shard_bounds(n, dist.get_rank(group), dist.get_world_size(group))
+    if hi > lo:
+        gpu.msm_batch_dev(1, hi - lo, C.c_void_p(d_scalars.value + 32 * lo), C.c_void_p(d_points.value + 64 * lo), d_out)
+        part = gpu.download(d_out, 64)
+    else:
+        part = bytes(64)
+    return combine_partial_points(part, gpu.points_sum, group)

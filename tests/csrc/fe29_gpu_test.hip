@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "../../mpc_bulletproof_amd/csrc/ec29.cuh"
+#include "../../mpc_bulletproof_amd/csrc/ec29_quad.cuh"
 using namespace bp;
 
 template <class F> __device__ bool d_load(Fe<F> &out, const uint32_t *w) {
@@ -78,6 +79,46 @@ __global__ void k_point(int op, const uint32_t *a, const uint32_t *b, uint32_t *
   rc[i] = 0;
 }
 
+// Quad-cooperative group law (ec29_quad.cuh): element i is handled by the 4 lanes of quad i.
+// op 0: a + b (both operands rescaled to non-trivial Z)   1: 2 a   2: ((a 2^32 + b) 2^32 + b) 2^4 + a  (a Horner stretch)
+__global__ void __launch_bounds__(64) k_q4(int op, const uint32_t *a, const uint32_t *b, uint32_t *out, int *rc, size_t n) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t i = t >> 2;
+  const int role = (int)(t & 3);
+  if (i >= n) i = n - 1;          // whole quads stay active (n is padded to a multiple of 16 quads by the caller anyway)
+  uint32_t wa[16], wb[16];
+  for (int j = 0; j < 16; j++) { wa[j] = a[16 * i + j]; wb[j] = b[16 * i + j]; }
+  Aff p, q;
+  if (!aff_from_boundary(p, wa) || !aff_from_boundary(q, wb)) { if (role == 0) rc[i] = -1; return; }
+  Jac pj = jac_from_aff(p), qj = jac_from_aff(q);
+  const uint32_t zw[8] = {0x12345, 7, 9, 0, 0, 0, 0, 0};
+  Fp z = to_mont(unpack<FP>(zw));
+  Fp z2 = sqr(z), z3 = mul(z2, z);
+  if (!jac_is_inf(qj)) { qj.X = mul(qj.X, z2); qj.Y = mul(qj.Y, z3); qj.Z = mul(qj.Z, z); }
+  if (!jac_is_inf(pj)) { Fp w = add(z, z2), w2 = sqr(w), w3 = mul(w2, w); pj.X = mul(pj.X, w2); pj.Y = mul(pj.Y, w3); pj.Z = mul(pj.Z, w); }
+  JacT P = jact_from_jac(pj), Q = jact_from_jac(qj), r;
+  if (op == 0) r = q4_add(P, Q, role);
+  else if (op == 1) r = q4_dbl(P, role);
+  else {
+    r = P;
+    for (int rep = 0; rep < 2; rep++) {
+      for (int d = 0; d < 32; d++) r = q4_dbl(r, role);
+      r = q4_add(r, Q, role);
+    }
+    for (int d = 0; d < 4; d++) r = q4_dbl(r, role);
+    r = q4_add(r, P, role);
+  }
+  // T must be Z^4 on exit (it feeds the next doubling)
+  Jac rj = jact_to_jac(r);
+  const bool t_ok = is_zero_exact(sub(r.T, sqr(sqr(r.Z))));
+  uint32_t wo[16];
+  aff_to_boundary(wo, jac_to_aff(jac_is_inf(rj) || is_zero_exact(rj.Z) ? jac_inf() : rj));
+  if (role == 0) {
+    for (int j = 0; j < 16; j++) out[16 * i + j] = wo[j];
+    rc[i] = t_ok ? 0 : -3;
+  }
+}
+
 namespace {
 struct DevBuf {
   void *p = nullptr;
@@ -107,6 +148,14 @@ int g29_rawmul(int field, int sq, const int32_t *a, const int32_t *b, size_t n, 
   else hipLaunchKernelGGL(k_rawmul<FN>, g, t, 0, 0, sq, (const int32_t *)da.p, (const int32_t *)db.p, (uint32_t *)dout.p, n);
   if (hipDeviceSynchronize() != hipSuccess) return -100;
   return down(out, dout, 32 * n) ? 0 : -100;
+}
+int g29_q4(int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, int *rc) {
+  DevBuf da(64 * n), db(64 * n), dout(64 * n), drc(4 * n);
+  if (!up(da, a, 64 * n) || !up(db, b, 64 * n) || !dout.p || !drc.p) return -100;
+  hipLaunchKernelGGL(k_q4, dim3((unsigned)((4 * n + 63) / 64)), dim3(64), 0, 0, op, (const uint32_t *)da.p, (const uint32_t *)db.p,
+                     (uint32_t *)dout.p, (int *)drc.p, n);
+  if (hipDeviceSynchronize() != hipSuccess) return -100;
+  return down(out, dout, 64 * n) && down(rc, drc, 4 * n) ? 0 : -100;
 }
 int g29_point(int op, const uint8_t *a, const uint8_t *b, size_t n, uint8_t *out, int *rc) {
   DevBuf da(64 * n), db(64 * n), dout(64 * n), drc(4 * n);

@@ -1,0 +1,58 @@
+"""One rank of the two-process HIP-path test (tests/test_gpu_multirank.py): torch.distributed over gloo, both ranks on
+cuda:0, every compute call through libbpgpu.so.  Started as a fresh interpreter (never forked from a GPU-initialised
+process).  Writes its results as JSON to argv[1].<rank>."""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_prefix, n_terms, n_bits, nb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch.distributed as dist
+    import bp_helpers as bh
+    import oracle_lib as o          # inputs only (seeded scalars, generators, oracle-made proofs): the sums are the GPU's
+    import mpc_bulletproof_amd as m
+    from mpc_bulletproof_amd import sharding as sh
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gpu = m.BpGpu(0)
+    try:
+        sc = o.random_scalars(4100, n_terms)
+        pts = ((o.gens("G", 512) + o.gens("H", 512)) * 3)[:64 * n_terms]
+        big_host = sh.sharded_msm(sc, pts, gpu.msm, gpu.points_sum)
+        d_sc, d_pts, d_out = gpu.to_device(sc), gpu.to_device(pts), gpu.malloc(64)
+        big_dev = sh.sharded_msm_dev(gpu, d_sc, d_pts, n_terms, d_out)
+        # proofs sharded by index: accept bits gathered, one combined-check partial per rank summed
+        recs, cap = bh.make_range_batch(n_bits, nb, tamper={1})
+        lo, hi = sh.shard_bounds(nb, rank, world)
+        s0 = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
+        rp, kind, idx, coeff = s0.csr()
+        circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+        gens = gpu.gens_create(o.gens("G", cap), o.gens("H", cap), o.generator(), o.generator(), 8)
+        p_b = q_b = c_b = b""
+        for proof, com in recs[lo:hi]:
+            s = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap)
+            k, p, q = bh.verify_inputs(proof, com)
+            p_b, q_b, c_b = p_b + p, q_b + q, c_b + s.challenges()
+            s.close()
+        ok, _, _ = gpu.r1cs_verify_batch(gens, circ, hi - lo, s0.n1, s0.k, s0.m, p_b, q_b, c_b)
+        full_ok = sh.gather_accept_bits(ok, nb)
+        rho = o.random_scalars(777, nb)
+        part = gpu.r1cs_verify_combined(gens, circ, hi - lo, s0.n1, s0.k, s0.m, p_b, q_b, c_b, rho[32 * lo:32 * hi])
+        comb = sh.combine_partial_points(part, gpu.points_sum)
+        tmax = sh.max_over_ranks(float(rank + 1))
+        with open(f"{out_prefix}.{rank}", "w") as f:
+            json.dump({"big_host": big_host.hex(), "big_dev": big_dev.hex(), "ok": full_ok, "comb": comb.hex(), "tmax": tmax,
+                       "lo": lo, "hi": hi}, f)
+    finally:
+        gpu.close()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

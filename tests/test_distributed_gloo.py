@@ -19,6 +19,14 @@ def _free_port():
     return p
 
 
+def _points_sum(points):
+    import oracle_lib as o
+    acc = bytes(64)
+    for i in range(0, len(points), 64):
+        acc = o.point_add(acc, points[i:i + 64])
+    return acc
+
+
 def _worker(rank, world, port, n_bits, nb, q):
     sys.path.insert(0, HERE)
     sys.path.insert(0, ROOT)
@@ -41,11 +49,11 @@ def _worker(rank, world, port, n_bits, nb, q):
             s = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap)
             local_pt = o.point_add(local_pt, s.mega_check())
             s.close()
-        total_pt = sh.combine_partial_points(local_pt, o.point_add)
+        total_pt = sh.combine_partial_points(local_pt, _points_sum)
         tmax = sh.max_over_ranks(float(rank + 1))
         # one large MSM split by term range; 37 terms -> uneven slices
         sc, pts = o.random_scalars(91, 37), (o.gens("G", 32) + o.gens("H", 32))[:64 * 37]
-        big = sh.sharded_msm(sc, pts, o.msm, o.point_add)
+        big = sh.sharded_msm(sc, pts, o.msm, _points_sum)
         q.put((rank, lo, hi, full, total_pt, tmax, big))
     finally:
         dist.destroy_process_group()

@@ -133,3 +133,35 @@ def test_point_ops_including_exceptional_cases_on_device(g):
     ba = (C.c_uint8 * 64).from_buffer_copy(bytes(bad))
     gg = (C.c_uint8 * 64).from_buffer_copy(pm.p2b(pm.G))
     assert g.g29_point(0, ba, gg, C.c_size_t(1), out, rc) == 0 and rc[0] == -1
+
+
+def test_quad_cooperative_group_law_on_device(g):
+    """ec29_quad.cuh (four lanes of a DPP quad per point, modified Jacobian coordinates with the halved doubling): sums,
+    doublings and a Horner stretch of 68 doublings and 3 additions equal the Python model for every pair of a point set that
+    includes the identity on either side, P + P and P + (-P); T = Z^4 holds on exit."""
+    rnd = random.Random(137)
+    pts = [pm.INF, pm.G, pm.pt_neg(pm.G), pm.pt_mul(2, pm.G), pm.pt_mul(N - 2, pm.G)] + \
+          [pm.pt_mul(rnd.randrange(1, N), pm.G) for _ in range(11)]
+    pairs = [(a, b) for a in pts for b in pts]
+    pairs += [(pm.pt_mul(k, pm.G), pm.pt_mul(k << 32, pm.G)) for k in (1, 5)]     # the chain meets its own operand
+    while len(pairs) % 16:
+        pairs.append((pm.G, pm.G))
+    n = len(pairs)
+    a = (C.c_uint8 * (64 * n)).from_buffer_copy(b"".join(pm.p2b(x) for x, _ in pairs))
+    b = (C.c_uint8 * (64 * n)).from_buffer_copy(b"".join(pm.p2b(y) for _, y in pairs))
+    out, rc = (C.c_uint8 * (64 * n))(), (C.c_int * n)()
+    for op in (0, 1, 2):
+        assert g.g29_q4(op, a, b, C.c_size_t(n), out, rc) == 0, "no HIP device"
+        assert not any(rc), (op, list(rc))
+        ob = bytes(out)
+        for i, (x, y) in enumerate(pairs):
+            if op == 0:
+                want = pm.pt_add(x, y)
+            elif op == 1:
+                want = pm.pt_add(x, x)
+            else:
+                acc = x
+                for _ in range(2):
+                    acc = pm.pt_add(pm.pt_mul(1 << 32, acc), y)
+                want = pm.pt_add(pm.pt_mul(16, acc), x)
+            assert pm.b2p(ob[64 * i:64 * i + 64]) == want, (op, i, x, y)

@@ -1,6 +1,6 @@
-"""GPU tests of the host-side C++ mirror of the reference API (libbphost.so over libbpgpu.so):
-its proofs are byte-identical to the CPU oracle's on the same seeds, and the reference's own tests
-(restated in mpc_bulletproof_amd/host/host_tests.cpp) pass."""
+"""GPU tests of the host-side C++ mirror of the reference API (libbphost.so over libbpgpu.so), driven through the flat
+harness tests/host/libbph_capi.so: its proofs are byte-identical to the CPU oracle's on the same seeds, and the reference's
+own tests (restated in tests/host/host_tests.cpp) pass."""
 import ctypes as C
 import os
 import subprocess
@@ -16,7 +16,7 @@ H = bytes.fromhex
 
 @pytest.fixture(scope="module")
 def host():
-    lib = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+    lib = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
     return lib
 
 
@@ -113,7 +113,7 @@ def test_prove_verify_64bit_and_errors(host):
 
 
 def test_reference_tests_restated_in_cpp():
-    exe = os.path.join(ROOT, "mpc_bulletproof_amd", "host", "host_tests")
+    exe = os.path.join(ROOT, "tests", "host", "host_tests")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "all passed" in r.stdout

@@ -861,7 +861,7 @@ def test_proof_wire_format_golden(golden_codec):
     wire bytes of the committed golden proofs (1-phase and 2-phase), and the reference's length / version errors."""
     import ctypes as C
     import os
-    host = C.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mpc_bulletproof_amd", "libbphost.so"))
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "host", "libbph_capi.so"))
     out, ln = (C.c_uint8 * 8192)(), C.c_size_t(0)
     for rec in golden_codec["proofs"]:
         flat, wire = H(rec["flat"]), H(rec["wire"])

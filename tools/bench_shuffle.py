@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as o   # noqa: E402
 
-host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
 label = b"ShuffleProofTest"
 NAMES = ["generators", "tables+commitments", "prover circuit", "prove", "verifier circuit", "verify"]
 

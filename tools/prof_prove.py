@@ -2,7 +2,7 @@ import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as o
-host = C.CDLL(os.path.join(ROOT, "mpc_bulletproof_amd", "libbphost.so"))
+host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
 nb, nvals, n_bits = int(sys.argv[1]), 16, 64
 n = nvals * n_bits
 label = b"RangeProofTest"
