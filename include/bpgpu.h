@@ -112,6 +112,22 @@ int bpgpu_msm_batch_dev(bpgpu_ctx *ctx, size_t nb, size_t n, const void *scalars
  * a node all-gather after a term-range-sharded MSM or a combined batch check -- one launch instead of an
  * MSM with unit scalars (whose 252-doubling chain costs ~1 ms however few the terms). */
 int bpgpu_points_sum(bpgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t out[64]);
+/* ---- arkworks in-memory forms: zero-copy hand-over from the Rust host --------------------------------
+ * mpc-stark's Scalar is ark_ff::Fp256<MontBackend<_, 4>>: four little-endian u64 limbs holding x * 2^256 mod n (32 bytes as
+ * they lie in memory); its StarkPoint is ark_ec::short_weierstrass::Projective: Jacobian (X : Y : Z), the point is
+ * (X / Z^2, Y / Z^3), each coordinate four u64 limbs holding c * 2^256 mod p (96 bytes), identity Z = 0.  These entry points take
+ * and return exactly those bytes: no de-Montgomery / serialisation / inversion on the host (one Montgomery multiplication per
+ * element on the device instead).  Non-canonical limbs (>= modulus) and points off the curve -> BPGPU_E_ARG.
+ *   bpgpu_msm_ark            StarkPoint::msm / msm_iter with operands and result in arkworks form
+ *                            -- verifier.rs:516-547, prover.rs:465-564, inner_product_proof.rs:90-172
+ *   bpgpu_scalars_from_ark / _to_ark, bpgpu_points_from_ark / _to_ark: convert whole vectors to / from the boundary encodings
+ *                            (32-byte LE canonical scalars, 64-byte affine x || y) that every other entry point takes. */
+int bpgpu_msm_ark(bpgpu_ctx *ctx, const uint8_t *scalars_mont, const uint8_t *points_jac_mont, size_t n,
+                  uint8_t out_jac_mont[96]);
+int bpgpu_scalars_from_ark(bpgpu_ctx *ctx, const uint8_t *scalars_mont, size_t n, uint8_t *scalars_le);
+int bpgpu_scalars_to_ark(bpgpu_ctx *ctx, const uint8_t *scalars_le, size_t n, uint8_t *scalars_mont);
+int bpgpu_points_from_ark(bpgpu_ctx *ctx, const uint8_t *points_jac_mont, size_t n, uint8_t *points_xy);
+int bpgpu_points_to_ark(bpgpu_ctx *ctx, const uint8_t *points_xy, size_t n, uint8_t *points_jac_mont);
 /* nsets MSMs over ONE point vector: out[s] = sum_i scalars[s*n + i] * points[i].  This is the local work of
  * StarkPoint::msm_authenticated_iter in the two-party prover -- one MSM each over the secret shares, the MACs and
  * the public modifiers of the same authenticated scalars against the same points (r1cs_mpc/mpc_prover.rs:621-657,

@@ -52,6 +52,7 @@ struct ProfScope {   // records start/stop events on `st` around a launch when p
   ProfScope(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) { if (c->prof) mark(c, kind, st); }
   ~ProfScope() { if (c->prof) mark(c, kind, st); }
 };
+static void prof_mark_cb(void *c, int kind, hipStream_t st) { ProfScope::mark((bpgpu_ctx *)c, kind, st); }
 struct bpgpu_gens {
   size_t cap = 0;
   int c = 0;
@@ -356,9 +357,21 @@ static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void 
   CK(ws_get(ctx, 2, tot * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
   CK(ws_get(ctx, 4, nb * sizeof(JacRaw), &dsum));
+  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  if (n >= pip_min) {
+    // 32-bit bucket ids, sorted entries (term index | sign bit) and offsets: reject what they cannot address
+    const size_t cW = 252 / (size_t)pippenger_window(n) + 1, chalf = (size_t)1 << (pippenger_window(n) - 1);
+    if (n >= ((size_t)1 << 31) / nb || nb * cW * chalf >= ((size_t)1 << 31) || tot * cW >= ((size_t)1 << 32)) return BPGPU_E_LEN;
+  }
+  if (nb == 1 && n >= pip_min && pippenger2_supported(n)) {   // one mid-size instance: seven launches (k_pip2.hip)
+    const int c2 = pippenger2_window(n);
+    void *dpip;
+    CK(ws_get(ctx, 14, pippenger2_scratch_bytes(n, c2), &dpip));
+    pippenger2_boundary(ctx->st, (const Words8 *)dxy, (const Words8 *)dsc, n, c2, (Words8 *)dout, (AffDev *)dpts, dpip, ctx->d_flag);
+    return launch_ok(ctx);
+  }
   scalars_check(ctx->st, (const Words8 *)dsc, tot, ctx->d_flag);
   points_from_boundary(ctx->st, (const Words8 *)dxy, (AffDev *)dpts, tot, ctx->d_flag);
-  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
   if (n >= pip_min) {   // bucket method
     int c = pippenger_window(n);
     void *dpip;
@@ -424,6 +437,116 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
 }
 
 /* nsets MSMs over ONE point vector (the share / MAC / public-modifier MSMs of msm_authenticated_iter) */
+/* ---------------------------------------------------------------- arkworks in-memory forms (k_ark.hip) */
+// sum_i scalars[i] * pts[i] for validated device operands (plain canonical scalars, Montgomery affine points) -> one JacRaw
+static int msm_core_locked(bpgpu_ctx *ctx, size_t n, const uint32_t *dsc, const AffDev *dpts, JacRaw *dsum) {
+  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  void *dpip;
+  if (n >= pip_min && pippenger2_supported(n)) {
+    const int c2 = pippenger2_window(n);
+    CK(ws_get(ctx, 14, pippenger2_scratch_bytes(n, c2), &dpip));
+    pippenger2(ctx->st, dpts, dsc, n, c2, dsum, dpip, ctx->d_flag);
+  } else if (n >= pip_min) {
+    const int c = pippenger_window(n);
+    const size_t cW = 252 / (size_t)c + 1;
+    if (n >= ((size_t)1 << 31) || cW * ((size_t)1 << (c - 1)) >= ((size_t)1 << 31) || n * cW >= ((size_t)1 << 32)) return BPGPU_E_LEN;
+    CK(ws_get(ctx, 14, pippenger_scratch_bytes(n, c), &dpip));
+    pippenger(ctx->st, dpts, dsc, n, c, dsum, dpip);
+  } else {
+    void *dres, *dstr;
+    CK(ws_get(ctx, 13, straus_scratch_bytes(1, n), &dstr));
+    CK(ws_get(ctx, 12, n * sizeof(JacRaw), &dres));
+    StrausArgs sa{};
+    sa.pts[0] = dpts; sa.pt_stride[0] = 1;
+    sa.sc[0] = dsc; sa.sc_stride[0] = 8;
+    straus(ctx->st, 1, sa, (JacRaw *)dres, n, dstr);
+    segmented_sum(ctx->st, (JacRaw *)dres, dsum, 1, n);
+  }
+  return BPGPU_OK;
+}
+int bpgpu_msm_ark(bpgpu_ctx *ctx, const uint8_t *scalars_mont, const uint8_t *points_jac_mont, size_t n, uint8_t out_jac_mont[96]) {
+  if (!ctx || !out_jac_mont || (n && (!scalars_mont || !points_jac_mont))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *dsc, *dpj, *daff, *djac, *dsum, *dout;
+  CK(ws_get(ctx, 0, (n ? n : 1) * 32, &dsc));
+  CK(ws_get(ctx, 1, (n ? n : 1) * 96, &dpj));
+  CK(ws_get(ctx, 2, (n ? n : 1) * sizeof(AffDev), &daff));
+  CK(ws_get(ctx, 3, (n ? n : 1) * sizeof(JacRaw), &djac));
+  CK(ws_get(ctx, 4, sizeof(JacRaw), &dsum));
+  CK(ws_get(ctx, 5, 96, &dout));
+  CK(flag_reset(ctx));
+  if (n) {
+    CK(h2d(ctx, dsc, scalars_mont, n * 32));
+    CK(h2d(ctx, dpj, points_jac_mont, n * 96));
+    scalars_from_ark(ctx->st, (const Words8 *)dsc, (Words8 *)dsc, n, ctx->d_flag);                 // in place
+    points_from_ark(ctx->st, (const Words8 *)dpj, (JacRaw *)djac, n, ctx->d_flag);
+    batch_normalize(ctx->st, (const JacRaw *)djac, (AffDev *)daff, n, 8);
+    CK(msm_core_locked(ctx, n, (const uint32_t *)dsc, (const AffDev *)daff, (JacRaw *)dsum));
+  } else {
+    HIPCK(ctx, hipMemsetAsync(dsum, 0, sizeof(JacRaw), ctx->st));                                  // Z = 0: the identity
+  }
+  points_to_ark(ctx->st, (const JacRaw *)dsum, (Words8 *)dout, 1);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out_jac_mont, dout, 96));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+static int ark_convert_locked(bpgpu_ctx *ctx, int what, const uint8_t *in, size_t n, uint8_t *out) {
+  static const size_t in_sz[4] = {32, 32, 96, 64}, out_sz[4] = {32, 32, 64, 96};
+  if (!n) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  void *din, *dout, *djac, *daff;
+  CK(ws_get(ctx, 0, n * in_sz[what], &din));
+  CK(ws_get(ctx, 1, n * out_sz[what], &dout));
+  CK(ws_get(ctx, 3, n * sizeof(JacRaw), &djac));
+  CK(ws_get(ctx, 2, n * sizeof(AffDev), &daff));
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, din, in, n * in_sz[what]));
+  switch (what) {
+    case 0: scalars_from_ark(ctx->st, (const Words8 *)din, (Words8 *)dout, n, ctx->d_flag); break;
+    case 1: scalars_to_ark(ctx->st, (const Words8 *)din, (Words8 *)dout, n, ctx->d_flag); break;
+    case 2:
+      points_from_ark(ctx->st, (const Words8 *)din, (JacRaw *)djac, n, ctx->d_flag);
+      jac_to_boundary(ctx->st, (const JacRaw *)djac, (Words8 *)dout, n);
+      break;
+    default:
+      points_from_boundary(ctx->st, (const Words8 *)din, (AffDev *)daff, n, ctx->d_flag);
+      aff_to_jacraw(ctx->st, (const AffDev *)daff, (JacRaw *)djac, n);
+      points_to_ark(ctx->st, (const JacRaw *)djac, (Words8 *)dout, n);
+      break;
+  }
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, out, dout, n * out_sz[what]));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_scalars_from_ark(bpgpu_ctx *ctx, const uint8_t *scalars_mont, size_t n, uint8_t *scalars_le) {
+  if (!ctx || (n && (!scalars_mont || !scalars_le))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ark_convert_locked(ctx, 0, scalars_mont, n, scalars_le);
+}
+int bpgpu_scalars_to_ark(bpgpu_ctx *ctx, const uint8_t *scalars_le, size_t n, uint8_t *scalars_mont) {
+  if (!ctx || (n && (!scalars_mont || !scalars_le))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ark_convert_locked(ctx, 1, scalars_le, n, scalars_mont);
+}
+int bpgpu_points_from_ark(bpgpu_ctx *ctx, const uint8_t *points_jac_mont, size_t n, uint8_t *points_xy) {
+  if (!ctx || (n && (!points_jac_mont || !points_xy))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ark_convert_locked(ctx, 2, points_jac_mont, n, points_xy);
+}
+int bpgpu_points_to_ark(bpgpu_ctx *ctx, const uint8_t *points_xy, size_t n, uint8_t *points_jac_mont) {
+  if (!ctx || (n && (!points_jac_mont || !points_xy))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return ark_convert_locked(ctx, 3, points_xy, n, points_jac_mont);
+}
 int bpgpu_points_sum(bpgpu_ctx *ctx, const uint8_t *points, size_t n, uint8_t out[64]) {
   if (!ctx || !out || (n && !points)) return BPGPU_E_ARG;
   if (!n) { memset(out, 0, 64); return BPGPU_OK; }
@@ -1122,6 +1245,15 @@ static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(ws_get(ctx, 14, pippenger_scratch_bytes(tot, cw), &dpip));
   VerifyDims d{nb, n1, n, np, k, m};
   CK(flag_reset(ctx));
+  if (verify_combined2_supported(nb, nvar, g->c, np)) {   // eight launches on one stream (k_pip2.hip)
+    void *dc2;
+    CK(ws_get(ctx, 14, verify_combined2_scratch_bytes(nb, nvar, nfix), &dc2));
+    CombinedArgs ca{circuit_dev(c), d, nvar, (const Words8 *)points, (const Words8 *)scalars, (const Words8 *)challenges,
+                    (const Words8 *)rho, (Words8 *)dfix, (Words8 *)dvar, (int32_t *)dzp, g->table, g->cap, g->c, dc2, ctx->d_flag,
+                    (Words8 *)partial_xy, ctx->prof ? &prof_mark_cb : nullptr, ctx};
+    verify_combined2(ctx->st, ca);
+    return launch_ok(ctx);
+  }
   // (canonicity of the scalars and challenges is checked inside verify_scalars)
   scalars_check(ctx->st, (const Words8 *)rho, nb, ctx->d_flag);
   verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,

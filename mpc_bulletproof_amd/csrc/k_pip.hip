@@ -14,6 +14,7 @@
 // Integer work only; step 5's doubling chain (<= 252 sequential doublings, ~1 ms) is the latency
 // floor of any variable-base MSM on this machine.
 #include "ec_dev.cuh"
+#include "ec29_quad.cuh"
 
 using namespace bp;
 
@@ -214,22 +215,24 @@ __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, co
   uint32_t b = task_bucket[t], slice = (uint32_t)t - toffsets[b];
   uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1], hi = lo + PIP_TASK < end ? lo + PIP_TASK : end;
   Jac acc = jac_inf();
-  // the point of entry e + 1 is requested before the addition of entry e starts (two dependent loads -- index, then a
-  // random 64-byte row -- per ~1 650-instruction addition; unpipelined the launch ran at half the addition rate)
-  uint32_t cur[16], vcur = 0;
+  // Two dependent loads per entry (index, then a random 64-byte row) against a ~1 650-instruction addition: the index
+  // of entry e + 2 and the row of entry e + 1 are requested before the addition of entry e starts (with the row of
+  // e + 1 waiting on an index fetched in the same iteration the launch ran at 60 percent of the addition rate).
+  uint32_t cur[16], vcur = 0, vnxt = 0;
   if (lo < hi) {
     vcur = sorted[lo];
     const AffDev *src = &pts[vcur & 0x7FFFFFFFu];
 #pragma unroll
     for (int j = 0; j < 16; j++) cur[j] = src->w[j];
+    if (lo + 1 < hi) vnxt = sorted[lo + 1];
   }
   for (uint32_t e = lo; e < hi; e++) {
-    uint32_t nxt[16], vnxt = 0;
+    uint32_t nxt[16], vnn = 0;
     if (e + 1 < hi) {
-      vnxt = sorted[e + 1];
       const AffDev *src = &pts[vnxt & 0x7FFFFFFFu];
 #pragma unroll
       for (int j = 0; j < 16; j++) nxt[j] = src->w[j];
+      if (e + 2 < hi) vnn = sorted[e + 2];
     }
     Aff q;
     q.x = unpack<FP>(cur);
@@ -239,6 +242,7 @@ __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, co
 #pragma unroll
     for (int j = 0; j < 16; j++) cur[j] = nxt[j];
     vcur = vnxt;
+    vnxt = vnn;
   }
   raw_store(&partial[t], acc);
 }
@@ -301,17 +305,22 @@ static int pip_window_chunks(int half, size_t ninst, int W) {
   while (half / (chunks * 2) >= PW_TPB * 4 && ninst * (size_t)W * (size_t)(chunks * 2) <= 8192) chunks *= 2;   // >= 4 buckets per lane
   return chunks;
 }
-// Horner over the windows, one lane per instance: sum_w 2^(c w) S_w with 252 doublings in all
-// (per-window doubling would cost c W^2 / 2 of them)
+// Horner over the windows, one QUAD per instance (ec29_quad.cuh: a doubling is 3 field multiplications deep instead of
+// 9): sum_w 2^(c w) S_w with 252 doublings in all (per-window doubling would cost c W^2 / 2 of them).  One lane per
+// instance took 0.75 - 0.9 ms however small the MSM: the latency floor of every bucket-method call.
 __global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, int c, size_t ninst, JacRaw *out, size_t out_stride) {
-  size_t inst = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (inst >= ninst) return;
-  Jac acc = raw_load(&win[inst * W + W - 1]);
+  const int role = threadIdx.x & 3;
+  size_t inst = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const bool live = inst < ninst;
+  if (!live) inst = ninst - 1;          // whole quads stay active
+  JacT acc = jact_from_jac(raw_load(&win[inst * W + W - 1]));
+#pragma unroll 1
   for (int w = W - 2; w >= 0; w--) {
-    for (int d = 0; d < c; d++) acc = jac_dbl(acc);
-    acc = jac_add(acc, raw_load(&win[inst * W + w]));
+#pragma unroll 1
+    for (int d = 0; d < c; d++) acc = q4_dbl(acc, role);
+    acc = q4_add(acc, jact_from_jac(raw_load(&win[inst * W + w])), role);
   }
-  raw_store(&out[inst * out_stride], acc);
+  if (live && role == 0) raw_store(&out[inst * out_stride], jact_to_jac(acc));
 }
 
 // window choice: minimise  n * W (bucket adds) + W * 2^(c-1) * ~3 (running sums), c in [8, 16]
@@ -409,7 +418,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   } else {
     hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, 1), dim3(PW_TPB), 0, st, pp, buckets, win, 1);
   }
-  hipLaunchKernelGGL(k_pip_final, dim3((ninst + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
+  hipLaunchKernelGGL(k_pip_final, dim3((ninst * 4 + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
 }
 void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
   pippenger_batch(st, pts, scalars, 1, n, c, out, 1, scratch);

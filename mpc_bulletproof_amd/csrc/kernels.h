@@ -81,12 +81,27 @@ void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c);
 void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t ninst, size_t n, int c, JacRaw *out,
                      size_t out_stride, void *scratch);
+// ---- k_pip2.hip: ONE mid-size instance in six launches (+ a front launch from boundary bytes); 2^8 <= n <= 2^18
+int pippenger2_window(size_t n);
+bool pippenger2_supported(size_t n);
+size_t pippenger2_scratch_bytes(size_t n, int c);
+void pippenger2(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch, int *bad);
+void pippenger2_boundary(hipStream_t st, const Words8 *points_xy, const Words8 *scalars, size_t n, int c, Words8 *out_xy,
+                         AffDev *pts_tmp, void *scratch, int *bad);
 // gather helper: dst[i] = src[idx(i)] for two-level strided sources (IPP round operands -> contiguous MSM inputs)
 void gather_points(hipStream_t st, const AffDev *src, size_t src_outer, size_t cnt, size_t nb, AffDev *dst, size_t dst_outer);
 void gather_scalars(hipStream_t st, const Words8 *src, size_t src_outer, size_t cnt, size_t nb, Words8 *dst, size_t dst_outer);
 
 // out[b] = sum_{i<n} in[b*n + i]
 void segmented_sum(hipStream_t st, const JacRaw *in, JacRaw *out, size_t nb, size_t n);
+
+// ---- arkworks in-memory forms (k_ark.hip): Scalar = 4 x u64 limbs of x 2^256 mod n; StarkPoint = Jacobian (X : Y : Z), each
+// coordinate 4 x u64 limbs of c 2^256 mod p, identity Z = 0
+void scalars_from_ark(hipStream_t st, const Words8 *in, Words8 *out_plain, size_t n, int *bad);
+void scalars_to_ark(hipStream_t st, const Words8 *in_plain, Words8 *out, size_t n, int *bad);
+void points_from_ark(hipStream_t st, const Words8 *in /* 3 per point */, JacRaw *out, size_t n, int *bad);
+void points_to_ark(hipStream_t st, const JacRaw *in, Words8 *out /* 3 per point */, size_t n);
+void aff_to_jacraw(hipStream_t st, const AffDev *in, JacRaw *out, size_t n);
 
 // ---- fixed-base tables -------------------------------------------------------------------------
 // table[(g*W + w) * 2^(c-1) + (d-1)] = d * 2^(c*w) * P_g,  W = 252/c + 1
@@ -192,6 +207,28 @@ void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, co
 // where the inversion pass writes (inside zpow_scratch) and its per-proof stride in field elements; false = the large-proof
 // path, which runs its own inversion pass
 bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_scratch, int32_t **aux, size_t *aux_stride);
+
+// ---- combined batch check in eight launches (k_pip2.hip): sum_p rho_p * mega_check_p as ONE boundary point
+// optional stage markers for per-kernel event timing: fn(ctx, kind, stream) is called before and after a stage
+typedef void (*ProfMarkFn)(void *ctx, int kind, hipStream_t st);
+struct ProfMark {
+  ProfMarkFn fn; void *ctx; int kind; hipStream_t st;
+  ProfMark(ProfMarkFn f, void *c, int k, hipStream_t s) : fn(f), ctx(c), kind(k), st(s) { if (fn) fn(ctx, kind, st); }
+  ~ProfMark() { if (fn) fn(ctx, kind, st); }
+};
+struct CombinedArgs {
+  CircuitDev circ; VerifyDims d; size_t nvar;
+  const Words8 *points, *proof_scalars, *challenges, *rho;     // ABI bytes in HBM
+  Words8 *fixed_sc, *var_sc;                                   // nb x (2 + 2 padded_n), nb x nvar (written here)
+  int32_t *zpow_scratch;                                       // verify_scalars_scratch_ints
+  const AffDev *table; size_t cap; int c;                      // resident generator tables
+  void *scratch;                                               // verify_combined2_scratch_bytes
+  int *bad; Words8 *partial_xy;                                // out: 64 boundary bytes
+  ProfMarkFn prof; void *prof_ctx;
+};
+size_t verify_combined2_scratch_bytes(size_t nb, size_t nvar, size_t nfix);
+bool verify_combined2_supported(size_t nb, size_t nvar, int c, size_t padded_n);
+void verify_combined2(hipStream_t st, const CombinedArgs &a);
 
 // one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);

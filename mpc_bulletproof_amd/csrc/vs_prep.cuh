@@ -12,11 +12,12 @@ namespace bpk {
 constexpr int VS_AUX = 66;
 struct VsPrepArgs { VerifyDims d; const Words8 *challenges; int32_t *aux_all; size_t aux_stride; };
 
-__device__ __forceinline__ void vs_prep_body(const VsPrepArgs &a, size_t blk) {
+// proof p (one lane)
+__device__ __forceinline__ void vs_prep_lane(const VsPrepArgs &a, size_t p) {
   // a short, serial link of every batch's dependency chain that shares the chip with the bulk MSM waves of the other
   // in-flight batches: raise its waves' issue priority
   __builtin_amdgcn_s_setprio(3);
-  const size_t p = blk * 64 + threadIdx.x, k = a.d.k;
+  const size_t k = a.d.k;
   if (p >= a.d.nb) return;
   const Words8 *ch = a.challenges + p * (6 + k);
   int32_t *aux = a.aux_all + p * a.aux_stride * NL;
@@ -42,5 +43,6 @@ __device__ __forceinline__ void vs_prep_body(const VsPrepArgs &a, size_t blk) {
   raw_put(aux, ai);   // after the loop ai = val_0^-1 = y^-1
   raw_put(aux + NL, allinv);
 }
+__device__ __forceinline__ void vs_prep_body(const VsPrepArgs &a, size_t blk) { vs_prep_lane(a, blk * 64 + threadIdx.x); }   // 64-thread blocks
 
 }  // namespace bpk

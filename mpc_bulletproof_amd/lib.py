@@ -8,7 +8,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
     "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
-    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
+    "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
@@ -60,8 +60,8 @@ def host_free(p):
 E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
 # bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
 PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
-              "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_scalars",
-              "combined_var_msm", "combined_fixed_msm", "combined_tail"]
+              "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_front_scalars_digits",
+              "combined_sort_accum_reduce", "combined_unused", "combined_final"]
 PROF_KINDS = len(PROF_NAMES)
 
 
@@ -160,6 +160,33 @@ class BpGpu:
 
     def msm_batch_dev(self, nb, n, d_scalars, d_points, d_out):
         self._ck(_lib.bpgpu_msm_batch_dev(self.ctx, C.c_size_t(nb), C.c_size_t(n), d_scalars, d_points, d_out))
+
+    # ---- arkworks in-memory forms (include/bpgpu.h): scalars 32 B = x 2^256 mod n, points 96 B = Jacobian coords c 2^256 mod p
+    def msm_ark(self, scalars_mont, points_jac_mont):
+        n = len(scalars_mont) // 32
+        if len(points_jac_mont) != 96 * n:
+            raise BpGpuError(E_LEN, "msm_ark: length mismatch")
+        o = _out(96)
+        self._ck(_lib.bpgpu_msm_ark(self.ctx, _buf(scalars_mont), _buf(points_jac_mont), C.c_size_t(n), o))
+        return bytes(o)
+
+    def _ark(self, fn, data, isz, osz):
+        n = len(data) // isz
+        o = _out(osz * n)
+        self._ck(fn(self.ctx, _buf(data), C.c_size_t(n), o))
+        return bytes(o)[:osz * n]
+
+    def scalars_from_ark(self, b):
+        return self._ark(_lib.bpgpu_scalars_from_ark, b, 32, 32)
+
+    def scalars_to_ark(self, b):
+        return self._ark(_lib.bpgpu_scalars_to_ark, b, 32, 32)
+
+    def points_from_ark(self, b):
+        return self._ark(_lib.bpgpu_points_from_ark, b, 96, 64)
+
+    def points_to_ark(self, b):
+        return self._ark(_lib.bpgpu_points_to_ark, b, 64, 96)
 
     def points_sum(self, points):
         """sum of the 64-byte points in `points` (no scalars) -> 64 bytes"""
@@ -327,6 +354,25 @@ class BpGpu:
             return bytes(b)[:32 * nb * k]
 
         return cut(wL, n_mul), cut(wR, n_mul), cut(wO, n_mul), cut(wV, m), bytes(wc)[:32 * nb]
+
+    def r1cs_prover_polys(self, circuit, nb, n, m, y, y_inv, z, a_L, a_R, a_O, s_L, s_R):
+        """prover.rs:587-619 for nb provers of one circuit -> (t_coeffs nb x 6 x 32 B, wV nb x m x 32 B, prover handle)"""
+        for v in (a_L, a_R, a_O, s_L, s_R):
+            if len(v) != 32 * nb * n:
+                raise BpGpuError(E_LEN, "r1cs_prover_polys: length mismatch")
+        t, wv, h = _out(32 * 6 * nb), _out(32 * nb * max(m, 1)), C.c_void_p()
+        self._ck(_lib.bpgpu_r1cs_prover_polys(self.ctx, circuit, C.c_size_t(nb), _buf(y), _buf(y_inv), _buf(z), _buf(a_L), _buf(a_R),
+                                              _buf(a_O), _buf(s_L), _buf(s_R), t, wv, C.byref(h)))
+        return bytes(t)[:32 * 6 * nb], bytes(wv)[:32 * nb * m], h
+
+    def r1cs_prover_eval(self, prover, nb, padded_n, x):
+        """prover.rs:659-672: l_vec, r_vec (nb x padded_n) = l(x), r(x) with the zero / -y^i padding"""
+        lv, rv = _out(32 * nb * padded_n), _out(32 * nb * padded_n)
+        self._ck(_lib.bpgpu_r1cs_prover_eval(self.ctx, prover, C.c_size_t(padded_n), _buf(x), lv, rv))
+        return bytes(lv)[:32 * nb * padded_n], bytes(rv)[:32 * nb * padded_n]
+
+    def prover_destroy(self, prover):
+        _lib.bpgpu_prover_destroy(self.ctx, prover)
 
     def r1cs_verify_batch(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, want_mega=True,
                           want_scalars=False):

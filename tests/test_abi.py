@@ -57,3 +57,28 @@ def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
                 offenders.append(node.name)
     assert offenders == [], offenders
     assert "import oracle_lib" not in src.split("def _cpu_verify_chunk")[0]
+
+
+def test_rust_sys_block_is_complete_and_in_step_with_the_header():
+    """shim/src/sys.rs (the `extern "C"` block a Rust host links against; generated, uncompiled here) declares every
+    function of include/bpgpu.h with the same parameter count, and is what tools/gen_rust_sys.py produces today."""
+    import subprocess
+    import sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py"), "--check"]) == 0, \
+        "shim/src/sys.rs is stale: run tools/gen_rust_sys.py"
+    rs = open(os.path.join(ROOT, "shim", "src", "sys.rs")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", open(os.path.join(ROOT, "include", "bpgpu.h")).read(), flags=re.S)
+    for name in _declared():
+        m = re.search(r"pub fn %s\((.*?)\)( -> [^;]+)?;" % name, rs)
+        assert m, name
+        c = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, flags=re.S)
+        nc = 0 if c.group(1).strip() in ("", "void") else c.group(1).count(",") + 1
+        nr = 0 if not m.group(1).strip() else m.group(1).count(",") + 1
+        assert nc == nr, (name, nc, nr)
+
+
+def test_host_harness_lives_under_tests():
+    """the reference's gadgets / tests restated and the flat C harness are test infrastructure (tests/host/), not product"""
+    host = os.path.join(ROOT, "mpc_bulletproof_amd", "host")
+    assert sorted(f for f in os.listdir(host) if f.endswith((".cpp", ".hpp"))) == ["mpc_bulletproof.cpp", "mpc_bulletproof.hpp"]
+    assert os.path.exists(os.path.join(ROOT, "tests", "host", "capi.cpp"))

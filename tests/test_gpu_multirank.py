@@ -71,3 +71,61 @@ def gpu_ctx():
     g = m.BpGpu(0)
     yield g
     g.close()
+
+
+# ------------------------------------------------------------------ arkworks in-memory forms (zero-copy hand-over)
+def _ark_scalar(x):
+    return (x * (1 << 256) % o.N).to_bytes(32, "little")
+
+
+def _ark_point(xy, z):
+    """affine boundary bytes -> ark Projective bytes (Jacobian, Montgomery R = 2^256) with the given Z"""
+    P = o.P
+    R = 1 << 256
+    if xy == bytes(64):
+        return (R % P).to_bytes(32, "little") * 2 + bytes(32)          # Projective::zero() = (1 : 1 : 0)
+    x, y = int.from_bytes(xy[:32], "little"), int.from_bytes(xy[32:], "little")
+    X, Y = x * z * z % P, y * z * z * z % P
+    return b"".join((c * R % P).to_bytes(32, "little") for c in (X, Y, z))
+
+
+def _ark_point_affine(b):
+    P = o.P
+    Ri = pow(1 << 256, -1, P)
+    X, Y, Z = (int.from_bytes(b[32 * i:32 * i + 32], "little") * Ri % P for i in range(3))
+    if Z == 0:
+        return bytes(64)
+    zi = pow(Z, -1, P)
+    return (X * zi * zi % P).to_bytes(32, "little") + (Y * zi * zi * zi % P).to_bytes(32, "little")
+
+
+@pytest.mark.parametrize("n", [0, 1, 40, 600, 3000])
+def test_msm_and_conversions_in_arkworks_memory_form(gpu_ctx, n):
+    """bpgpu_msm_ark takes Scalars as ark-ff Montgomery limbs (x 2^256 mod n) and StarkPoints as ark-ec Jacobian coordinates in
+    Montgomery form (random Z per point, one identity) and returns the sum in the same form: equal, as a point, to the oracle's MSM of the
+    canonical encodings.  The vector conversions round-trip with the boundary encodings."""
+    import random
+    rnd = random.Random(60 + n)
+    sc = o.random_scalars(900 + n, n)
+    pts = ((o.gens("G", 512) + o.gens("H", 512)) * 3)[:64 * n]
+    if n >= 40:
+        pts = pts[:64 * 7] + bytes(64) + pts[64 * 8:]                 # an identity operand
+    xs = [int.from_bytes(sc[32 * i:32 * i + 32], "little") for i in range(n)]
+    ark_sc = b"".join(_ark_scalar(x) for x in xs)
+    ark_pts = b"".join(_ark_point(pts[64 * i:64 * i + 64], rnd.randrange(1, o.P) if i % 3 else 1) for i in range(n))
+    got = gpu_ctx.msm_ark(ark_sc, ark_pts)
+    assert _ark_point_affine(got) == (o.msm(sc, pts) if n else bytes(64))
+    if n:
+        assert gpu_ctx.scalars_from_ark(ark_sc) == sc and gpu_ctx.scalars_to_ark(sc) == ark_sc
+        assert gpu_ctx.points_from_ark(ark_pts) == pts
+        back = gpu_ctx.points_to_ark(pts)
+        assert all(_ark_point_affine(back[96 * i:96 * i + 96]) == pts[64 * i:64 * i + 64] for i in range(n))
+        assert gpu_ctx.points_to_ark(pts[:64]) == _ark_point(pts[:64], 1)         # Z = 1 out, byte for byte
+    import mpc_bulletproof_amd as m
+    if n == 40:
+        bad = bytearray(ark_pts)
+        bad[96 * 5 + 3] ^= 1                                                  # off the curve
+        with pytest.raises(m.BpGpuError):
+            gpu_ctx.msm_ark(ark_sc, bytes(bad))
+        with pytest.raises(m.BpGpuError):
+            gpu_ctx.scalars_from_ark(o.N.to_bytes(32, "little"))              # limbs >= modulus

@@ -429,6 +429,62 @@ def test_verify_batch_generators_too_short(gpu):
         gpu.circuit_destroy(circ)
 
 
+# ------------------------------------------------------------------ prover polynomials
+@pytest.mark.parametrize("kind,param,nb", [(0, 8, 3), (0, 64, 2), (1, 5, 2)])
+def test_prover_polys_and_eval_unit_parity(gpu, kind, param, nb):
+    """bpgpu_r1cs_prover_polys / _eval against r1cs/prover.rs:587-619, 659-672 and util.rs:152-181 restated literally on
+    Python integers: t_1..t_6 (special_inner_product), wV, and l_vec / r_vec with the zero / -y^i padding -- directly,
+    not through whole-proof bytes.  Circuits: the 8- and 64-bit range gadget (n = 8, 64: padded = n) and a 5-shuffle
+    (n = 8 multipliers of a 2-phase circuit).  The weights come from the oracle's flattened_constraints."""
+    okind = [o.K_RANGE, o.K_SHUFFLE][kind]
+    label = [b"RangeProofTest", b"ShuffleProofTest"][kind]
+    import random
+    rnd = random.Random(77 + param)
+    vals = [rnd.getrandbits(param)] if kind == 0 else (lambda x: x + sorted(x))([rnd.getrandbits(32) for _ in range(param)])
+    cap = 64
+    rc, proof, com = o.r1cs_prove(okind, param, label, vals, 5, cap)
+    assert rc == 0
+    s = o.VerifySession(okind, param, label, [], com, proof, cap)
+    n, m = s.n1 + s.n2, s.m
+    padded = 1 << max(0, (n - 1).bit_length())
+    rp, kd, idx, coeff = s.csr()
+    circ = gpu.circuit_create(rp, kd, idx, coeff, n, m)
+    N_ = o.N
+    I = lambda b, i: int.from_bytes(b[32 * i:32 * i + 32], "little")      # noqa: E731
+    try:
+        ys = [rnd.randrange(1, N_) for _ in range(nb)]
+        zs = [rnd.randrange(1, N_) for _ in range(nb)]
+        xs = [rnd.randrange(1, N_) for _ in range(nb)]
+        wit = {k_: [[rnd.randrange(N_) if k_ in ("sL", "sR") or rnd.random() < 0.5 else rnd.randrange(2) for _ in range(n)]
+                    for _ in range(nb)] for k_ in ("aL", "aR", "aO", "sL", "sR")}
+        pk = lambda rows: b"".join(o.s2b(v) for r in rows for v in r)       # noqa: E731
+        t, wv, h = gpu.r1cs_prover_polys(circ, nb, n, m, pk([ys]), pk([[pow(y, -1, N_) for y in ys]]), pk([zs]),
+                                         pk(wit["aL"]), pk(wit["aR"]), pk(wit["aO"]), pk(wit["sL"]), pk(wit["sR"]))
+        lv, rv = gpu.r1cs_prover_eval(h, nb, padded, pk([xs]))
+        gpu.prover_destroy(h)
+        for p in range(nb):
+            y, z, x = ys[p], zs[p], xs[p]
+            wL, wR, wO, wV, _ = s.flatten(o.s2b(z))
+            yi = pow(y, -1, N_)
+            l1 = [(wit["aL"][p][i] + pow(yi, i, N_) * I(wR, i)) % N_ for i in range(n)]
+            l2, l3 = wit["aO"][p], wit["sL"][p]
+            r0 = [(I(wO, i) - pow(y, i, N_)) % N_ for i in range(n)]
+            r1 = [(pow(y, i, N_) * wit["aR"][p][i] + I(wL, i)) % N_ for i in range(n)]
+            r3 = [pow(y, i, N_) * wit["sR"][p][i] % N_ for i in range(n)]
+            ip = lambda a, b: sum(u * v for u, v in zip(a, b)) % N_       # noqa: E731
+            want_t = [ip(l1, r0), (ip(l1, r1) + ip(l2, r0)) % N_, (ip(l2, r1) + ip(l3, r0)) % N_, (ip(l1, r3) + ip(l3, r1)) % N_,
+                      ip(l2, r3), ip(l3, r3)]
+            assert [I(t, 6 * p + j) for j in range(6)] == want_t, p
+            assert wv[32 * m * p:32 * m * (p + 1)] == wV, p
+            want_l = [(x * (l1[i] + x * (l2[i] + x * l3[i]))) % N_ for i in range(n)] + [0] * (padded - n)
+            want_r = [(r0[i] + x * (r1[i] + x * (x * r3[i]))) % N_ for i in range(n)] + [(-pow(y, i, N_)) % N_ for i in range(n, padded)]
+            assert [I(lv, padded * p + i) for i in range(padded)] == want_l, p
+            assert [I(rv, padded * p + i) for i in range(padded)] == want_r, p
+    finally:
+        gpu.circuit_destroy(circ)
+        s.close()
+
+
 # ------------------------------------------------------------------ IPP prover (lock-step session)
 def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b, gens=None, w=None):
     """Drive InnerProductProof::create (inner_product_proof.rs:49-193) with the transcript on the host
