@@ -198,6 +198,11 @@ size_t bpgpu_ipp_len(const bpgpu_ipp *s);
 int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R);
 int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t *u_inv);
 int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_out);
+/* Resident-generator sessions only, after the last fold (bpgpu_ipp_len == 1): the folded generators as points,
+ * G' = sum_i cG[i] G_i and H' = sum_i cH[i] H_i (nb x 64 B each) -- the pair the final (a, b) refers to.  A rank of a
+ * vector-sharded IPP (one proof's a, b, G, H dealt cyclically over the GPUs of a node: SURVEY 8e.2,
+ * mpc_bulletproof_amd/sharding.py sharded_ipp_create) hands (a, b, G', H') to the last log2(ranks) rounds. */
+int bpgpu_ipp_folded_gens(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *G_out, uint8_t *H_out);
 
 /* ---- R1CS ------------------------------------------------------------------------------------
  * Constraint rows as the reference holds them (Vec<LinearCombination>, r1cs/prover.rs:31,
@@ -212,6 +217,16 @@ void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c);
 int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z,
                               uint8_t *wL, uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc);
 
+/* Circuits with RANDOMIZED (second-phase) constraints whose coefficients are affine in the gadget's challenge
+ * (RandomizableConstraintSystem::specify_randomized_constraints + cs.challenge_scalar(label) -- r1cs/verifier.rs:366-385,
+ * r1cs/prover.rs:383-402; the shuffle gadget (x_i - z), tests/r1cs.rs:23-62): coefficient of a term = c0 + sum_j chi_j * c_j.
+ * The CSR has (1 + nchi) * q rows: rows [0, q) hold the constant parts c0, rows [j q, (j + 1) q) the chi_j parts (row r of block j
+ * belongs to constraint r).  One such circuit serves every proof of the gadget, whatever challenge its transcript produced.
+ * Use it with bpgpu_r1cs_verify_batch_param (gadget challenges from the host) or bpgpu_r1cs_verify_batch_fs2 (transcript on the
+ * device); the other entry points reject it (BPGPU_E_ARG).  nchi <= 8 (the device transcript supports nchi <= 1). */
+int bpgpu_circuit_create_param(bpgpu_ctx *ctx, size_t q, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
+                               const uint32_t *idx, const uint8_t *coeff, size_t n_multipliers, size_t m_commitments,
+                               bpgpu_circuit **out);
 /* Prover::prove arithmetic between the y,z and the u,x challenges -- r1cs/prover.rs:587-619:
  * flattened_constraints(z), exp_y / exp_y_inv, the l(x)/r(x) coefficient vectors and
  * t_1..t_6 = VecPoly3::special_inner_product (util.rs:152-170), for nb provers of ONE circuit.
@@ -296,6 +311,22 @@ int bpgpu_r1cs_verify_batch_wire_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const 
                                      size_t proof_len, const void *proofs_dev, const void *commitments_dev,
                                      const void *init_states_dev, void *ok_dev);
 
+/* Verifier::verify for nb proofs of ONE two-phase circuit (bpgpu_circuit_create_param).  _param: as bpgpu_r1cs_verify_batch with the
+ * gadget challenges (nb x nchi x 32 B, in the order the gadget drew them) beside the usual 6 + k challenges.  _fs2: as
+ * bpgpu_r1cs_verify_batch_fs -- the whole transcript replay on the device, including the phase separator and the gadget's
+ * challenge_scalar(gadget_label) (label zero-padded to 32 bytes; verifier.rs:373-383), whose value selects the constraint weights;
+ * gadget_challenges_out (optional) returns it.  Same per-proof rejection rules as the one-phase entry points. */
+int bpgpu_r1cs_verify_batch_param(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                  size_t k, const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges,
+                                  const uint8_t *gadget_challenges, int32_t *ok, uint8_t *mega, uint8_t *msm_scalars);
+int bpgpu_r1cs_verify_batch_fs2(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                const uint8_t *init_states, const uint8_t gadget_label[32], const uint8_t *points,
+                                const uint8_t *scalars, int32_t *ok, uint8_t *mega, uint8_t *challenges_out,
+                                uint8_t *gadget_challenges_out);
+int bpgpu_r1cs_verify_batch_fs2_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                    const void *init_states_dev, const uint8_t gadget_label[32], const void *points_dev,
+                                    const void *scalars_dev, void *ok_dev, void *mega_dev, void *challenges_out_dev,
+                                    void *gadget_challenges_out_dev);
 /* Combined batch check (NOT a reference API -- the reference verifies proof by proof; this is
  * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random
  * weights rho (nb x 32 B, e.g. from a CSPRNG) computes  sum_p rho_p * mega_check_p  as ONE point:

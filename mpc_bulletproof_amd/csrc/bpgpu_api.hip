@@ -78,7 +78,7 @@ struct bpgpu_ipp {
   Words8 *cG = nullptr, *cH = nullptr, *w = nullptr;               //   coefficient vectors nb x n0 and Q = w * B
 };
 struct bpgpu_circuit {
-  size_t q = 0, n = 0, m = 0, nnz = 0;
+  size_t q = 0, n = 0, m = 0, nnz = 0, nchi = 0;   // nchi: gadget challenges the coefficients are affine in (kernels.h CircuitDev)
   uint32_t *col_ptr = nullptr, *row = nullptr;
   Words8 *coeff = nullptr;
 };
@@ -828,10 +828,11 @@ int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t
 }
 
 /* ---------------------------------------------------------------- R1CS */
-int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
-                         const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
+static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
+                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
   if (!ctx || !out || !row_ptr) return BPGPU_E_ARG;
   *out = nullptr;
+  const size_t q = q_real * (1 + nchi);     // CSR rows: block j (rows j q_real ..) holds the chi_j parts of the coefficients
   size_t nnz = row_ptr[q];
   if (nnz && (!kind || !idx || !coeff)) return BPGPU_E_ARG;
   // CSR (row-major, as the reference holds constraints) -> column-major by output variable
@@ -868,7 +869,7 @@ int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, cons
   HIPCK(ctx, hipSetDevice(ctx->device));
   bpgpu_circuit *c = new (std::nothrow) bpgpu_circuit();
   if (!c) return BPGPU_E_OOM;
-  c->q = q; c->n = n_mul; c->m = m; c->nnz = nnz;
+  c->q = q_real; c->n = n_mul; c->m = m; c->nnz = nnz; c->nchi = nchi;
   auto fail = [&](int rc) { hipFree(c->col_ptr); hipFree(c->row); hipFree(c->coeff); delete c; return rc; };
   if (hipMalloc((void **)&c->col_ptr, (nout + 1) * 4) != hipSuccess || hipMalloc((void **)&c->row, (nnz ? nnz : 1) * 4) != hipSuccess ||
       hipMalloc((void **)&c->coeff, (nnz ? nnz : 1) * 32) != hipSuccess)
@@ -887,6 +888,15 @@ int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, cons
   *out = c;
   return BPGPU_OK;
 }
+int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
+                         const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
+  return circuit_create_impl(ctx, q, 0, row_ptr, kind, idx, coeff, n_mul, m, out);
+}
+int bpgpu_circuit_create_param(bpgpu_ctx *ctx, size_t q, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
+                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
+  if (nchi > 8) return BPGPU_E_LEN;
+  return circuit_create_impl(ctx, q, nchi, row_ptr, kind, idx, coeff, n_mul, m, out);
+}
 void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c) {
   if (!c) return;
   if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
@@ -899,11 +909,13 @@ static CircuitDev circuit_dev(const bpgpu_circuit *c) {
   CircuitDev d;
   d.col_ptr = c->col_ptr; d.row = c->row; d.coeff = c->coeff;
   d.q = c->q; d.n = c->n; d.m = c->m; d.nnz = c->nnz;
+  d.nchi = c->nchi; d.qz = c->q * (1 + c->nchi);
   return d;
 }
 int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z, uint8_t *wL,
                               uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc) {
   if (!ctx || !c || (nb && (!z || (c->n && (!wL || !wR || !wO)) || (c->m && !wV)))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;     // parametric circuits are flattened inside the verification entry points (they need chi)
   if (!nb) return BPGPU_OK;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -933,8 +945,9 @@ int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb,
 
 static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
                                    size_t k, const void *points, const void *scalars, const void *challenges,
-                                   void *ok, void *mega, void *full_sc) {
+                                   void *ok, void *mega, void *full_sc, const void *chi = nullptr) {
   if (k >= 32) return BPGPU_E_LEN;
+  if ((c->nchi != 0) != (chi != nullptr)) return BPGPU_E_ARG;   // a parametric circuit needs its gadget challenges, and only it
   size_t np = (size_t)1 << k, n = c->n, m = c->m;
   if (n > np || n1 > n || (np > 1 && n <= np / 2 && n != 0)) return BPGPU_E_LEN;   // padded_n = next_pow2(n)
   if (np > g->cap) return BPGPU_E_GENS;
@@ -945,12 +958,12 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   CK(ws_get(ctx, 7, nb * nvar * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, nb * nvar * 32, &dvar));
-  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m}) * 4, &dzp));
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m, (const Words8 *)chi}) * 4, &dzp));
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
   CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
   void *dstr;
   CK(straus_ws(ctx, 4, nb * nvar, &dstr));
-  VerifyDims d{nb, n1, n, np, k, m};
+  VerifyDims d{nb, n1, n, np, k, m, (const Words8 *)chi};
   // per-proof canonicity bits of the scalar assembly (every entry is written by the kernel: no reset)
   void *dbadsc;
   CK(ws_get(ctx, 20, 2 * nb * sizeof(int32_t), &dbadsc));
@@ -1090,29 +1103,31 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
 /* ---------------------------------------------------------------- Verifier::verify with the transcript on the device */
 static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                             const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
-                            void *challenges_out) {
+                            void *challenges_out, const uint8_t *gadget_label = nullptr, void *chi_out = nullptr) {
   if (k >= 32) return BPGPU_E_LEN;
+  if (c->nchi > 1 || (c->nchi == 1 && !gadget_label)) return BPGPU_E_ARG;   // one gadget challenge label per schedule
   if (!nb) return BPGPU_OK;
   HIPCK(ctx, hipSetDevice(ctx->device));
-  const size_t m = c->m, np = (size_t)1 << k;
-  void *dsteps, *dch, *dbad;
+  const size_t m = c->m, np = (size_t)1 << k, nchi = c->nchi;
+  void *dsteps, *dch, *dbad, *dchi = nullptr;
+  if (nchi) { if (chi_out) dchi = chi_out; else CK(ws_get(ctx, 21, nb * nchi * 32, &dchi)); }
   CK(ws_get(ctx, 19, transcript_schedule_max(m, k) * sizeof(TrStep) + 64, &dsteps));
   CK(ws_get(ctx, 17, nb * (6 + k) * 32, &dch));
   CK(ws_get(ctx, 18, nb * 4, &dbad));
-  if (ctx->sched_key[0] != m || ctx->sched_key[1] != k || ctx->sched_key[2] != np) {
+  if (ctx->sched_key[0] != m || ctx->sched_key[1] != k || ctx->sched_key[2] != np + (nchi << 40)) {
     std::vector<TrStep> steps(transcript_schedule_max(m, k));
-    ctx->sched_len = transcript_schedule(steps.data(), m, k, np);
+    ctx->sched_len = transcript_schedule(steps.data(), m, k, np, nchi);
     HIPCK(ctx, hipMemcpyAsync(dsteps, steps.data(), ctx->sched_len * sizeof(TrStep), hipMemcpyHostToDevice, ctx->st));
     HIPCK(ctx, hipStreamSynchronize(ctx->st));   // `steps` is a local
-    ctx->sched_key[0] = m; ctx->sched_key[1] = k; ctx->sched_key[2] = np;
+    ctx->sched_key[0] = m; ctx->sched_key[1] = k; ctx->sched_key[2] = np + (nchi << 40);
   }
   Words8 *chp = challenges_out ? (Words8 *)challenges_out : (Words8 *)dch;
   {
     ProfScope ps(ctx, 5, ctx->st);
     verify_transcript(ctx->st, nb, m, k, (const TrStep *)dsteps, ctx->sched_len, (const Words8 *)init_states,
-                      (const Words8 *)points, (const Words8 *)scalars, chp, (int32_t *)dbad);
+                      (const Words8 *)points, (const Words8 *)scalars, chp, (int32_t *)dbad, gadget_label, (Words8 *)dchi, nchi);
   }
-  CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, chp, ok, mega, nullptr));
+  CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, chp, ok, mega, nullptr, dchi));
   and_not(ctx->st, (int32_t *)ok, (const int32_t *)dbad, nb);
   return launch_ok(ctx);
 }
@@ -1146,6 +1161,72 @@ int bpgpu_r1cs_verify_batch_fs(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
   CK(d2h(ctx, ok, dok, nb * 4));
   if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
   if (challenges_out) CK(d2h(ctx, challenges_out, dcho, nb * (6 + k) * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* two-phase circuits (parametric constraint weights): host challenges + gadget challenges, or the transcript on the device */
+int bpgpu_r1cs_verify_batch_param(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
+                                  size_t k, const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges,
+                                  const uint8_t *gadget_challenges, int32_t *ok, uint8_t *mega, uint8_t *msm_scalars) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok)) || (c && c->nchi && !gadget_challenges)) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t np = (size_t)1 << k, m = c->m, nvar = 11 + m + 2 * k, nterms = 13 + m + 2 * np + 2 * k;
+  void *dP, *dS, *dC, *dok, *dmega, *dfull = nullptr, *dchi = nullptr;
+  CK(ws_get(ctx, 0, nb * nvar * 64, &dP));
+  CK(ws_get(ctx, 1, nb * 5 * 32, &dS));
+  CK(ws_get(ctx, 2, nb * (6 + k) * 32, &dC));
+  CK(ws_get(ctx, 3, nb * 4, &dok));
+  CK(ws_get(ctx, 4, nb * 64, &dmega));
+  if (msm_scalars) CK(ws_get(ctx, 5, nb * nterms * 32, &dfull));
+  if (c->nchi) { CK(ws_get(ctx, 21, nb * c->nchi * 32, &dchi)); CK(h2d(ctx, dchi, gadget_challenges, nb * c->nchi * 32)); }
+  CK(h2d(ctx, dP, points, nb * nvar * 64));
+  CK(h2d(ctx, dS, scalars, nb * 5 * 32));
+  CK(h2d(ctx, dC, challenges, nb * (6 + k) * 32));
+  if (dchi) scalars_check(ctx->st, (const Words8 *)dchi, nb * c->nchi, ctx->d_flag);
+  CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, dP, dS, dC, dok, mega ? dmega : nullptr, dfull, dchi));
+  CK(d2h(ctx, ok, dok, nb * 4));
+  if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
+  if (msm_scalars) CK(d2h(ctx, msm_scalars, dfull, nb * nterms * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+int bpgpu_r1cs_verify_batch_fs2_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                    const void *init_states, const uint8_t gadget_label[32], const void *points, const void *scalars,
+                                    void *ok, void *mega, void *challenges_out, void *gadget_challenges_out) {
+  if (!ctx || !g || !c || (nb && (!init_states || !points || !scalars || !ok))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_fs_locked(ctx, g, c, nb, n1, k, init_states, points, scalars, ok, mega, challenges_out, gadget_label, gadget_challenges_out);
+}
+int bpgpu_r1cs_verify_batch_fs2(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                const uint8_t *init_states, const uint8_t gadget_label[32], const uint8_t *points,
+                                const uint8_t *scalars, int32_t *ok, uint8_t *mega, uint8_t *challenges_out,
+                                uint8_t *gadget_challenges_out) {
+  if (!ctx || !g || !c || (nb && (!init_states || !points || !scalars || !ok))) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  size_t m = c->m, nvar = 11 + m + 2 * k;
+  void *dP, *dS, *dI, *dok, *dmega, *dcho, *dchi;
+  CK(ws_get(ctx, 0, nb * nvar * 64, &dP));
+  CK(ws_get(ctx, 1, nb * 5 * 32, &dS));
+  CK(ws_get(ctx, 2, nb * 32, &dI));
+  CK(ws_get(ctx, 3, nb * 4 + nb * 64, &dok));
+  dmega = (uint8_t *)dok + ((nb * 4 + 63) / 64) * 64;
+  CK(ws_get(ctx, 16, nb * (6 + k) * 32, &dcho));
+  CK(ws_get(ctx, 22, nb * (c->nchi ? c->nchi : 1) * 32, &dchi));
+  CK(h2d(ctx, dP, points, nb * nvar * 64));
+  CK(h2d(ctx, dS, scalars, nb * 5 * 32));
+  CK(h2d(ctx, dI, init_states, nb * 32));
+  CK(verify_fs_locked(ctx, g, c, nb, n1, k, dI, dP, dS, dok, mega ? dmega : nullptr, dcho, gadget_label, c->nchi ? dchi : nullptr));
+  CK(d2h(ctx, ok, dok, nb * 4));
+  if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
+  if (challenges_out) CK(d2h(ctx, challenges_out, dcho, nb * (6 + k) * 32));
+  if (gadget_challenges_out && c->nchi) CK(d2h(ctx, gadget_challenges_out, dchi, nb * c->nchi * 32));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
 }
@@ -1238,12 +1319,13 @@ static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(ws_get(ctx, 7, tot * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, tot * 32, &dvar));
-  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m}) * 4, &dzp));
+  if (c->nchi) return BPGPU_E_ARG;
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m, nullptr}) * 4, &dzp));
   CK(ws_get(ctx, 10, nfix * 32, &dfsum));
   CK(ws_get(ctx, 11, 2 * sizeof(JacRaw), &dtwo));
   CK(ws_get(ctx, 15, sizeof(JacRaw), &dsum));
   CK(ws_get(ctx, 14, pippenger_scratch_bytes(tot, cw), &dpip));
-  VerifyDims d{nb, n1, n, np, k, m};
+  VerifyDims d{nb, n1, n, np, k, m, nullptr};
   CK(flag_reset(ctx));
   if (verify_combined2_supported(nb, nvar, g->c, np)) {   // eight launches on one stream (k_pip2.hip)
     void *dc2;
@@ -1595,6 +1677,28 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
   return BPGPU_OK;
 }
 /* final a, b -- inner_product_proof.rs:187-192 */
+// The generators a resident-generator session has folded SO FAR, as points: G'_t = sum_{i = t mod n} cG[i] G_i (and H'), n = the
+// session's current length.  For n == 1 this is the pair (G', H') the remaining state (a, b) refers to -- what a rank of a
+// vector-sharded IPP (sharding.sharded_ipp_create: SURVEY 8e.2) hands to the final log2(ranks) rounds.  Only n == 1 is exposed.
+int bpgpu_ipp_folded_gens(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *G_out, uint8_t *H_out) {
+  if (!ctx || !s || !G_out || !H_out || !s->gens) return BPGPU_E_ARG;
+  if (s->n != 1) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = s->nb, n0 = s->n0, per = 2 + 2 * n0;
+  // MSM 2p over [B, Bb, G.., H..]: scalars cG[p] on the G block; MSM 2p + 1: cH[p] on the H block
+  HIPCK(ctx, hipMemsetAsync(s->msc, 0, nb * 2 * per * 32, ctx->st));
+  HIPCK(ctx, hipMemcpy2DAsync((uint8_t *)s->msc + 2 * 32, 2 * per * 32, s->cG, n0 * 32, n0 * 32, nb, hipMemcpyDeviceToDevice, ctx->st));
+  HIPCK(ctx, hipMemcpy2DAsync((uint8_t *)s->msc + (per + 2 + n0) * 32, 2 * per * 32, s->cH, n0 * 32, n0 * 32, nb, hipMemcpyDeviceToDevice, ctx->st));
+  CK(msm_gens_dev(ctx, s->gens, 2 * nb, n0, (const uint32_t *)s->msc, s->sums, ctx->st));
+  jac_to_boundary(ctx->st, s->sums, s->out_xy, 2 * nb);
+  CK(launch_ok(ctx));
+  std::vector<uint8_t> tmp(nb * 2 * 64);
+  CK(d2h(ctx, tmp.data(), s->out_xy, nb * 2 * 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  for (size_t p = 0; p < nb; p++) { memcpy(G_out + 64 * p, &tmp[128 * p], 64); memcpy(H_out + 64 * p, &tmp[128 * p + 64], 64); }
+  return BPGPU_OK;
+}
 int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_out) {
   if (!ctx || !s || !a_out || !b_out) return BPGPU_E_ARG;
   if (s->n != 1) return BPGPU_E_LEN;
@@ -1619,6 +1723,7 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
                             const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
                             bpgpu_prover **out) {
   if (!ctx || !c || !out || !nb || !y || !y_inv || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;      // the prover knows its gadget challenges when it builds the rows: numeric circuits only
   size_t n = c->n, m = c->m;
   if (n && (!a_L || !a_R || !a_O || !s_L || !s_R)) return BPGPU_E_ARG;
   *out = nullptr;
@@ -1646,7 +1751,7 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
   scalars_check(ctx->st, w, 3 * nb + 5 * tot, ctx->d_flag);
   if (hipMemcpyAsync(s->y, dy, nb * 32, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
   CircuitDev cd = circuit_dev(c);
-  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);
+  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);   // (parametric circuits are rejected above: the prover builds numeric rows)
   prover_polys(ctx->st, cd, nb, dy, dyi, dL, dR, dO, dsL, dsR, (const int32_t *)dzp, s->polys, dwV);
   prover_tcoeffs(ctx->st, nb, n, s->polys, dt);
   if ((rc = launch_ok(ctx))) return fail(rc);

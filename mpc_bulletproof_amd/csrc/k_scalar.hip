@@ -308,12 +308,15 @@ void ipp_gens_fold(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words
 
 // flattened_constraints: zpow[b][r] = z_b^(r+1); output o = sum over its column of coeff * zpow[row]
 // (w_V and w_c carry the reference's minus sign: prover.rs:367-369, verifier.rs:349-354)
-__global__ void __launch_bounds__(256) k_zpow(const Words8 *z, size_t z_stride, size_t q, int32_t *zpow) {
+__global__ void __launch_bounds__(256) k_zpow(const Words8 *z, size_t z_stride, size_t q, int32_t *zpow, size_t nchi, const Words8 *chi) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   size_t b = blockIdx.y;
   if (r >= q) return;
   Fn zz = load_plain((const Words8 *)((const uint32_t *)z + b * z_stride));
-  raw_put(zpow + (b * q + r) * NL, fn_pow_u32(zz, (uint32_t)r + 1));
+  const Fn zr = fn_pow_u32(zz, (uint32_t)r + 1);
+  const size_t qz = (1 + nchi) * q;
+  raw_put(zpow + (b * qz + r) * NL, zr);
+  for (size_t j = 0; j < nchi; j++) raw_put(zpow + (b * qz + (j + 1) * q + r) * NL, mul(zr, load_plain(&chi[b * nchi + j])));
 }
 __device__ __forceinline__ Fn flatten_column(const CircuitDev &c, size_t o, const int32_t *zp) {
   Fn acc = fe_zero<FN>();
@@ -334,7 +337,7 @@ __global__ void __launch_bounds__(256) k_flatten(CircuitDev c, const int32_t *zp
   size_t b = blockIdx.y;
   size_t nout = 3 * c.n + c.m + 1;
   if (o >= nout) return;
-  Fn v = flatten_column(c, o, zpow + b * c.q * NL);
+  Fn v = flatten_column(c, o, zpow + b * c.qz * NL);
   if (o < c.n) store_plain(&wL[b * c.n + o], v);
   else if (o < 2 * c.n) store_plain(&wR[b * c.n + o - c.n], v);
   else if (o < 3 * c.n) store_plain(&wO[b * c.n + o - 2 * c.n], v);
@@ -342,15 +345,16 @@ __global__ void __launch_bounds__(256) k_flatten(CircuitDev c, const int32_t *zp
   else if (wc) store_plain(&wc[b], v);
 }
 void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
-             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow) {
+             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow, const Words8 *chi) {
   if (!nb) return;
-  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, c.q, zpow);
+  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, c.q, zpow, c.nchi, chi);
   size_t nout = 3 * c.n + c.m + 1;
   hipLaunchKernelGGL(k_flatten, dim3((nout + 255) / 256, nb), dim3(256), 0, st, c, zpow, wL, wR, wO, wV, wc);
 }
 
-void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow) {
-  if (nb && q) hipLaunchKernelGGL(k_zpow, dim3((q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, q, zpow);
+void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow, size_t nchi, const Words8 *chi) {
+  if (!nb || !q) return;
+  hipLaunchKernelGGL(k_zpow, dim3((q + 255) / 256, nb), dim3(256), 0, st, z, z_stride_words, q, zpow, nchi, chi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -362,7 +366,7 @@ __global__ void __launch_bounds__(128) k_prover_polys(CircuitDev c, size_t nb, c
                                                       int32_t *polys, Words8 *wV_out) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
   const size_t n = c.n;
-  const int32_t *zp = zpow_all + p * c.q * NL;
+  const int32_t *zp = zpow_all + p * c.qz * NL;
   if (i < c.m && wV_out) store_plain(&wV_out[p * c.m + i], flatten_column(c, 3 * n + i, zp));
   if (i >= n) return;
   Fn yi = fn_pow_u32(load_plain(&y[p]), (uint32_t)i), yni = fn_pow_u32(load_plain(&y_inv[p]), (uint32_t)i);
@@ -480,7 +484,7 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m, n1 = d.n1;
   const Words8 *ch = challenges + p * (6 + k);
   const Words8 *ps = proof_scalars + p * 5;
-  int32_t *zpow = zpow_all + p * c.q * NL;
+  int32_t *zpow = zpow_all + p * c.qz * NL;
   Fn y = load_plain(&ch[0]), z = load_plain(&ch[1]), u = load_plain(&ch[2]), x = load_plain(&ch[3]);
   (void)y;
   for (int t = tid; t < VS_AUX * NL; t += VS_TPB) sm[t] = aux_all[p * VS_AUX * NL + t];
@@ -502,7 +506,11 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
   {   // z^(r+1) table (verifier.rs:336,358): lane r starts at z^(r+1) and steps by z^64
     Fn cur = mul(z, wave64_powers(z, tid, tab)), z64 = z;        // z^(tid + 1)
     for (int t = 0; t < 6; t++) z64 = sqr(z64);
-    for (size_t r = tid; r < c.q; r += VS_TPB) { raw_put(zpow + r * NL, cur); cur = mul(cur, z64); }
+    for (size_t r = tid; r < c.q; r += VS_TPB) {
+      raw_put(zpow + r * NL, cur);
+      for (size_t j = 0; j < c.nchi; j++) raw_put(zpow + ((j + 1) * c.q + r) * NL, mul(cur, load_plain(&d.chi[p * c.nchi + j])));
+      cur = mul(cur, z64);
+    }
   }
   __syncthreads();
   Fn y_inv = raw_get(sm + 0 * NL), allinv = raw_get(sm + 1 * NL);
@@ -633,7 +641,7 @@ __global__ void __launch_bounds__(VSL_TPB) k_vsl_gh(CircuitDev c, VerifyDims d, 
   const size_t k = d.k, n = d.n, np = d.padded_n, m = d.m, n1 = d.n1;
   const Words8 *ch = challenges + p * (6 + k);
   const Words8 *ps = proof_scalars + p * 5;
-  const int32_t *zpow = zpow_all + p * c.q * NL;
+  const int32_t *zpow = zpow_all + p * c.qz * NL;
   int32_t *aux = aux_all + p * VSL_AUX * NL;
   const int32_t *s_usq = aux + 2 * NL;
   Fn u = load_plain(&ch[2]), x = load_plain(&ch[3]);
@@ -684,7 +692,7 @@ __global__ void __launch_bounds__(VSL_TPB) k_vsl_wc(CircuitDev c, VerifyDims d, 
   __shared__ int32_t s_part[NL * (VSL_TPB / 64)];
   const size_t p = blockIdx.y;
   const int tid = threadIdx.x;
-  const int32_t *zpow = zpow_all + p * c.q * NL;
+  const int32_t *zpow = zpow_all + p * c.qz * NL;
   int32_t *aux = aux_all + p * VSL_AUX * NL;
   const size_t o = 3 * d.n + d.m;
   Fn wcp = fe_zero<FN>();
@@ -717,7 +725,7 @@ __global__ void __launch_bounds__(VSL_TPB) k_vsl_tail(CircuitDev c, VerifyDims d
   if (v >= nvar + 2) return;
   const Words8 *ch = challenges + p * (6 + k);
   const Words8 *ps = proof_scalars + p * 5;
-  const int32_t *zpow = zpow_all + p * c.q * NL;
+  const int32_t *zpow = zpow_all + p * c.qz * NL;
   const int32_t *aux = aux_all + p * VSL_AUX * NL;
   Words8 *fx = fixed_sc + p * (2 + 2 * np);
   Words8 *vs = var_sc + p * nvar;
@@ -758,11 +766,11 @@ static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
   return d.padded_n >= thr || d.m >= thr || c.q >= 4 * thr;
 }
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {
-  return d.nb * ((c.q ? c.q : 1) + (vs_large(c, d) ? VSL_AUX : VS_AUX)) * NL;
+  return d.nb * ((c.qz ? c.qz : 1) + (vs_large(c, d) ? VSL_AUX : VS_AUX)) * NL;
 }
 bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_scratch, int32_t **aux, size_t *aux_stride) {
   if (vs_large(c, d)) return false;
-  *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
+  *aux = zpow_scratch + d.nb * (c.qz ? c.qz : 1) * NL;
   *aux_stride = VS_AUX;
   return true;
 }
@@ -770,7 +778,7 @@ void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, co
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
                     int32_t *zpow_scratch, int *bad, int32_t *bad_proof, bool prep_done) {
   if (!d.nb) return;
-  int32_t *aux = zpow_scratch + d.nb * (c.q ? c.q : 1) * NL;
+  int32_t *aux = zpow_scratch + d.nb * (c.qz ? c.qz : 1) * NL;
   if (!vs_large(c, d)) {
     if (!prep_done) hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, VsPrepArgs{d, challenges, aux, (size_t)VS_AUX});
     hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
@@ -788,7 +796,7 @@ void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, co
   // number of `One` terms is only known on the device (col_ptr); size its grid from the row count
   const int gh_parts = parts(d.padded_n), wc_parts = parts(c.q);
   hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, VsPrepArgs{d, challenges, aux, (size_t)VSL_AUX});
-  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, d.nb), dim3(256), 0, st, challenges + 1, (6 + d.k) * 8, c.q, zpow_scratch);
+  if (c.q) hipLaunchKernelGGL(k_zpow, dim3((c.q + 255) / 256, d.nb), dim3(256), 0, st, challenges + 1, (6 + d.k) * 8, c.q, zpow_scratch, c.nchi, d.chi);
   hipLaunchKernelGGL(k_vsl_gh, dim3(gh_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, challenges, proof_scalars, fixed_sc,
                      full_sc, zpow_scratch, aux);
   hipLaunchKernelGGL(k_vsl_wc, dim3(wc_parts, d.nb), dim3(VSL_TPB), 0, st, c, d, zpow_scratch, aux);

@@ -5,7 +5,10 @@
 // src/inner_product_proof.rs:269-278 -- runs without per-proof host hashing (at 10^6 verifications/s the
 // ~80 keccak permutations per proof would need tens of host cores).
 //
-// Scope: circuits WITHOUT randomized (second-phase) constraints, where the challenge schedule is fixed.
+// Scope: circuits without randomized (second-phase) constraints, and two-phase circuits whose gadgets draw their challenges
+// right after the phase separator (RandomizableConstraintSystem::specify_randomized_constraints with
+// cs.challenge_scalar(label): the shuffle gadget, tests/r1cs.rs:23-62) -- the schedule is still fixed; the gadget challenges are
+// exported (chi) and the constraint weights depend on them through the parametric circuit form (kernels.h CircuitDev).
 // The hash chain is the build's stand-in for merlin's HashChainTranscript (source absent from the
 // reference tree: transcript bytes are parity-unpinned); it is bit-identical to the host
 // transcripts of mpc_bulletproof_amd/host and of the oracle:
@@ -151,14 +154,14 @@ __device__ __forceinline__ bool load64(const Words8 *p, uint64_t m[8]) {   // a 
 
 // The verifier's transcript schedule as data (built on the host by transcript_schedule): one switch with a
 // single inlined copy of each message shape keeps the kernel at ~6 keccak-f bodies instead of ~40.
-enum : uint8_t { TS_DOMSEP = 0, TS_U64 = 1, TS_POINT = 2, TS_SCALAR = 3, TS_CHALLENGE = 4 };
+enum : uint8_t { TS_DOMSEP = 0, TS_U64 = 1, TS_POINT = 2, TS_SCALAR = 3, TS_CHALLENGE = 4, TS_GADGET_CHALLENGE = 5 };
 enum : uint8_t { LB_V, LB_m, LB_AI1, LB_AO1, LB_S1, LB_AI2, LB_AO2, LB_S2, LB_y, LB_z, LB_T1, LB_T3, LB_T4, LB_T5, LB_T6, LB_u, LB_x,
-                 LB_tx, LB_txb, LB_eb, LB_w, LB_r, LB_n, LB_L, LB_R, LB_r1cs, LB_1phase, LB_ipp, LB_COUNT };
+                 LB_tx, LB_txb, LB_eb, LB_w, LB_r, LB_n, LB_L, LB_R, LB_r1cs, LB_1phase, LB_ipp, LB_2phase, LB_COUNT };
 __constant__ Label TR_LABELS[LB_COUNT] = {
     mk_label("V"), mk_label("m"), mk_label("A_I1"), mk_label("A_O1"), mk_label("S1"), mk_label("A_I2"), mk_label("A_O2"), mk_label("S2"),
     mk_label("y"), mk_label("z"), mk_label("T_1"), mk_label("T_3"), mk_label("T_4"), mk_label("T_5"), mk_label("T_6"), mk_label("u"),
     mk_label("x"), mk_label("t_x"), mk_label("t_x_blinding"), mk_label("e_blinding"), mk_label("w"), mk_label("r"), mk_label("n"),
-    mk_label("L"), mk_label("R"), mk_label("r1cs v1"), mk_label("r1cs-1phase"), mk_label("ipp v1")};
+    mk_label("L"), mk_label("R"), mk_label("r1cs v1"), mk_label("r1cs-1phase"), mk_label("ipp v1"), mk_label("r1cs-2phase")};
 
 // One lane per proof.  points layout as bpgpu_r1cs_verify_batch: A_I1 A_O1 S1 A_I2 A_O2 S2 | V[m] | T_1 T_3 T_4 T_5 T_6 | L[k] | R[k]
 // scalars: t_x t_x_blinding e_blinding a b.  init_state: the 32-byte chain state the host holds when it would
@@ -167,7 +170,8 @@ __constant__ Label TR_LABELS[LB_COUNT] = {
 // (TranscriptProtocol::validate_and_append_point -> VerificationError, transcript.rs:101-113).
 __global__ void __launch_bounds__(64) k_verify_transcript(size_t nb, size_t nvar, size_t nch, const TrStep *steps, int nsteps,
                                                           const Words8 *init_state, const Words8 *points, const Words8 *scalars,
-                                                          Words8 *challenges, int32_t *tr_bad) {
+                                                          Words8 *challenges, int32_t *tr_bad, Label gadget_label, Words8 *chi,
+                                                          size_t nchi) {
   __builtin_amdgcn_s_setprio(3);   // serial hash chain at the head of every batch's dependency chain (see k_vs_prep)
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb) return;
@@ -210,6 +214,9 @@ __global__ void __launch_bounds__(64) k_verify_transcript(size_t nb, size_t nvar
         chain_hash<9>(st, 0x00, lab, tail);
         break;
       }
+      case TS_GADGET_CHALLENGE:   // cs.challenge_scalar(gadget label) inside the randomized-constraints callback (verifier.rs:366-385)
+        tr_challenge_scalar(st, gadget_label, &chi[p * nchi + s.src]);
+        break;
       default:
         tr_challenge_scalar(st, lab, &ch[s.src]);
         break;
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(64) k_verify_transcript(size_t nb, size_t nvar
   tr_bad[p] = bad ? 1 : 0;
 }
 // Verifier::verify's transcript order for a circuit without randomized constraints
-int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n) {
+int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n, size_t nchi) {
   int n = 0;
   auto add = [&](uint8_t kind, uint8_t label, uint32_t src, uint8_t validate, uint64_t value) {
     out[n].kind = kind; out[n].label = label; out[n].validate = validate; out[n].src = src; out[n].value = value; n++;
@@ -227,7 +234,11 @@ int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n) {
   for (size_t j = 0; j < m; j++) add(TS_POINT, LB_V, (uint32_t)(6 + j), 0, 0);    // Verifier::commit, :303
   add(TS_U64, LB_m, 0, 0, m);                                                     // :398
   add(TS_POINT, LB_AI1, 0, 1, 0); add(TS_POINT, LB_AO1, 1, 1, 0); add(TS_POINT, LB_S1, 2, 1, 0);   // :401-406
-  add(TS_DOMSEP, LB_1phase, 0, 0, 0);                                             // :371
+  if (nchi == 0) add(TS_DOMSEP, LB_1phase, 0, 0, 0);                              // :371
+  else {                                                                          // :373-383: phase separator, then the gadgets' challenges
+    add(TS_DOMSEP, LB_2phase, 0, 0, 0);
+    for (size_t j = 0; j < nchi; j++) add(TS_GADGET_CHALLENGE, LB_z, (uint32_t)j, 0, 0);
+  }
   add(TS_POINT, LB_AI2, 3, 0, 0); add(TS_POINT, LB_AO2, 4, 0, 0); add(TS_POINT, LB_S2, 5, 0, 0);   // :428-430
   add(TS_CHALLENGE, LB_y, 0, 0, 0); add(TS_CHALLENGE, LB_z, 1, 0, 0);             // :432-433
   const uint8_t tl[5] = {LB_T1, LB_T3, LB_T4, LB_T5, LB_T6};
@@ -244,12 +255,15 @@ int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n) {
   add(TS_CHALLENGE, LB_r, 5, 0, 0);                                               // verifier.rs:506
   return n;
 }
-size_t transcript_schedule_max(size_t m, size_t k) { return 32 + m + 3 * k; }
+size_t transcript_schedule_max(size_t m, size_t k) { return 48 + m + 3 * k; }
 void verify_transcript(hipStream_t st, size_t nb, size_t m, size_t k, const TrStep *steps_dev, int nsteps, const Words8 *init_state,
-                       const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad) {
+                       const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad,
+                       const uint8_t *gadget_label, Words8 *chi_out, size_t nchi) {
   if (!nb) return;
+  Label gl{{0, 0, 0, 0}};
+  if (gadget_label) for (int i = 0; i < 32; i++) gl.w[i >> 3] |= (uint64_t)gadget_label[i] << (8 * (i & 7));
   hipLaunchKernelGGL(k_verify_transcript, dim3((nb + 63) / 64), dim3(64), 0, st, nb, 11 + m + 2 * k, 6 + k, steps_dev, nsteps,
-                     init_state, points, scalars, challenges, tr_bad);
+                     init_state, points, scalars, challenges, tr_bad, gl, chi_out, nchi);
 }
 // ok[p] &= !tr_bad[p]
 __global__ void k_and_not(int32_t *ok, const int32_t *bad, size_t n) {

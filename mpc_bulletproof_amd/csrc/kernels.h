@@ -60,7 +60,7 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
 // latency_mode: more, shorter lanes in the two longest launches (2 points per table lane, 32 lanes per fixed-base MSM): one batch
 // alone finishes ~25 % sooner, a pipelined stream of batches runs ~5 % slower (more instructions)
 struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; };
-struct VerifyDims { size_t nb, n1, n, padded_n, k, m; };
+struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */ };
 struct VsPrepArgs;
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n);
@@ -167,10 +167,14 @@ struct CircuitDev {
   const uint32_t *row;       // nnz: constraint row of the term
   const Words8 *coeff;       // nnz: Montgomery form
   size_t q, n, m, nnz;
+  // Randomized (second-phase) constraints whose coefficients are affine in gadget challenges chi_1..chi_nchi (verifier.rs:366-385):
+  // a term's row index r' = j * q + r selects the multiplier chi_j (chi_0 = 1) of z^(r+1); the z-power table of a proof then has
+  // qz = (1 + nchi) * q entries, zpow[j * q + r] = chi_j * z^(r+1), and the flattening itself is unchanged.
+  size_t nchi, qz;
 };
 // zpow scratch: nb * q field elements (9 int32 each)
 void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
-             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow_scratch);
+             Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow_scratch, const Words8 *chi = nullptr);
 
 // ---- R1CS prover polynomials (r1cs/prover.rs:587-619, 659-672) -----------------------------------
 // polys: raw Montgomery limbs, layout [6][nb][n][9]: l1 l2 l3 r0 r1 r3
@@ -182,14 +186,19 @@ void prover_tcoeffs(hipStream_t st, size_t nb, size_t n, const int32_t *polys, W
 // l_vec, r_vec[nb][padded_n] = l(x), r(x) with the padding of prover.rs:661-672
 void prover_eval(hipStream_t st, size_t nb, size_t n, size_t padded_n, const Words8 *x, const Words8 *y,
                  const int32_t *polys, Words8 *l_vec, Words8 *r_vec);
-void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow);
+// zpow[b][j * q + r] = chi_{b,j} * z_b^(r+1), j <= nchi (chi: nb x nchi plain words, may be nullptr when nchi = 0)
+void zpow_table(hipStream_t st, size_t nb, size_t q, const Words8 *z, size_t z_stride_words, int32_t *zpow, size_t nchi = 0,
+                const Words8 *chi = nullptr);
 
 // ---- device-side verifier transcript (k_transcript.hip) ------------------------------
 struct TrStep { uint8_t kind, label, validate, pad; uint32_t src; uint64_t value; };
 size_t transcript_schedule_max(size_t m, size_t k);
-int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n);   // host: fills the step list, returns its length
+int transcript_schedule(TrStep *out, size_t m, size_t k, size_t padded_n, size_t nchi = 0);   // host: fills the step list, returns its length
+                                                                                                // (nchi > 0: two-phase circuit with nchi gadget challenges)
+// gadget_label (32 bytes, zero-padded) + chi_out (nb x nchi): the challenge of a second-phase gadget (schedule built with nchi = 1)
 void verify_transcript(hipStream_t st, size_t nb, size_t m, size_t k, const TrStep *steps_dev, int nsteps, const Words8 *init_state,
-                       const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad);
+                       const Words8 *points, const Words8 *scalars, Words8 *challenges, int32_t *tr_bad,
+                       const uint8_t *gadget_label = nullptr, Words8 *chi_out = nullptr, size_t nchi = 0);
 void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n);
 
 // Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes

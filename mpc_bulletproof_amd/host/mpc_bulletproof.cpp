@@ -2,6 +2,7 @@
 // Citations are to renegade-fi/mpc-bulletproof (paths relative to its root).
 #include "mpc_bulletproof.hpp"
 #include <sys/random.h>
+#include <unistd.h>
 #include <cerrno>
 #include <chrono>
 #include <exception>
@@ -399,15 +400,55 @@ static std::vector<StarkPoint> generators_chain(char which, uint32_t party, size
   auto padded = pad_label(lab);
   uint8_t state[32], nx[32];
   keccak256(padded.data(), padded.size(), state);
+  // On-disk cache, opt-in: BPH_GENS_CACHE_DIR=<dir> keeps every chain's points in
+  // <dir>/gens_<G|H><party>.bin = records of [32-byte chain state BEFORE the element | 64-byte point]; a stretch is served
+  // from the file when the record at `skip` carries the very state the hash chain has reached there (so a cache written for
+  // another label, transcript definition or curve can never be mistaken for this one), and extended otherwise.
+  // 65 536 generators: 90 ms of host hashing + 8 MB of file instead of 2 x 65 536 scalar multiplications.
+  std::vector<uint8_t> sc(count * 32), out(count * 64), states(count * 32);
+  const char *dir = getenv("BPH_GENS_CACHE_DIR");
+  std::string path;
+  std::vector<uint8_t> cached;
+  if (dir && *dir) {
+    path = std::string(dir) + "/gens_" + which + std::to_string(party) + ".bin";
+    if (FILE *f = std::fopen(path.c_str(), "rb")) {
+      std::fseek(f, 0, SEEK_END);
+      long sz = std::ftell(f);
+      std::fseek(f, 0, SEEK_SET);
+      if (sz > 0 && sz % 96 == 0) { cached.resize((size_t)sz); if (std::fread(cached.data(), 1, cached.size(), f) != cached.size()) cached.clear(); }
+      std::fclose(f);
+    }
+  }
   for (size_t i = 0; i < skip; i++) { keccak256(state, 32, nx); memcpy(state, nx, 32); }
-  std::vector<uint8_t> sc(count * 32), out(count * 64);
+  const size_t have = cached.size() / 96;
+  size_t served = 0;      // elements [skip, skip + served) come from the file
   for (size_t i = 0; i < count; i++) {
+    memcpy(&states[32 * i], state, 32);
+    if (served == i && skip + i < have && memcmp(&cached[96 * (skip + i)], state, 32) == 0) {
+      memcpy(&out[64 * i], &cached[96 * (skip + i) + 32], 64);
+      served = i + 1;
+    }
     keccak256(state, 32, nx);
     memcpy(state, nx, 32);
     hash_to_scalar(state).to_bytes_le(&sc[32 * i]);
   }
-  Device &d = Device::default_device();
-  d.check(bpgpu_generator_mul(d.ctx(), sc.data(), count, out.data()), "bpgpu_generator_mul");
+  if (served < count) {
+    Device &d = Device::default_device();
+    d.check(bpgpu_generator_mul(d.ctx(), sc.data() + 32 * served, count - served, out.data() + 64 * served), "bpgpu_generator_mul");
+    if (!path.empty() && skip + served <= have) {       // extend (or repair from the first mismatch on) atomically
+      std::vector<uint8_t> file(cached.begin(), cached.begin() + 96 * (skip + served));
+      for (size_t i = served; i < count; i++) {
+        file.insert(file.end(), &states[32 * i], &states[32 * i] + 32);
+        file.insert(file.end(), &out[64 * i], &out[64 * i] + 64);
+      }
+      const std::string tmp = path + ".tmp" + std::to_string((unsigned long)getpid());
+      if (FILE *f = std::fopen(tmp.c_str(), "wb")) {
+        const bool ok = std::fwrite(file.data(), 1, file.size(), f) == file.size();
+        std::fclose(f);
+        if (!ok || std::rename(tmp.c_str(), path.c_str()) != 0) std::remove(tmp.c_str());
+      }
+    }
+  }
   return unpack_points(out.data(), count);
 }
 BulletproofGens::BulletproofGens(size_t cap, size_t parties) : party_capacity(parties), G_vec_(parties), H_vec_(parties) {

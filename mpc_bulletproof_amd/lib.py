@@ -11,11 +11,12 @@ SYMBOLS = [
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
-    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
-    "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
+    "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
-    "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev",
+    "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev", "bpgpu_r1cs_verify_batch_param", "bpgpu_r1cs_verify_batch_fs2",
+    "bpgpu_r1cs_verify_batch_fs2_dev",
 ]
 
 
@@ -298,6 +299,11 @@ class BpGpu:
         self._ck(_lib.bpgpu_ipp_finish(self.ctx, s, a, b))
         return bytes(a)[:32 * nb], bytes(b)[:32 * nb]
 
+    def ipp_folded_gens(self, s, nb):
+        G, H = _out(64 * nb), _out(64 * nb)
+        self._ck(_lib.bpgpu_ipp_folded_gens(self.ctx, s, G, H))
+        return bytes(G)[:64 * nb], bytes(H)[:64 * nb]
+
     def ipp_run_fs(self, s, nb, k, states):
         """all rounds with the transcript on the device -> (L bytes nb*k*64, R, a, b, states_out)"""
         L, R = _out(64 * nb * max(k, 1)), _out(64 * nb * max(k, 1))
@@ -398,6 +404,38 @@ class BpGpu:
         self._ck(_lib.bpgpu_r1cs_verify_batch_fs(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                  _buf(init_states), _buf(points), _buf(scalars), ok, mega, ch))
         return list(ok)[:nb], (bytes(mega)[:64 * nb] if want_mega else None), bytes(ch)[:32 * nb * (6 + k)]
+
+    def circuit_create_param(self, q, nchi, row_ptr, kind, idx, coeff, n_mul, m):
+        """two-phase circuit with coefficients affine in nchi gadget challenges: a CSR of (1 + nchi) * q rows (include/bpgpu.h)"""
+        nnz = len(kind)
+        rp = (C.c_uint32 * len(row_ptr))(*row_ptr)
+        kd = (C.c_uint32 * max(nnz, 1))(*kind)
+        ix = (C.c_uint32 * max(nnz, 1))(*idx)
+        h = C.c_void_p()
+        self._ck(_lib.bpgpu_circuit_create_param(self.ctx, C.c_size_t(q), C.c_size_t(nchi), rp, kd, ix, _buf(coeff), C.c_size_t(n_mul),
+                                                 C.c_size_t(m), C.byref(h)))
+        return h
+
+    def r1cs_verify_batch_param(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, gadget_challenges, want_mega=True,
+                                want_scalars=False):
+        np_ = 1 << k
+        nterms = 13 + m + 2 * np_ + 2 * k
+        ok = (C.c_int32 * max(nb, 1))()
+        mega = _out(64 * nb) if want_mega else None
+        full = _out(32 * nb * nterms) if want_scalars else None
+        self._ck(_lib.bpgpu_r1cs_verify_batch_param(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k), _buf(points),
+                                                    _buf(scalars), _buf(challenges), _buf(gadget_challenges), ok, mega, full))
+        return (list(ok)[:nb], bytes(mega)[:64 * nb] if want_mega else None, bytes(full)[:32 * nb * nterms] if want_scalars else None)
+
+    def r1cs_verify_batch_fs2(self, gens, circuit, nb, n1, k, m, nchi, init_states, gadget_label, points, scalars, want_mega=True):
+        """-> (ok, mega, challenges nb x (6 + k) x 32, gadget challenges nb x nchi x 32)"""
+        ok = (C.c_int32 * max(nb, 1))()
+        mega = _out(64 * nb) if want_mega else None
+        ch, chi = _out(32 * nb * (6 + k)), _out(32 * nb * max(nchi, 1))
+        lab = (gadget_label + bytes(32))[:32]
+        self._ck(_lib.bpgpu_r1cs_verify_batch_fs2(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k), _buf(init_states),
+                                                  _buf(lab), _buf(points), _buf(scalars), ok, mega, ch, chi))
+        return list(ok)[:nb], (bytes(mega)[:64 * nb] if want_mega else None), bytes(ch)[:32 * nb * (6 + k)], bytes(chi)[:32 * nb * nchi]
 
     def r1cs_verify_batch_fs_dev(self, gens, circuit, nb, n1, k, d_init, d_points, d_scalars, d_ok, d_mega=None, d_ch=None):
         self._ck(_lib.bpgpu_r1cs_verify_batch_fs_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),

@@ -84,3 +84,67 @@ def sharded_msm_dev(gpu, d_scalars, d_points, n, d_out, group=None) -> bytes:
     else:
         part = bytes(64)
     return combine_partial_points(part, gpu.points_sum, group)
+
+
+def sharded_ipp_create(gpu, transcript, n, w, B, Gf, Hf, G, H, a, b, window_bits=8, group=None):
+    """InnerProductProof::create (inner_product_proof.rs:49-193) for ONE large proof with a, b, G, H dealt CYCLICALLY over the
+    ranks (BASELINE configs[3]): rank r owns the indices i = r (mod ranks).  A fold pairs i with i + h, and
+    ranks | h while h >= ranks, so every fold is local and each rank runs an ordinary resident-generator IPP session of length
+    n / ranks on its own sub-vectors (its own fixed-base tables: 1 / ranks of the memory).  Per round the only exchange is the
+    all-gather of the ranks' partial L and R (2 x 64 B each; the c_L Q terms add up with them) and one point-sum launch; the
+    Fiat-Shamir transcript runs redundantly on every rank.  When a rank's session is down to one element, (a_r, b_r) and
+    its folded generators (G'_r, H'_r) are all-gathered and the last log2(ranks) rounds run on every rank as the literal
+    schedule (bpgpu_ipp_begin) over those `ranks` elements.  Same L, R, a, b bytes as the single-GPU proof.
+
+    gpu: BpGpu.  transcript: object with append_message(label, bytes) and challenge_scalar(label) -> 32 LE bytes, already past
+    innerproduct_domain_sep(n); every rank feeds its own copy the same bytes.  w: 32 B (Q = w * B); B: 64 B; Gf, Hf, a, b: n x 32 B;
+    G, H: n x 64 B (full vectors; only this rank's residue class is uploaded).  Returns (L_list, R_list, a, b)."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    assert n & (n - 1) == 0 and world & (world - 1) == 0 and world <= n
+    sub = n // world
+
+    def strided(buf, sz):
+        return b"".join(buf[sz * i:sz * i + sz] for i in range(rank, n, world))
+
+    Ls, Rs = [], []
+
+    def challenge(L, R):
+        transcript.append_message(b"L", L)
+        transcript.append_message(b"R", R)
+        u = transcript.challenge_scalar(b"u")
+        Ls.append(L)
+        Rs.append(R)
+        return u
+
+    gens = gpu.gens_create(strided(G, 64), strided(H, 64), B, B, window_bits)
+    s = gpu.ipp_begin_gens(gens, 1, sub, w, strided(Gf, 32), strided(Hf, 32), strided(a, 32), strided(b, 32))
+    try:
+        while gpu.ipp_len(s) > 1:
+            Lr, Rr = gpu.ipp_round(s, 1)
+            parts = allgather_bytes(Lr + Rr, group)
+            L = gpu.points_sum(b"".join(p[:64] for p in parts))
+            R = gpu.points_sum(b"".join(p[64:] for p in parts))
+            u = challenge(L, R)
+            gpu.ipp_fold(s, u, gpu.batch_inverse(u))
+        ar, br = gpu.ipp_finish(s, 1)
+        Gr, Hr = gpu.ipp_folded_gens(s, 1)
+    finally:
+        gpu.ipp_destroy(s)
+        gpu.gens_destroy(gens)
+    if world == 1:
+        return Ls, Rs, ar, br
+    parts = allgather_bytes(ar + br + Gr + Hr, group)          # rank order = residue order = element order of the tail
+    a_t, b_t = b"".join(p[:32] for p in parts), b"".join(p[32:64] for p in parts)
+    G_t, H_t = b"".join(p[64:128] for p in parts), b"".join(p[128:192] for p in parts)
+    one = (1).to_bytes(32, "little") * world
+    Q = gpu.msm(w, B)
+    t = gpu.ipp_begin(1, world, Q, one, one, G_t, H_t, True, a_t, b_t)
+    try:
+        while gpu.ipp_len(t) > 1:
+            L, R = gpu.ipp_round(t, 1)
+            u = challenge(L, R)
+            gpu.ipp_fold(t, u, gpu.batch_inverse(u))
+        a_f, b_f = gpu.ipp_finish(t, 1)
+    finally:
+        gpu.ipp_destroy(t)
+    return Ls, Rs, a_f, b_f

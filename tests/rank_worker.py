@@ -46,9 +46,32 @@ def main():
         part = gpu.r1cs_verify_combined(gens, circ, hi - lo, s0.n1, s0.k, s0.m, p_b, q_b, c_b, rho[32 * lo:32 * hi])
         comb = sh.combine_partial_points(part, gpu.points_sum)
         tmax = sh.max_over_ranks(float(rank + 1))
+        # one inner-product proof with a, b, G, H dealt cyclically over the ranks: the host transcript is the
+        # oracle's Python model of it, every arithmetic step is the GPU's
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import pymodel as pm
+
+        class Tr:
+            def __init__(self, n):
+                self.t = pm.Transcript(b"innerproducttest")
+                self.t.innerproduct_domain_sep(n)
+
+            def append_message(self, label, data):
+                self.t.append_message(label, data)
+
+            def challenge_scalar(self, label):
+                return pm.s2b(self.t.challenge_scalar(label))
+
+        ipp = {}
+        for n_ipp in (2, 32):
+            Gp, Hp, B = o.gens("G", n_ipp), o.gens("H", n_ipp), o.generator()
+            av, bv = o.random_scalars(51, n_ipp), o.random_scalars(52, n_ipp)
+            Gf, Hf, w = o.scalars([1] * (n_ipp // 2) + [7] * (n_ipp - n_ipp // 2)), o.random_scalars(54, n_ipp), o.random_scalars(55, 1)
+            Ls, Rs, aa, bb = sh.sharded_ipp_create(gpu, Tr(n_ipp), n_ipp, w, B, Gf, Hf, Gp, Hp, av, bv)
+            ipp[str(n_ipp)] = {"L": b"".join(Ls).hex(), "R": b"".join(Rs).hex(), "a": aa.hex(), "b": bb.hex()}
         with open(f"{out_prefix}.{rank}", "w") as f:
             json.dump({"big_host": big_host.hex(), "big_dev": big_dev.hex(), "ok": full_ok, "comb": comb.hex(), "tmax": tmax,
-                       "lo": lo, "hi": hi}, f)
+                       "lo": lo, "hi": hi, "ipp": ipp}, f)
     finally:
         gpu.close()
         dist.destroy_process_group()

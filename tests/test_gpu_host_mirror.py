@@ -45,6 +45,32 @@ def test_generators_match_oracle(host):
         assert bytes(out) == o.gens(which, 40)
 
 
+def test_generator_cache_on_disk(host, tmp_path, monkeypatch):
+    """BPH_GENS_CACHE_DIR: the chains' points are written once, served from the file afterwards (validated by
+    the hash-chain state stored with every record), extended when more are asked for and repaired when a record is stale."""
+    monkeypatch.setenv("BPH_GENS_CACHE_DIR", str(tmp_path))
+    want = o.gens("G", 48), o.gens("H", 48)
+
+    def get(which, n):
+        out = (C.c_uint8 * (64 * n))()
+        assert host.bph_gens(ord(which), 0, C.c_size_t(n), out) == 0
+        return bytes(out)
+
+    assert get("G", 20) == want[0][:64 * 20]
+    f = tmp_path / "gens_G0.bin"
+    assert f.stat().st_size == 96 * 20 and (tmp_path / "gens_H0.bin").stat().st_size == 96 * 20
+    recs = f.read_bytes()
+    assert all(recs[96 * i + 32:96 * i + 96] == want[0][64 * i:64 * i + 64] for i in range(20))
+    assert get("G", 20) == want[0][:64 * 20] and get("H", 48) == want[1]            # served; extended
+    assert f.stat().st_size == 96 * 48
+    bad = bytearray(f.read_bytes())
+    bad[96 * 5 + 40] ^= 1                 # a corrupted POINT behind a valid state would be served: states are the check ...
+    bad[96 * 9] ^= 1                      # ... so corrupt a state: everything from record 9 on is recomputed and rewritten
+    f.write_bytes(bytes(bad[:96 * 5 + 40]) + bytes([bad[96 * 5 + 40] ^ 1]) + bytes(bad[96 * 5 + 41:]))
+    assert get("G", 48) == want[0]
+    assert f.read_bytes()[96 * 9:96 * 10 + 96] == recs[96 * 9:96 * 10 + 96]
+
+
 def test_prover_bytes_identical_to_oracle(host, golden_r1cs):
     """Prover::prove on the GPU reproduces the oracle's proof bytes (same transcript, same RNG)."""
     for rec in golden_r1cs["range"]:

@@ -49,6 +49,15 @@ def test_sharded_msm_and_combined_check_two_ranks_one_gpu(tmp_path):
     comb = o.msm(rho, b"".join(s.mega_check() for s in sessions), 1).hex()
     assert all(r["comb"] == comb for r in res) and comb != bytes(64).hex()
     assert [(r["lo"], r["hi"]) for r in res] == [(0, 5), (5, 9)] and all(r["tmax"] == 2.0 for r in res)
+    # the vector-sharded inner-product proof (sharding.sharded_ipp_create): byte-identical to the oracle's InnerProductProof::create
+    for n_ipp in (2, 32):
+        Gp, Hp, B = o.gens("G", n_ipp), o.gens("H", n_ipp), o.generator()
+        av, bv = o.random_scalars(51, n_ipp), o.random_scalars(52, n_ipp)
+        Gf, Hf, w = o.scalars([1] * (n_ipp // 2) + [7] * (n_ipp - n_ipp // 2)), o.random_scalars(54, n_ipp), o.random_scalars(55, 1)
+        L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n_ipp, o.point_mul(w, B), Gf, Hf, Gp, Hp, av, bv)
+        for r in res:
+            got = r["ipp"][str(n_ipp)]
+            assert (got["L"], got["R"], got["a"], got["b"]) == (L.hex(), R.hex(), ao.hex(), bo.hex()), n_ipp
 
 
 def test_points_sum(gpu_ctx):

@@ -872,6 +872,90 @@ def test_verify_with_device_transcript(gpu):
             gpu.circuit_destroy(circ)
 
 
+def test_two_phase_circuits_batched_with_device_transcript(gpu):
+    """SURVEY 8f N1 for circuits with RANDOMIZED constraints (verifier.rs:366-385): four k-shuffle proofs with different
+    inputs -- hence four different gadget challenges z -- verified in ONE batch against ONE parametric circuit (coefficient
+    = c0 + chi * c1: the shuffle gadget's (x_i - z) terms, tests/r1cs.rs:23-62).  With the transcript on the device
+    (bpgpu_r1cs_verify_batch_fs2: phase separator + challenge_scalar("shuffle challenge") inside the schedule) every
+    challenge equals the oracle's replay, -chi equals the oracle's numeric `One` coefficients, and accept bits, mega_check
+    points (one proof tampered) and all MSM scalars equal the oracle's; the same through bpgpu_r1cs_verify_batch_param with
+    host-supplied challenges."""
+    sys_path_oracle()
+    import pymodel as pm
+    import random
+    k_sh, nb, cap = 6, 4, 16
+    rnd = random.Random(2025)
+    recs, sessions = [], []
+    for p in range(nb):
+        x = [rnd.getrandbits(40) for _ in range(k_sh)]
+        y = list(x)
+        rnd.shuffle(y)
+        rc, proof, com = o.r1cs_prove(o.K_SHUFFLE, k_sh, b"ShuffleProofTest", x + y, 300 + p, cap)
+        assert rc == 0
+        if p == 2:
+            bad = bytearray(proof)
+            bad[8 + 11 * 64 + 64] ^= 1                      # e_blinding
+            proof = bytes(bad)
+        recs.append((proof, com))
+        sessions.append(o.VerifySession(o.K_SHUFFLE, k_sh, b"ShuffleProofTest", [], com, proof, cap))
+    s0 = sessions[0]
+    n, m, q = s0.n1 + s0.n2, s0.m, s0.q
+    assert s0.n1 == 0 and n == 2 * (k_sh - 1) and q == 2 * n + 1 and m == 2 * k_sh
+    # parametric CSR from the numeric one: in the shuffle circuit every `One` term is a (-z) (kind 4: linear_combination.rs:15-28)
+    rp, kd, ix, cf = s0.csr()
+    rows0, rows1 = [[] for _ in range(q)], [[] for _ in range(q)]
+    for r in range(q):
+        for t in range(rp[r], rp[r + 1]):
+            if kd[t] == 4:
+                rows1[r].append((4, 0, (o.N - 1).to_bytes(32, "little")))     # chi * (-1)
+            else:
+                rows0[r].append((kd[t], ix[t], cf[32 * t:32 * t + 32]))
+    prp, pkd, pix, pcf = [0], [], [], b""
+    for row in rows0 + rows1:
+        for a, b, c in row:
+            pkd.append(a)
+            pix.append(b)
+            pcf += c
+        prp.append(len(pkd))
+    circ = gpu.circuit_create_param(q, 1, prp, pkd, pix, pcf, n, m)
+    g = _gens(gpu, cap, 8)
+    try:
+        t = pm.Transcript(b"ShuffleProofTest")
+        t.append_message(b"dom-sep", b"ShuffleProof")           # tests/r1cs.rs:80-81
+        t.append_u64(b"k", k_sh)
+        init = t.state * nb
+        pts = sc = b""
+        for proof, com in recs:
+            kk, p_, q_ = bh.verify_inputs(proof, com)
+            pts, sc = pts + p_, sc + q_
+        ok, mega, ch, chi = gpu.r1cs_verify_batch_fs2(g, circ, nb, 0, s0.k, m, 1, init, b"shuffle challenge", pts, sc)
+        chis = set()
+        for i, s in enumerate(sessions):
+            assert ch[32 * (6 + s.k) * i:32 * (6 + s.k) * (i + 1)] == s.challenges(), i
+            z = int.from_bytes(chi[32 * i:32 * i + 32], "little")
+            rp_i, kd_i, ix_i, cf_i = s.csr()
+            ones = {cf_i[32 * t_:32 * t_ + 32] for t_ in range(len(kd_i)) if kd_i[t_] == 4}
+            assert ones == {((o.N - z) % o.N).to_bytes(32, "little")}, i                      # the oracle's rows carry -z
+            chis.add(z)
+            assert ok[i] == (1 if s.rc == 0 else 0) == (0 if i == 2 else 1), i
+            assert mega[64 * i:64 * i + 64] == s.mega_check(), i
+        assert len(chis) == nb
+        allch = b"".join(s.challenges() for s in sessions)
+        ok2, mega2, full2 = gpu.r1cs_verify_batch_param(g, circ, nb, 0, s0.k, m, pts, sc, allch, chi, True, True)
+        assert ok2 == ok and mega2 == mega
+        for i, s in enumerate(sessions):
+            assert full2[32 * s.nterms * i:32 * s.nterms * (i + 1)] == s.msm_terms()[0], i
+        # a parametric circuit without its gadget challenges is refused
+        import mpc_bulletproof_amd as m_
+        with pytest.raises(m_.BpGpuError):
+            gpu.r1cs_verify_batch(g, circ, nb, 0, s0.k, m, pts, sc, allch)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        for s in sessions:
+            s.close()
+
+
 # ------------------------------------------------------------------ wire codec (SURVEY 8f N3)
 def test_points_codec_golden(gpu, golden_codec):
     """32-byte compressed points <-> affine: the model's vectors (signs, identity) both ways, and the rejected

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""PMC passes of tools/pmc_sq.sh -> profiles/pmc_constants.json: VALU wave-instructions per 1024-proof step and HBM traffic per
+launch of the kernels of the verification chain, tagged with the hash of the libbpgpu.so they were measured on (bench.py prints
+them with `binary_matches`).  Usage: pmc_constants.py gpurun_out profiles/r02"""
+import hashlib
+import json
+import os
+import sqlite3
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, tag = sys.argv[1], sys.argv[2]
+KERNELS = {"verify_front": "k_verify_front", "verify_scalars": "k_verify_scalars", "verify_windows": "k_verify_windows",
+           "verify_groups": "k_verify_horner_groups", "verify_back": "k_verify_back", "verify_verdict": "k_verify_verdict"}
+
+
+def per_kernel(dbpath, counter):
+    db = sqlite3.connect(dbpath)
+    rows = db.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name",
+                      (counter,)).fetchall()
+    out = {}
+    for short, needle in KERNELS.items():
+        for name, v, cnt in rows:
+            if needle in name:
+                out[short] = (v, cnt)
+    return out
+
+
+valu = per_kernel(f"{src}/pmc_sq/sq_results.db", "SQ_INSTS_VALU")
+fetch = per_kernel(f"{src}/pmc_FETCH_SIZE/p_results.db", "FETCH_SIZE")
+write = per_kernel(f"{src}/pmc_WRITE_SIZE/p_results.db", "WRITE_SIZE")
+h = hashlib.sha256()
+with open(os.path.join(ROOT, "mpc_bulletproof_amd", "libbpgpu.so"), "rb") as f:
+    h.update(f.read())
+out = {
+    "lib_sha256_16": h.hexdigest()[:16],
+    "source": f"{tag}_pmc_sq_summary.txt, {tag}_pmc_FETCH_SIZE.csv, {tag}_pmc_WRITE_SIZE.csv (tools/pmc_sq.sh: solo run, 1 step in flight, batch 1024, c = 20)",
+    "valu_wave_instr_per_launch": {k: v[0] for k, v in valu.items()},
+    "valu_wave_instr_per_step_1024": sum(v[0] for v in valu.values()),
+    # HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request)
+    "traffic_bytes_per_launch": {k: int((2 * fetch[k][0] + write.get(k, (0, 0))[0]) * 1024) for k in fetch},
+}
+path = os.path.join(ROOT, "profiles", "pmc_constants.json")
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps(out, indent=1))
