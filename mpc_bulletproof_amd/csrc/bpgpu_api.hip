@@ -74,6 +74,7 @@ struct bpgpu_ipp {
   Words8 *msc = nullptr;                                           //   (bucket-method rounds)
   Words8 *out_xy = nullptr;                                        // nb x 2 points
   int cur = 0;                                                     // index of the live a/b/G/H buffers
+  bpgpu_gens *own_gens = nullptr;                                  // tables built for this session only (bpgpu_ipp_begin, one proof)
   const bpgpu_gens *gens = nullptr;                                // resident-generator mode: no G/H buffers,
   Words8 *cG = nullptr, *cH = nullptr, *w = nullptr;               //   coefficient vectors nb x n0 and Q = w * B
 };
@@ -1404,6 +1405,22 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   if (!ctx || !out || !nb || !Q || !G_factors || !H_factors || !G || !H || !a || !b) return BPGPU_E_ARG;
   if (!n || (n & (n - 1))) return BPGPU_E_LEN;   // assert!(n.is_power_of_two()), inner_product_proof.rs:70
   *out = nullptr;
+  // ONE proof over arbitrary generators (the reference's `ipp-prover` criterion bench, benches/inner_product.rs:34-64; the tail of a
+  // vector-sharded proof): the literal schedule folds G and H every round -- two dependent 252-doubling chains, ~2.8 ms per round
+  // however small n is.  Instead build fixed-base tables for THESE generators once (B = B_blinding = Q, w = 1) and run the
+  // resident-generator session: a round becomes table lookups.  Same group elements, same bytes.  BPGPU_IPP_LITERAL=1 keeps the
+  // literal schedule (nb > 1 with per-proof Q always takes it).
+  const int literal = getenv("BPGPU_IPP_LITERAL") ? atoi(getenv("BPGPU_IPP_LITERAL")) : 0;   // read per call: tests vary it
+  if (nb == 1 && n >= 2 && !literal) {
+    bpgpu_gens *g = nullptr;
+    int rc = bpgpu_gens_create(ctx, G, H, n, Q, Q, n <= 1024 ? 8 : 4, &g);
+    if (rc) return rc;
+    uint8_t one[32] = {1};
+    rc = bpgpu_ipp_begin_gens(ctx, g, 1, n, one, G_factors, H_factors, a, b, out);
+    if (rc) { bpgpu_gens_destroy(ctx, g); return rc; }
+    (*out)->own_gens = g;
+    return BPGPU_OK;
+  }
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
   bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
@@ -1493,7 +1510,9 @@ int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t 
 void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s) {
   if (!s) return;
   if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
+  bpgpu_gens *own = s->own_gens;
   ipp_free_all(s);
+  if (own) bpgpu_gens_destroy(ctx, own);
 }
 size_t bpgpu_ipp_len(const bpgpu_ipp *s) { return s ? s->n : 0; }
 

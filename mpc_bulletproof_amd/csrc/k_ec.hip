@@ -5,6 +5,7 @@
 // Hot-path rows: a1 StarkPoint::msm_iter / msm, a2 fold_witness (point half),
 // a3 first-round generator scaling, a9 mega_check.  All integer work (F_p, 9 x 29-bit limbs); the
 // kernels are VALU-integer bound (v_mad_u64_u32), not HBM bound -- DESIGN.md has the numbers.
+#include <cstdio>
 #include <cstdlib>
 #include "fixed_body.cuh"
 #include "vs_prep.cuh"
@@ -412,9 +413,18 @@ static int wp_tnp(const VerifyWp &v) {
 struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
-  const size_t tnp = 2, lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
-  return al256(blocks * tnp * SE * STE * 64 * 4) + al256(nb * nvar * SE * sizeof(AffRaw)) + al256(nb * 64 * sizeof(JacRaw)) +
-         al256(nb * sizeof(JacRaw)) + al256(nb * lanes * 4);
+  // the layout depends on the points per table lane (wp_tnp): fewer points per lane = more lanes, but the staging is per
+  // BLOCK of 64 lanes, so for a handful of proofs the block rounding makes the larger tnp the larger staging -- take the
+  // maximum of each part over the three lane shapes
+  size_t stage = 0, lanes_max = 0;
+  for (size_t tnp : {(size_t)2, (size_t)4, (size_t)8}) {
+    const size_t lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
+    const size_t b = al256(blocks * tnp * SE * STE * 64 * 4);
+    if (b > stage) stage = b;
+    if (lanes > lanes_max) lanes_max = lanes;
+  }
+  return stage + al256(nb * nvar * SE * sizeof(AffRaw)) + al256(nb * 64 * sizeof(JacRaw)) + al256(nb * sizeof(JacRaw)) +
+         al256(nb * lanes_max * 4);
 }
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
   const size_t total = (2 + 2 * n) * (252 / c + 1);
@@ -430,8 +440,12 @@ static WpLayout wp_layout(const VerifyWp &v) {
   L.t.tab = (AffRaw *)sp; sp += al256(v.nb * v.nvar * SE * sizeof(AffRaw));
   L.winsum = (JacRaw *)sp; sp += al256(v.nb * 64 * sizeof(JacRaw));
   L.varsum = (JacRaw *)sp; sp += al256(v.nb * sizeof(JacRaw));
-  L.t.bad_lane = (int32_t *)sp;
+  L.t.bad_lane = (int32_t *)sp; sp += al256(v.nb * L.t.lanes * 4);
   L.blocks = (unsigned)nblk;
+  if ((size_t)(sp - (uint8_t *)v.scratch) > verify_wp_scratch_bytes(v.nb, v.nvar)) {   // the caller sized the buffer with that function
+    fprintf(stderr, "bpgpu: verification scratch layout exceeds verify_wp_scratch_bytes\n");
+    abort();
+  }
   return L;
 }
 // tables of the proof points | inversion pass of the scalar assembly (with_prep = false: tables only)

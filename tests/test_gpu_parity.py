@@ -514,8 +514,12 @@ def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b, gens=None,
     return Ls, Rs, aa, bb, chs
 
 
-def test_ipp_create_golden(gpu, golden_ipp):
+@pytest.mark.parametrize("literal", [0, 1])
+def test_ipp_create_golden(gpu, golden_ipp, monkeypatch, literal):
+    """InnerProductProof::create of ONE proof over arbitrary generators: through tables built for the session (default: rounds are
+    table lookups) and through the literal generator-folding schedule (BPGPU_IPP_LITERAL=1) -- the same bytes."""
     sys_path_oracle()
+    monkeypatch.setenv("BPGPU_IPP_LITERAL", str(literal))
     for c in golden_ipp["create"]:
         n = c["n"]
         Gp, Hp = o.gens("G", n), o.gens("H", n)

@@ -61,7 +61,8 @@ for lg in range(1, 11):
     def verify():
         return host.bph_r1cs_verify(3, C.c_size_t(n), buf(label), C.c_size_t(len(label)), vals, C.c_size_t(0), com, C.c_size_t(1),
                                     proof, C.c_size_t(plen.value), C.c_size_t(cap), None)
-    assert prove() == 0 and verify() == 0
+    rp, rv = prove(), verify()
+    assert rp == 0 and rv == 0, (lg, rp, rv)
     t0 = time.perf_counter()
     for _ in range(3):
         assert prove() == 0
