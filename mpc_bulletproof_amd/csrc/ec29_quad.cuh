@@ -7,12 +7,16 @@
 // different lanes of a quad (v_mov_b32_dpp quad_perm moves an operand between them in one instruction per limb), so
 // a doubling is 3 multiplications deep instead of 9 and a general addition 5 deep instead of 16.
 //
-// Coordinates: modified Jacobian (X : Y : Z : T) with T = Z^4 (a = 1), the point is (X / Z^2, Y / Z^3); the identity
-// has all limbs of Z and T literally zero.  Doubling returns the representative scaled by lambda = 1/2, which removes
-// every small constant of dbl-2007-bl but one halving:
-//     E = (3 X^2 + T) / 2,  X3 = E^2 - 2 X Y^2,  Y3 = E (X Y^2 - X3) - Y^4,  Z3 = Y Z,  T3 = Y^4 T
-// (= (X3'/4, Y3'/8, Z3'/2) of the textbook result, the same point).  Levels: {X^2, Y^2, Y Z} -> {E^2, X Y^2, Y^4} ->
-// {E (..), Y^4 T}.
+// Coordinates: modified Jacobian (X : Y : Z : Th) with Th = -Z^4 / 2 (a = 1), the point is (X / Z^2, Y / Z^3); the identity
+// has all limbs of Z and Th literally zero.  Doubling returns the representative scaled by lambda = 1/2, which removes
+// every small constant of dbl-2007-bl:
+//     E = (3 X^2 + Z^4) / 2 = X (3X/2) - Th,  X3 = E^2 - 2 X Y^2,  Y3 = E (X Y^2 - X3) - Y^4,  Z3 = Y Z,  Th3 = Y^4 Th
+// (= (X3'/4, Y3'/8, Z3'/2) of the textbook result, the same point).  Levels: {X (3X/2), Y^2, Y Z} -> {E^2, X Y^2, Y^4,
+// (2X) Y^2} -> {E (..), Y^4 Th}.  Every sum between two levels is a DIFFERENCE of two products (limbs in (-2^29, 2^29),
+// signed limbs are what fe29.cuh multiplies) or feeds one side of a product only (|limb| < 2^30.6 against a tight
+// operand keeps the 9-term column sums below 2^63): no carry pass inside a doubling.  3X/2 = X + X/2 is the one halving,
+// taken BEFORE the product (E^2 could not absorb a sum of three terms); 2 X Y^2 is its own product in the lane that
+// idles at level 2, so that X3 is a plain difference.
 //
 // Convention: on entry and exit of every q4_* function the whole state is REPLICATED in the four lanes of the quad;
 // `role` = lane & 3.  All four lanes of a quad must be active together (they take every branch together: the branch
@@ -24,9 +28,13 @@
 #if defined(__HIPCC__)
 namespace bp {
 
-struct JacT { Fp X, Y, Z, T; };
+struct JacT { Fp X, Y, Z, Th; };   // Th = -Z^4 / 2; X, Y: signed limbs in (-2^29, 2^29); Z, Th: tight
 
-template <int CTRL> __device__ __forceinline__ Fp fp_dpp(const Fp &a) {   // quad_perm move
+// quad_perm move.  bound_ctrl stays 0 ON PURPOSE: with bound_ctrl = 1 the compiler folds the move into the consuming
+// subtraction, and for `a - dpp(b)` it emits v_subrev_u32_dpp, which this toolchain (ROCm 7.2) assembles so that the
+// permutation lands on the OTHER operand (measured on gfx950: v_subrev_u32_dpp d, x, y quad_perm:[3,3,3,3] returns
+// y[lane 3] - x, not y - x[lane 3]; v_sub_u32_dpp is fine) -- every difference below has the moved operand on the right.
+template <int CTRL> __device__ __forceinline__ Fp fp_dpp(const Fp &a) {
   Fp r;
 #pragma unroll
   for (int j = 0; j < NL; j++) {
@@ -62,51 +70,52 @@ __device__ __forceinline__ Fp fp_half_nr(const Fp &x) {
 
 __device__ __forceinline__ JacT jact_inf() {
   JacT r;
-  r.X = fe_one<FP>(); r.Y = fe_one<FP>(); r.Z = fe_zero<FP>(); r.T = fe_zero<FP>();
+  r.X = fe_one<FP>(); r.Y = fe_one<FP>(); r.Z = fe_zero<FP>(); r.Th = fe_zero<FP>();
   return r;
 }
 __device__ __forceinline__ bool jact_is_inf(const JacT &p) { return is_zero_limbs(p.Z); }
+// -w / 2 for a tight w, limbs in (-2^28 - 2^22, 2^28 + 2^22): one side of a product
+__device__ __forceinline__ Fp fp_neg_half_nr(const Fp &w) { return fp_half_nr(sub_nr(fe_zero<FP>(), w)); }
 // one-lane helpers (every lane of the quad does the same): Jacobian <-> modified Jacobian
 __device__ __forceinline__ JacT jact_from_jac(const Jac &p) {
   JacT r;
   r.X = p.X; r.Y = p.Y; r.Z = p.Z;
-  r.T = sqr(sqr(p.Z));       // zero limbs in, zero limbs out
+  const Fp zz = sqr(p.Z);
+  r.Th = mul(zz, fp_neg_half_nr(zz));       // zero limbs in, zero limbs out
   return r;
 }
-__device__ __forceinline__ Jac jact_to_jac(const JacT &p) { Jac r; r.X = p.X; r.Y = p.Y; r.Z = p.Z; return r; }
+__device__ __forceinline__ Jac jact_to_jac(const JacT &p) { Jac r; r.X = norm(p.X); r.Y = norm(p.Y); r.Z = p.Z; return r; }
 __device__ __forceinline__ JacT jact_select(bool c, const JacT &a, const JacT &b) {
   JacT r;
-  r.X = fp_sel(c, a.X, b.X); r.Y = fp_sel(c, a.Y, b.Y); r.Z = fp_sel(c, a.Z, b.Z); r.T = fp_sel(c, a.T, b.T);
+  r.X = fp_sel(c, a.X, b.X); r.Y = fp_sel(c, a.Y, b.Y); r.Z = fp_sel(c, a.Z, b.Z); r.Th = fp_sel(c, a.Th, b.Th);
   return r;
 }
 
-// 2 P
+// 2 P.  In: X, Y limbs in (-2^29, 2^29) (tight included); Z, Th tight.  Out: the same.
 __device__ __forceinline__ JacT q4_dbl(const JacT &p, int role) {
-  const bool is0 = role == 0, is1 = role == 1, is3 = role == 3;
-  // level 1 -- lane 0: X X, lanes 1 and 2: Y Y, lane 3: Y Z
+  const bool is0 = role == 0, is2 = role == 2, is3 = role == 3;
+  const Fp X15 = add_nr(p.X, fp_half_nr(p.X));          // 3X/2, |limb| < 2^30
+  const Fp X2 = add_nr(p.X, p.X);                       // |limb| < 2^30
+  // level 1 -- lane 0: X (3X/2), lanes 1 and 2: Y Y, lane 3: Y Z
   Fp A = fp_sel(is0, p.X, p.Y);
-  Fp B = fp_sel(is3, p.Z, A);
+  Fp B = fp_sel(is0, X15, fp_sel(is3, p.Z, p.Y));
   const Fp P = mul(A, B);
-  // E = (3 XX + T) / 2 = XX + (XX + T) / 2 from the lane's own product (meaningful in lane 0 only).  XX, T tight: the
-  // limbs stay below 2^31 at every step (3 XX + T first would leave no room for the + p of the halving)
-  const Fp E = norm(add_nr(P, fp_half_nr(add_nr(P, p.T))));
-  // level 2 -- lane 0: E E, lane 1: X YY, lane 2: YY YY
-  A = fp_sel(is0, E, fp_sel(is1, p.X, P));
-  B = fp_sel(is0, E, P);
+  const Fp E = sub_nr(P, p.Th);                         // lane 0: (3 XX + Z^4) / 2, limbs in (-2^29, 2^29)
+  // level 2 -- lane 0: E E, lane 1: X YY, lane 2: YY YY, lane 3: (2X) YY
+  A = fp_sel(is0, E, fp_sel(is2, P, fp_sel(is3, X2, p.X)));
+  B = fp_sel(is0, E, fp_dpp<0xA4>(P));                  // quad_perm [0, 1, 2, 2]: lane 3 <- YY of lane 2
   const Fp Q = mul(A, B);
-  const Fp XYY = fp_dpp<QBC1>(Q);
-  const Fp X3 = norm(sub_nr(sub_nr(Q, XYY), XYY));      // lane 0: EE - 2 XYY
-  // level 3 -- lane 0: E (XYY - X3), lane 2: Y4 T
+  const Fp X3 = sub_nr(Q, fp_dpp<QBC3>(Q));             // lane 0: EE - 2 XYY
+  // level 3 -- lane 0: E (XYY - X3), lane 2: Y4 Th
   A = fp_sel(is0, E, Q);
-  B = fp_sel(is0, sub_nr(XYY, X3), p.T);
+  B = fp_sel(is0, sub_nr(fp_dpp<QBC1>(Q), X3), p.Th);   // lane 0: |limb| < 2^30 against E
   const Fp R = mul(A, B);
-  const Fp Y4 = fp_dpp<QBC2>(Q);
-  const Fp Y3 = sub(R, Y4);                             // lane 0
+  const Fp Y3 = sub_nr(R, fp_dpp<QBC2>(Q));             // lane 0
   JacT r;
   r.X = fp_dpp<QBC0>(X3);
   r.Y = fp_dpp<QBC0>(Y3);
   r.Z = fp_dpp<QBC3>(P);
-  r.T = fp_dpp<QBC2>(R);
+  r.Th = fp_dpp<QBC2>(R);
   return r;
 }
 
@@ -144,15 +153,15 @@ __device__ __forceinline__ JacT q4_add(const JacT &p1, const JacT &p2, int role)
   const Fp W = mul(A, B);
   const Fp HHH = fp_dpp<QBC0>(W), V = fp_dpp<QBC1>(W), RR = fp_dpp<QBC2>(W);
   const Fp X3 = norm(sub_nr(sub_nr(sub_nr(RR, HHH), V), V));
-  // level 5 -- lane 0: rr (V - X3), lane 1: S1 HHH, lane 3: T3 = (Z3 Z3)^2
+  // level 5 -- lane 0: rr (V - X3), lane 1: S1 HHH, lane 3: Th3 = (Z3 Z3) (-(Z3 Z3) / 2)
   A = fp_sel(is0, rr, fp_sel(is1, S1, W));
-  B = fp_sel(is0, sub_nr(V, X3), fp_sel(is1, HHH, W));
+  B = fp_sel(is0, sub_nr(V, X3), fp_sel(is1, HHH, fp_neg_half_nr(W)));
   const Fp F = mul(A, B);
   JacT r;
   r.X = X3;
   r.Y = sub(fp_dpp<QBC0>(F), fp_dpp<QBC1>(F));
   r.Z = Z3;
-  r.T = fp_dpp<QBC3>(F);
+  r.Th = fp_dpp<QBC3>(F);
   r = jact_select(inf1, p2, r);
   return jact_select(inf2, p1, r);
 }

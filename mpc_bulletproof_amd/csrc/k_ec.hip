@@ -341,6 +341,26 @@ __global__ void __launch_bounds__(64) k_verify_horner_groups(JacRaw *winsum, siz
   }
   raw_store(&s[0], acc);
 }
+// stage 1 with a DPP quad per (proof, group): the 28 doublings and 7 additions at the quad's depth (latency mode: 4x the lanes
+// and ~2.3x the instructions of this small stage for ~40 % of its time)
+__global__ void __launch_bounds__(64) k_verify_horner_groups4(JacRaw *winsum, size_t nb) {
+  __builtin_amdgcn_s_setprio(2);
+  const int role = threadIdx.x & 3;
+  size_t t = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+  const size_t units = nb * (64 / HG);
+  const bool live = t < units;
+  if (!live) t = units - 1;            // whole quads stay active
+  JacRaw *s = winsum + t * HG;
+  JacT acc = jact_from_jac(raw_load(&s[HG - 1]));
+#pragma unroll 1
+  for (int i = HG - 2; i >= 0; i--) {
+#pragma unroll 1
+    for (int d = 0; d < SW; d++) acc = q4_dbl(acc, role);
+    acc = q4_add(acc, jact_from_jac(raw_load(&s[i])), role);
+  }
+  // (a clamped quad recomputes the last unit; only live quads store, after every load of the unit's slot 0 is done)
+  if (live && role == 0) raw_store(&s[0], jact_to_jac(acc));
+}
 // one lane per proof over `count` partial sums `stride` slots apart, `dbl` doublings between them
 struct HornerArgs { const JacRaw *winsum; JacRaw *varsum; size_t nb; int count, stride, dbl, quad; };
 __device__ __forceinline__ void horner_body(const HornerArgs &h, size_t blk) {
@@ -474,16 +494,20 @@ void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   static_assert(num_windows<SW>() == 64, "64 window sums per proof");
   if (!wp_grouped()) return;
   WpLayout L = wp_layout(v);
-  hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
+  static const int quad_env = getenv("BPGPU_GROUPS_QUAD") ? atoi(getenv("BPGPU_GROUPS_QUAD")) : -1;
+  const bool quad = quad_env >= 0 ? quad_env != 0 : v.latency_mode;
+  if (quad) hipLaunchKernelGGL(k_verify_horner_groups4, dim3((v.nb * (64 / HG) + 15) / 16), dim3(64), 0, st, L.winsum, v.nb);
+  else hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
 }
 template <int C>
 static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode) {
   // lanes per fixed-base MSM: 16 = fewest instructions (4 butterfly levels), 32 = half the serial additions per lane
   // (the fixed-base lanes are the longest link of this launch once the Horner pass runs on quads); BPGPU_FIXED_LPM overrides
   static const int lpm_env = getenv("BPGPU_FIXED_LPM") ? atoi(getenv("BPGPU_FIXED_LPM")) : 0;
-  const int lpm = lpm_env == 16 || lpm_env == 32 ? lpm_env : (f.nb >= 1024 && !latency_mode ? 16 : 32);
+  const int lpm = lpm_env == 16 || lpm_env == 32 || lpm_env == 64 ? lpm_env : (f.nb >= 1024 && !latency_mode ? 16 : 32);
   if (lpm == 16) hipLaunchKernelGGL((k_verify_back<C, 16>), dim3(hb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, h, hb, f);
-  else hipLaunchKernelGGL((k_verify_back<C, 32>), dim3(hb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, h, hb, f);
+  else if (lpm == 32) hipLaunchKernelGGL((k_verify_back<C, 32>), dim3(hb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, h, hb, f);
+  else hipLaunchKernelGGL((k_verify_back<C, 64>), dim3(hb + (unsigned)f.nb), dim3(64), 0, st, h, hb, f);
 }
 // Horner pass over the window sums | table-lookup MSMs over the generators (fixed scalars as for fixed_msm)
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,

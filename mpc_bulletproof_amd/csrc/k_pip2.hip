@@ -300,11 +300,7 @@ __device__ __forceinline__ void p2_final_body(const P2Final &f) {
     if (f.out_xy) {
       if (!jac_is_inf(r) && is_zero_exact(r.Z)) r = jac_inf();
       uint32_t w[16];
-      // one lane, so the data-dependent branches of the binary GCD cost nothing: ~20 k instructions against ~33 k for Fermat
-      Aff af;
-      if (jac_is_inf(r)) { af.x = fe_zero<FP>(); af.y = fe_zero<FP>(); }
-      else af = jac_to_aff_with_zinv(r, inv_gcd(r.Z));
-      aff_to_boundary(w, af);
+      aff_to_boundary(w, jac_to_aff(r));   // Fermat: the one-lane binary GCD measured 150 us slower (its compare / shift steps are serial too)
 #pragma unroll
       for (int j = 0; j < 8; j++) { f.out_xy[0].w[j] = w[j]; f.out_xy[1].w[j] = w[8 + j]; }
     }

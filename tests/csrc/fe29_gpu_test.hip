@@ -108,9 +108,9 @@ __global__ void __launch_bounds__(64) k_q4(int op, const uint32_t *a, const uint
     for (int d = 0; d < 4; d++) r = q4_dbl(r, role);
     r = q4_add(r, P, role);
   }
-  // T must be Z^4 on exit (it feeds the next doubling)
+  // Th must be -Z^4 / 2 on exit (it feeds the next doubling)
   Jac rj = jact_to_jac(r);
-  const bool t_ok = is_zero_exact(sub(r.T, sqr(sqr(r.Z))));
+  const bool t_ok = is_zero_exact(add(add_nr(r.Th, r.Th), sqr(sqr(r.Z))));
   uint32_t wo[16];
   aff_to_boundary(wo, jac_to_aff(jac_is_inf(rj) || is_zero_exact(rj.Z) ? jac_inf() : rj));
   if (role == 0) {

@@ -1,0 +1,27 @@
+#!/bin/bash
+# bursts of 20 steps (the driver's bench call) under the tuning knobs of the verification chain: median of 12 bursts per setting
+R=$GRAFT_REPO_ROOT
+WL=$R/gpurun_out/wl_burst
+[ -f $WL.1024 ] || python3 $R/bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > $R/gpurun_out/wl_burst.log 2>&1
+export GPU_MAX_HW_QUEUES=24
+KS=20,20,20,20,20,20,20,20,20,20,20,20,1024
+run() {
+  env "$@" BURST_KS=$KS python3 $R/tools/burst_probe.py $WL.1024 20 | grep K= > /tmp/b20.txt
+  python3 - "$*" <<'PY'
+import sys, re
+v20, v1k = [], []
+for l in open('/tmp/b20.txt'):
+    m = re.match(r"K=\s*(\d+):.*=\s*([\d.]+) M/s", l)
+    if m: (v20 if int(m.group(1)) == 20 else v1k).append(float(m.group(2)))
+v20.sort()
+print(f"{sys.argv[1]:60s} K=20: min {v20[0]:.2f} median {v20[len(v20)//2]:.2f} max {v20[-1]:.2f}   K=1024: {v1k}", flush=True)
+PY
+}
+run BPGPU_FIXED_LPM=16
+run BPGPU_FIXED_LPM=32
+run BPGPU_FIXED_LPM=32 BPGPU_TABLE_NP=2
+run BPGPU_FIXED_LPM=16 BPGPU_TABLE_NP=2
+run BPGPU_FIXED_LPM=16 BPGPU_TABLE_NP=8
+run BPGPU_FIXED_LPM=16 BPGPU_HORNER_QUAD=0
+run BPGPU_FIXED_LPM=32 BPGPU_HORNER_QUAD=0
+run BPGPU_FIXED_LPM=16 BPGPU_HORNER_GROUPS=0

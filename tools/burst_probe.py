@@ -35,6 +35,8 @@ def step():
 
 for c in ctxs:
     c.profile_enable(prof_on)
+    if os.environ.get("BURST_LATENCY_MODE"):   # the un-pipelined caller's setting (bpgpu_set_latency_mode)
+        c.set_latency_mode(True)
 for _ in range(3000):
     step()
 torch.cuda.synchronize()
