@@ -482,8 +482,8 @@ template <class F> BP_HD Fe<F> fe_pow(const Fe<F> &x, const uint32_t e[8]) {
   }
   return acc;
 }
-// Field inversion by Fermat (0 -> 0).  F_p: p - 2 = (2^59 + 16) * 2^192 + (2^192 - 1).
-template <class F> BP_HD Fe<F> inv(const Fe<F> &x) {
+// Field inversion by Fermat (0 -> 0).  F_p: p - 2 = (2^59 + 16) * 2^192 + (2^192 - 1).  The cross-check of inv() below.
+template <class F> BP_HD Fe<F> inv_fermat(const Fe<F> &x) {
   if constexpr (F::sparse) {
     Fe<F> x2 = sqr(x), x3 = mul(x2, x), x6 = sqr(x3), x7 = mul(x6, x), x14 = sqr(x7), x15 = mul(x14, x);
     Fe<F> t = x;
@@ -588,5 +588,87 @@ template <class F> BP_HD Fe<F> inv_gcd(const Fe<F> &x) {
   w8_inv_mod<F>(iw, w);
   return to_mont(unpack<F>(iw));
 }
+
+// ---- inversion by divsteps (Bernstein-Yang "safegcd": the half-delta variant with a 2x2 transition matrix per batch of
+// steps, as libsecp256k1's modinv32 organises it, restated for 9 limbs of 29 bits: a batch is 29 divsteps on the low limbs
+// of f and g, then one pass over the limbs of (f, g) and of (d, e)).  21 batches = 609 divsteps >= the 590 that suffice for
+// any odd modulus below 2^256.  No data-dependent branch anywhere (every lane of a wave inverts its own value in lock
+// step), ~17 k instructions against ~34 k (F_p) / ~90 k (F_n) for Fermat's x^(m-2).  0 -> 0.
+struct DsMat { int32_t u, v, q, r; };   // t (f, g) = 2^29 (f', g')
+BP_HD int32_t ds_divsteps(int32_t zeta, uint32_t f0, uint32_t g0, DsMat &t) {
+  uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;   // matrix entries: signed values held mod 2^32 (left shifts stay defined)
+#pragma unroll
+  for (int i = 0; i < LB; i++) {
+    uint32_t c1 = (uint32_t)(zeta >> 31);             // zeta < 0
+    const uint32_t c2 = 0u - (g & 1u);                // g odd
+    const uint32_t x = (f ^ c1) - c1, y = (u ^ c1) - c1, z = (v ^ c1) - c1;   // +-(f, u, v)
+    g += x & c2; q += y & c2; r += z & c2;
+    c1 &= c2;
+    zeta = (int32_t)((uint32_t)zeta ^ c1) - 1;        // -zeta - 2 or zeta - 1
+    f += g & c1; u += q & c1; v += r & c1;
+    g >>= 1; u <<= 1; v <<= 1;
+  }
+  t.u = (int32_t)u; t.v = (int32_t)v; t.q = (int32_t)q; t.r = (int32_t)r;
+  return zeta;
+}
+// x^-1 in the representation x is in (Montgomery form in, Montgomery form out: the run starts from e = R^2 instead of 1).
+// Output: lazy signed limbs, |value| < 2m.
+template <class F> BP_HD Fe<F> inv_ds(const Fe<F> &x) {
+  int32_t MOD[NL];
+  if constexpr (F::sparse) { constexpr int32_t C[NL] = FP_MOD; for (int j = 0; j < NL; j++) MOD[j] = C[j]; }
+  else { constexpr int32_t C[NL] = FN_MOD; for (int j = 0; j < NL; j++) MOD[j] = C[j]; }
+  Fe<F> f, g = canon(x), d = fe_zero<F>(), e = fe_r2<F>();
+#pragma unroll
+  for (int j = 0; j < NL; j++) f.v[j] = MOD[j];
+  int32_t zeta = -1;
+#pragma unroll 1
+  for (int it = 0; it < 21; it++) {
+    DsMat t;
+    zeta = ds_divsteps(zeta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+    {   // (d, e) <- t (d, e) / 2^29 mod m, both kept in (-2m, m)
+      const int32_t sd = d.v[NL - 1] >> 31, se = e.v[NL - 1] >> 31;
+      int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+      int64_t cd = (int64_t)t.u * d.v[0] + (int64_t)t.v * e.v[0], ce = (int64_t)t.q * d.v[0] + (int64_t)t.r * e.v[0];
+      // multiples of m that clear the low 29 bits: m^-1 mod 2^29 is 1 for p, -N0 for n
+      if constexpr (F::sparse) {
+        md -= (int32_t)(((uint32_t)cd + (uint32_t)md) & (uint32_t)LMASK);
+        me -= (int32_t)(((uint32_t)ce + (uint32_t)me) & (uint32_t)LMASK);
+      } else {
+        md -= (int32_t)(((uint32_t)md - FN_N0 * (uint32_t)cd) & (uint32_t)LMASK);
+        me -= (int32_t)(((uint32_t)me - FN_N0 * (uint32_t)ce) & (uint32_t)LMASK);
+      }
+      cd += (int64_t)MOD[0] * md; ce += (int64_t)MOD[0] * me;
+      cd >>= LB; ce >>= LB;
+#pragma unroll
+      for (int j = 1; j < NL; j++) {
+        cd += (int64_t)t.u * d.v[j] + (int64_t)t.v * e.v[j];
+        ce += (int64_t)t.q * d.v[j] + (int64_t)t.r * e.v[j];
+        if (MOD[j] != 0) { cd += (int64_t)MOD[j] * md; ce += (int64_t)MOD[j] * me; }
+        d.v[j - 1] = (int32_t)(cd & LMASK); cd >>= LB;
+        e.v[j - 1] = (int32_t)(ce & LMASK); ce >>= LB;
+      }
+      d.v[NL - 1] = (int32_t)cd; e.v[NL - 1] = (int32_t)ce;
+    }
+    {   // (f, g) <- t (f, g) / 2^29, exact
+      int64_t cf = (int64_t)t.u * f.v[0] + (int64_t)t.v * g.v[0], cg = (int64_t)t.q * f.v[0] + (int64_t)t.r * g.v[0];
+      cf >>= LB; cg >>= LB;
+#pragma unroll
+      for (int j = 1; j < NL; j++) {
+        cf += (int64_t)t.u * f.v[j] + (int64_t)t.v * g.v[j];
+        cg += (int64_t)t.q * f.v[j] + (int64_t)t.r * g.v[j];
+        f.v[j - 1] = (int32_t)(cf & LMASK); cf >>= LB;
+        g.v[j - 1] = (int32_t)(cg & LMASK); cg >>= LB;
+      }
+      f.v[NL - 1] = (int32_t)cf; g.v[NL - 1] = (int32_t)cg;
+    }
+  }
+  // g = 0, f = +-gcd = +-1 (or +-m for x = 0, where d = 0): the inverse is d * sign(f)
+  const int32_t sf = f.v[NL - 1] >> 31;
+#pragma unroll
+  for (int j = 0; j < NL; j++) d.v[j] = (d.v[j] ^ sf) - sf;
+  return d;
+}
+// THE field inversion of every kernel (0 -> 0)
+template <class F> BP_HD Fe<F> inv(const Fe<F> &x) { return inv_ds(x); }
 
 }  // namespace bp

@@ -424,11 +424,12 @@ __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, con
   }
 }
 // points per table lane: 8 = fewest instructions (one inversion per 8 points), 4 (default) = half the dependency chain of
-// the front launch for +1.3 % instructions per batch, 2 (latency mode) = a quarter for +4 %.  BPGPU_TABLE_NP overrides.
+// the front launch for +1.3 % instructions per batch, 1 (latency mode) = 7 additions + one inversion per lane, the shortest
+// chain (a lone batch: 0.665 ms against 0.715 ms with 2).  BPGPU_TABLE_NP overrides.
 static int wp_tnp(const VerifyWp &v) {
   static const int env = getenv("BPGPU_TABLE_NP") ? atoi(getenv("BPGPU_TABLE_NP")) : 0;
-  const int t = env ? env : (v.latency_mode ? 2 : 4);
-  return t == 8 ? 8 : (t == 2 ? 2 : 4);
+  const int t = env ? env : (v.latency_mode ? 1 : 4);
+  return t == 8 ? 8 : (t == 2 ? 2 : (t == 1 ? 1 : 4));
 }
 struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -437,7 +438,7 @@ size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
   // BLOCK of 64 lanes, so for a handful of proofs the block rounding makes the larger tnp the larger staging -- take the
   // maximum of each part over the three lane shapes
   size_t stage = 0, lanes_max = 0;
-  for (size_t tnp : {(size_t)2, (size_t)4, (size_t)8}) {
+  for (size_t tnp : {(size_t)1, (size_t)2, (size_t)4, (size_t)8}) {
     const size_t lanes = (nvar + tnp - 1) / tnp, blocks = (nb * lanes + 63) / 64;
     const size_t b = al256(blocks * tnp * SE * STE * 64 * 4);
     if (b > stage) stage = b;
@@ -478,6 +479,7 @@ void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims 
   switch (wp_tnp(v)) {
     case 8: hipLaunchKernelGGL((k_verify_front<8>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
     case 2: hipLaunchKernelGGL((k_verify_front<2>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
+    case 1: hipLaunchKernelGGL((k_verify_front<1>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
     default: hipLaunchKernelGGL((k_verify_front<4>), dim3(L.blocks + pb), dim3(64), 0, st, L.t, L.blocks, prep); break;
   }
 }

@@ -26,7 +26,7 @@ template <class F> static int binop(int op, const uint8_t *a, const uint8_t *b, 
     case 1: r = sub(x, y); break;
     case 2: r = mul(x, y); break;
     case 3: r = sqr(x); break;
-    case 4: r = inv(x); break;
+    case 4: r = inv_fermat(x); break;
     case 5: r = neg(x); break;
     case 6: r = mul_small<8>(x); break;
     // lazy chains: products of un-canonical operands
@@ -34,6 +34,8 @@ template <class F> static int binop(int op, const uint8_t *a, const uint8_t *b, 
     case 8: r = sqr(sub(sub(x, y), y)); break;                     // (x - 2y)^2
     case 9: r = mul(norm(add_nr(add_nr(x, x), x)), sub(y, x)); break;  // 3x (y - x)
     case 10: r = inv_gcd(x); break;
+    case 11: r = inv_ds(x); break;
+    case 12: r = mul(inv_ds(sub(x, y)), sub(x, y)); break;        // lazy operand in, lazy result straight into a product: 1 (or 0)
     default: return -2;
   }
   store_fe(out, r);

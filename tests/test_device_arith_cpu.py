@@ -51,7 +51,8 @@ def test_field_ops(h, name, m):
     want = {0: lambda a, b: a + b, 1: lambda a, b: a - b, 2: lambda a, b: a * b, 3: lambda a, b: a * a,
             4: lambda a, b: pow(a, m - 2, m), 5: lambda a, b: -a, 6: lambda a, b: 8 * a,
             7: lambda a, b: a * a - b * b, 8: lambda a, b: (a - 2 * b) ** 2, 9: lambda a, b: 3 * a * (b - a),
-            10: lambda a, b: pow(a, m - 2, m)}
+            10: lambda a, b: pow(a, m - 2, m), 11: lambda a, b: pow(a, m - 2, m),
+            12: lambda a, b: 0 if (a - b) % m == 0 else 1}
     out = (C.c_uint8 * 32)()
     for a, b in field_cases(m, rnd):
         for op, fn in want.items():

@@ -355,7 +355,7 @@ def test_verify_batch_launch_variants(gpu, monkeypatch, np_, fuse, wp, c):
 
 @pytest.mark.parametrize("n_bits,nb,c", [(8, 71, 8), (8, 12, 8), (64, 65, 20)])
 def test_verify_batch_latency_mode(gpu, n_bits, nb, c):
-    """bpgpu_set_latency_mode (the un-pipelined caller's setting: 2 points per table lane, 32 lanes per fixed-base MSM, a DPP
+    """bpgpu_set_latency_mode (the un-pipelined caller's setting: 1 point per table lane, 32 lanes per fixed-base MSM, a DPP
     quad per (proof, group) in the first Horner stage): same accept bits, mega_check points and MSM scalars as the oracle.
     An odd batch leaves half a block of quads without a unit in the quad stage."""
     gpu.set_latency_mode(True)
