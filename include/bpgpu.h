@@ -139,7 +139,7 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
 /* ---- resident generators ---------------------------------------------------------------------
  * BulletproofGens::share(0).G(n) / .H(n) and PedersenGens{B, B_blinding}
  *   -- src/generators.rs:32-37,158-167,310-320.  Uploads the points once and precomputes signed
- * fixed-window tables (window_bits in {4, 8, 10, 12, 14, 16}; table bytes = (2*cap+2) * (252/c+1) * 2^(c-1) * 64). */
+ * fixed-window tables (window_bits in {4, 8, 10, 12, 14, 16, 20}; table bytes = (2*cap+2) * (252/c+1) * 2^(c-1) * 64). */
 int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t gens_capacity,
                       const uint8_t B[64], const uint8_t B_blinding[64], int window_bits,
                       bpgpu_gens **out);

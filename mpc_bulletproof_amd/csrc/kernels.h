@@ -57,7 +57,7 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
 // Window-parallel variant of the same (k_ec.hip): front [tables | inversion pass] -> (k_verify_scalars) -> windows -> groups ->
 // back [Horner | fixed-base MSMs] -> verdict, which writes ok / mega itself (no verify_finalize).
 // bad_sc: the per-proof canonicity bits written by verify_scalars (nullable)
-// latency_mode: more, shorter lanes in the two longest launches (2 points per table lane, 32 lanes per fixed-base MSM): one batch
+// latency_mode: more, shorter lanes in the two longest launches (1 point per table lane, 32 lanes per fixed-base MSM, a quad per group in the first Horner stage): one batch
 // alone finishes ~25 % sooner, a pipelined stream of batches runs ~5 % slower (more instructions)
 struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; };
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */ };

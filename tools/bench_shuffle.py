@@ -55,11 +55,15 @@ args = ap.parse_args()
 run(4)    # warm-up (context, kernels)
 for lg in args.log2k:
     k = 1 << lg
-    for rep in range(2):   # second repetition: workspaces grown, code paged in
+    runs = []
+    for rep in range(4):   # first repetition untimed (workspaces grow, code is paged in); then the median of three, stage by stage
         vals, cap, proof, com, ms, dt = run(k)
+        if rep:
+            runs.append(ms)
+    ms = [sorted(r[i] for r in runs)[1] for i in range(6)]
     q = 4 * (k - 1) + 1
     print(f"k=2^{lg}: n={2 * (k - 1)} q={q} m={2 * k} proof {len(proof)} B | " +
-          " ".join(f"{n} {t:.1f}" for n, t in zip(NAMES, ms)) + " ms")
+          " ".join(f"{n} {t:.1f}" for n, t in zip(NAMES, ms)) + " ms (medians of 3)")
     print(f"    prove  {ms[3]:9.1f} ms = {q / ms[3] / 1e3:8.3f} M constraints/s   (with circuit build {q / (ms[2] + ms[3]) / 1e3:.3f})")
     print(f"    verify {ms[5]:9.1f} ms = {q / ms[5] / 1e3:8.3f} M constraints/s   (with circuit build {q / (ms[4] + ms[5]) / 1e3:.3f})")
     sys.stdout.flush()

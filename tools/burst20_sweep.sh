@@ -17,11 +17,10 @@ v20.sort()
 print(f"{sys.argv[1]:60s} K=20: min {v20[0]:.2f} median {v20[len(v20)//2]:.2f} max {v20[-1]:.2f}   K=1024: {v1k}", flush=True)
 PY
 }
-run BPGPU_FIXED_LPM=16
-run BPGPU_FIXED_LPM=32
-run BPGPU_FIXED_LPM=32 BPGPU_TABLE_NP=2
-run BPGPU_FIXED_LPM=16 BPGPU_TABLE_NP=2
-run BPGPU_FIXED_LPM=16 BPGPU_TABLE_NP=8
-run BPGPU_FIXED_LPM=16 BPGPU_HORNER_QUAD=0
-run BPGPU_FIXED_LPM=32 BPGPU_HORNER_QUAD=0
-run BPGPU_FIXED_LPM=16 BPGPU_HORNER_GROUPS=0
+run BPGPU_TABLE_NP=4
+run BPGPU_TABLE_NP=2
+run BPGPU_TABLE_NP=1
+run BPGPU_TABLE_NP=8
+run BPGPU_TABLE_NP=2 BPGPU_FIXED_LPM=32
+run BURST_LATENCY_MODE=1
+run BPGPU_TABLE_NP=2 BPGPU_GROUPS_QUAD=1
