@@ -257,9 +257,18 @@ def main():
     counter = [0]
     all_ok = (1).to_bytes(4, "little") * nb
 
+    sample_period = [0]            # > 0: step number s carries HIP-event pairs when s % sample_period == 0 (see below)
+    prof_state = [False] * len(ctxs)
+
     def step():
-        i = counter[0] % len(ctxs)
+        n = counter[0]
+        i = n % len(ctxs)
         counter[0] += 1
+        if sample_period[0]:
+            on = n % sample_period[0] == 0
+            if on != prof_state[i]:
+                ctxs[i].profile_enable(on)
+                prof_state[i] = on
         ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[i])
 
     def sync_all():
@@ -295,15 +304,27 @@ def main():
         return dt
 
     # Per-kernel HIP-event timing (event pairs on the stream each kernel is launched on, recycled from a per-context pool).
-    # In the timed region the launches of ONE context in `inflight` carry events (an event pair per launch on every context
-    # costs a short run a quarter of its throughput: ~12 barrier packets per step in each queue); right after it the same
-    # K steps are REPLAYED with event pairs around every launch of every context: `roofline` is computed from the replay
-    # (>= K launches per kernel) and quotes the timed region's own sample beside it.  BPGPU_PROF_EVERY overrides the sampling.
-    prof_every = max(1, int(os.environ.get("BPGPU_PROF_EVERY", str(len(ctxs)))))
+    # In the timed region ONE STEP in `inflight + 1` carries events, so the sampled steps rotate over the contexts (an event
+    # pair per launch on every context costs a short run a quarter of its throughput: ~12 barrier packets per step in each
+    # queue; always the same context made that context lag, and the closing fence waited for it: 3-5 % of a 2 048-step run);
+    # right after it the same K steps are REPLAYED with event pairs around every launch of every context: `roofline` is
+    # computed from the replay (>= K launches per kernel) and quotes the timed region's own sample beside it.
+    # BPGPU_PROF_EVERY overrides the sampling period.
+    prof_every = max(1, int(os.environ.get("BPGPU_PROF_EVERY", str(len(ctxs) + 1))))
     noprof = bool(os.environ.get("BPGPU_BENCH_NOPROF"))
     def sampling_on():
+        # in the timed region a sampled step times its dominant kernel only (bpgpu_profile_select): one event pair = two
+        # barrier packets in that step's queue instead of twelve (a fully timed step in a 20-step run cost the run 4-5 %)
+        for c in ctxs:
+            c.profile_select(["verify_back"])
+        sample_period[0] = 0 if noprof else prof_every
+
+    def sampling_off():
+        sample_period[0] = 0
         for i, c in enumerate(ctxs):
-            c.profile_enable(not noprof and i % prof_every == 0)
+            c.profile_enable(False)
+            c.profile_select(None)
+            prof_state[i] = False
 
     for _ in range(max(a.warmup, len(ctxs))):
         step()
@@ -313,13 +334,18 @@ def main():
     # the checks above leave the GPU idle for milliseconds: the warm-up keeps submitting steps (untimed) for
     # BPGPU_WARM_SECONDS of wall time; timed() then hands the device over busy
     warm_s = float(os.environ.get("BPGPU_WARM_SECONDS", "0.3"))
+    sampling_on()      # the warm-up also fills the sampled contexts' event pools: no hipEventCreate inside the timed region
     tw = time.perf_counter()
     while time.perf_counter() - tw < warm_s:
         for _ in range(2 * len(ctxs)):
             step()
     sync_all()
+    for c in ctxs:
+        c.profile_read()     # discard the warm-up's timings; the events go back to the pools
+    sampling_off()
     counter[0] = 0
     dt = timed(lambda i: step(), a.steps, before=sampling_on)
+    sample_period[0] = 0      # (the per-context flags are cleared below, after the sample is read)
 
     def collect():
         acc = {}
@@ -339,8 +365,7 @@ def main():
             for c in ctxs:
                 c.profile_enable(True)
 
-        for c in ctxs:
-            c.profile_enable(False)
+        sampling_off()
         counter[0] = 0
         replay_steps = min(a.steps, 256)
         replay_dt = timed(lambda i: step(), replay_steps, before=all_on)
@@ -524,7 +549,7 @@ def main():
                     "timed": f"HIP-event pairs around every launch of every context in a replay of {replay_steps} steps right after the "
                              f"timed region (replay: {replay_dt / replay_steps * 1e3:.3f} ms/step)" if replay_dt else "timed-region sample",
                     "timed_region_sample": ({"avg_launch_ms": prof_sample[dom][0] / prof_sample[dom][1], "launches": prof_sample[dom][1],
-                                             "contexts_sampled": f"1 in {prof_every}"} if prof_sample.get(dom, (0, 0))[1] else None),
+                                             "steps_sampled": f"1 in {prof_every} (rotating over the contexts)"} if prof_sample.get(dom, (0, 0))[1] else None),
                     "note": "achieved = algorithmic bytes of the dominant kernel / its average launch duration (HIP events on the "
                             "launch stream, steps overlapping on the GPU).  The path is VALU-integer bound, not HBM bound: 252-bit "
                             "modular arithmetic spends ~1 650 instructions per 96 algorithmic bytes; see roofline_valu_issue"}

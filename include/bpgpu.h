@@ -63,9 +63,12 @@ int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
  * groups, 10 back (Horner pass | fixed-base MSMs), 11 verdict; 5 device transcript; 12..15 the stages of the
  * combined batch check (scalars + weights, proof-point MSM, generator MSM, tail).  Other launch paths: 6 fused Straus +
  * fixed-base launch, 1 fixed-base MSM, 2 point import, 3 Straus, 4 verify tail.  read() synchronises, returns sums
- * since the last read. */
+ * since the last read (at most 64 launches per kind are kept between two reads).  select() restricts the timing to the
+ * kinds of a bit mask (bit k = kind k; default all): an event pair is a barrier in the queue on either side of its kernel,
+ * so a caller that wants one kernel's duration out of a pipelined run pays for that kernel only. */
 #define BPGPU_PROF_KINDS 16
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
+int bpgpu_profile_select(bpgpu_ctx *ctx, uint32_t kind_mask);
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t launches[BPGPU_PROF_KINDS]);
 
 /* device memory plumbing */

@@ -36,13 +36,23 @@ struct bpgpu_ctx {
   bool latency_mode = false;      // bpgpu_set_latency_mode
   std::vector<hipEvent_t> prof_ev[BPGPU_PROF_KINDS];
   std::vector<hipEvent_t> prof_pool;   // recycled events
+  bool prof_skip[BPGPU_PROF_KINDS] = {};
+  uint32_t prof_mask = 0xffffffffu;    // bpgpu_profile_select
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
 };
 struct ProfScope {   // records start/stop events on `st` around a launch when profiling is on (events come from a per-context pool)
   bpgpu_ctx *c; int kind; hipStream_t st;
+  // start and stop marks of a kind alternate (scopes of one kind do not nest).  At most PROF_CAP timed launches per kind are
+  // kept between two reads: a long run samples its first launches instead of creating thousands of events inside the timed
+  // region (2 048 steps: 1 200 hipEventCreate calls on the sampled context cost the run 5 % of its throughput).
+  static constexpr size_t PROF_CAP = 64;
   static void mark(bpgpu_ctx *c, int kind, hipStream_t st) {
+    auto &v = c->prof_ev[kind];
+    if (!((c->prof_mask >> kind) & 1u)) return;
+    if (c->prof_skip[kind]) { c->prof_skip[kind] = false; return; }                       // the stop of a skipped start
+    if ((v.size() & 1) == 0 && v.size() >= 2 * PROF_CAP) { c->prof_skip[kind] = true; return; }
     hipEvent_t e = nullptr;
     if (!c->prof_pool.empty()) { e = c->prof_pool.back(); c->prof_pool.pop_back(); }
     else if (hipEventCreate(&e) != hipSuccess) return;
@@ -224,6 +234,14 @@ int bpgpu_profile_enable(bpgpu_ctx *ctx, int on) {
   if (!ctx) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->prof = on != 0;
+  return BPGPU_OK;
+}
+int bpgpu_profile_select(bpgpu_ctx *ctx, uint32_t kind_mask) {
+  if (!ctx) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  for (int k = 0; k < BPGPU_PROF_KINDS; k++)      // a pair may not straddle a change of the mask
+    if ((ctx->prof_ev[k].size() & 1) || ctx->prof_skip[k]) return BPGPU_E_ARG;
+  ctx->prof_mask = kind_mask;
   return BPGPU_OK;
 }
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t launches[BPGPU_PROF_KINDS]) {

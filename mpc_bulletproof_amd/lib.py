@@ -7,7 +7,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
+    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
@@ -145,6 +145,11 @@ class BpGpu:
 
     def profile_enable(self, on=True):
         self._ck(_lib.bpgpu_profile_enable(self.ctx, 1 if on else 0))
+
+    def profile_select(self, names=None):
+        """restrict the event timing to the named kinds (PROF_NAMES); None = all"""
+        mask = 0xffffffff if names is None else sum(1 << PROF_NAMES.index(n) for n in names)
+        self._ck(_lib.bpgpu_profile_select(self.ctx, C.c_uint32(mask)))
 
     def profile_read(self):
         ms = (C.c_double * PROF_KINDS)()
