@@ -150,10 +150,10 @@ __global__ void k_coeff_to_mont(Words8 *io, size_t n, int *bad) {
   for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
 }
 static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
-                        hipStream_t st) {
+                        hipStream_t st, int part_slot = 12) {
   size_t chunks = fixed_msm_chunks(g->c, n, nb);
   void *dpart = nullptr;
-  if (chunks > 1) CK(ws_get(ctx, 12, nb * chunks * sizeof(JacRaw), &dpart));
+  if (chunks > 1) CK(ws_get(ctx, part_slot, nb * chunks * sizeof(JacRaw), &dpart));
   fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart);
   return BPGPU_OK;
 }
@@ -991,7 +991,12 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   // back [Horner | fixed-base MSMs], verdict (k_ec.hip).  Every launch is on ctx->st.
   const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
   const bool no_wp = getenv("BPGPU_WINDOW_PARALLEL") && atoi(getenv("BPGPU_WINDOW_PARALLEL")) == 0;
-  if (!no_fuse && !no_wp && fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
+  // The generator half rides in the back launch when it is small (<= 16 384 (generator, window) pairs per proof, one chunk);
+  // otherwise -- few proofs of a mid-size circuit, or a table window the fused kernel is not built for -- it is its own
+  // chunked launch ahead of the Horner pass.  The window kernel walks a proof's points serially in every window lane: up to
+  // 256 proof points (the 2^14-shuffle's 32 809 take the Straus launches below).
+  const bool fused_fixed = fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np);
+  if (!no_fuse && !no_wp && nvar && (fused_fixed || nvar <= 256)) {
     void *dwp;
     CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
     VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc, ctx->latency_mode};
@@ -1007,8 +1012,10 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
       verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
     { ProfScope ps(ctx, 9, ctx->st);
       verify_wp_groups(ctx->st, v); }
+    if (!fused_fixed) { ProfScope ps(ctx, 1, ctx->st);
+      CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st, 23)); }
     { ProfScope ps(ctx, 10, ctx->st);
-      verify_wp_back(ctx->st, v, g->c, g->table, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
+      verify_wp_back(ctx->st, v, g->c, fused_fixed ? g->table : nullptr, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
     { ProfScope ps(ctx, 11, ctx->st);
       verify_wp_verdict(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
     return launch_ok(ctx);

@@ -521,6 +521,11 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
   if (wp_grouped()) { h.count = 64 / HG; h.stride = HG; h.dbl = SW * HG; }
   const unsigned hb = (unsigned)(quad ? (v.nb + 15) / 16 : (v.nb + 63) / 64);
   FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
+  if (!table) {   // the generator half ran as its own launch: Horner pass only
+    f.nb = 0;
+    launch_back<8>(st, h, hb, f, v.latency_mode);
+    return;
+  }
   if (c == 8) launch_back<8>(st, h, hb, f, v.latency_mode);
   else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode);
   else launch_back<20>(st, h, hb, f, v.latency_mode);
