@@ -1177,3 +1177,35 @@ def test_verify_batch_other_circuits_all_launch_variants(gpu, monkeypatch, kind,
             gpu.circuit_destroy(circ)
     for s in sessions:
         s.close()
+
+
+def test_profile_events_select_and_cap(gpu):
+    """bpgpu_profile_enable / _select / _read (the HIP-event timing bench.py's roofline uses): with a kind mask only the selected
+    launches are timed; at most 64 launches per kind are kept between two reads; verdicts are unaffected."""
+    recs, cap = bh.make_range_batch(8, 70, tamper={3})
+    sessions = [o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+    s0 = sessions[0]
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        pts = sc = ch = b""
+        for (proof, com), s in zip(recs, sessions):
+            k, p, q = bh.verify_inputs(proof, com)
+            pts, sc, ch = pts + p, sc + q, ch + s.challenges()
+        want = [1 if s.rc == 0 else 0 for s in sessions]
+        gpu.profile_enable(True)
+        ok, _, _ = gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
+        assert list(ok) == want
+        every = {n: c for n, (ms, c) in gpu.profile_read().items() if c}
+        assert {"verify_front", "verify_scalars", "verify_windows", "verify_groups", "verify_back", "verify_verdict"} <= set(every)
+        gpu.profile_select(["verify_back"])
+        for _ in range(70):
+            ok, _, _ = gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
+        assert list(ok) == want
+        only = {n: (ms, c) for n, (ms, c) in gpu.profile_read().items() if c}
+        assert set(only) == {"verify_back"} and only["verify_back"][1] == 64 and only["verify_back"][0] > 0
+        gpu.profile_select(None)
+    finally:
+        gpu.profile_enable(False)
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
