@@ -153,6 +153,11 @@ size_t bpgpu_gens_capacity(const bpgpu_gens *g);
  *   -- the generator part of prover.rs:465-494 and verifier.rs:525-530,541-544 */
 int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars,
                    uint8_t *out);
+/* the same with the scalars as they lie in the reference's memory (ark-ff Montgomery limbs, x * 2^256 mod n, 4 x u64 little
+ * endian; see the arkworks section below): converted on the device, no de-Montgomery per scalar on the host.  The 256
+ * lock-step provers of BASELINE configs[2] hand over 1.3 M witness and blinding scalars per batch this way. */
+int bpgpu_msm_gens_ark(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars_ark,
+                       uint8_t *out);
 
 /* ---- inner-product argument ------------------------------------------------------------------
  * InnerProductProof::fold_witness  -- src/inner_product_proof.rs:202-248
@@ -242,6 +247,11 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
                             const uint8_t *y_inv, const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R,
                             const uint8_t *a_O, const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs,
                             uint8_t *wV, bpgpu_prover **out);
+/* the same with every INPUT scalar (y, y_inv, z, a_L, a_R, a_O, s_L, s_R) in ark-ff Montgomery form; outputs as above */
+int bpgpu_r1cs_prover_polys_ark(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y,
+                                const uint8_t *y_inv, const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R,
+                                const uint8_t *a_O, const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs,
+                                uint8_t *wV, bpgpu_prover **out);
 int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, const uint8_t *x,
                            uint8_t *l_vec, uint8_t *r_vec);
 /* prover.rs:659-708 in one call with everything staying in HBM: evaluates l(x), r(x) (with the padding), forms

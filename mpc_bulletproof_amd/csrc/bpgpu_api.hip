@@ -746,7 +746,9 @@ void bpgpu_gens_destroy(bpgpu_ctx *ctx, bpgpu_gens *g) {
 }
 size_t bpgpu_gens_capacity(const bpgpu_gens *g) { return g ? g->cap : 0; }
 
-int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars, uint8_t *out) {
+// ark = the scalars are ark-ff Montgomery limbs (x 2^256 mod n, what the reference's Scalar holds in memory): converted in
+// place on the device (one multiplication per scalar) instead of one de-Montgomery per scalar on the host
+static int msm_gens_impl(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars, uint8_t *out, bool ark) {
   if (!ctx || !g || (nb && (!scalars || !out))) return BPGPU_E_ARG;
   if (n > g->cap) return BPGPU_E_GENS;
   if (!nb) return BPGPU_OK;
@@ -759,7 +761,8 @@ int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, con
   CK(ws_get(ctx, 5, nb * 64, &dout));
   CK(flag_reset(ctx));
   CK(h2d(ctx, dsc, scalars, tot * 32));
-  scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
+  if (ark) scalars_from_ark(ctx->st, (const Words8 *)dsc, (Words8 *)dsc, tot, ctx->d_flag);
+  else scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   CK(msm_gens_dev(ctx, g, nb, n, (uint32_t *)dsc, (JacRaw *)dres, ctx->st));
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb);
   CK(launch_ok(ctx));
@@ -769,6 +772,12 @@ int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, con
   CK(d2h(ctx, out, dout, nb * 64));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   return BPGPU_OK;
+}
+int bpgpu_msm_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars, uint8_t *out) {
+  return msm_gens_impl(ctx, g, nb, n, scalars, out, false);
+}
+int bpgpu_msm_gens_ark(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint8_t *scalars_ark, uint8_t *out) {
+  return msm_gens_impl(ctx, g, nb, n, scalars_ark, out, true);
 }
 
 /* ---------------------------------------------------------------- IPP */
@@ -1762,10 +1771,10 @@ struct bpgpu_prover {
   int32_t *polys = nullptr;   // [6][nb][n][9]
   Words8 *y = nullptr;        // nb
 };
-int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
-                            const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
-                            const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
-                            bpgpu_prover **out) {
+static int prover_polys_impl(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
+                             const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
+                             const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
+                             bpgpu_prover **out, bool ark) {
   if (!ctx || !c || !out || !nb || !y || !y_inv || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
   if (c->nchi) return BPGPU_E_ARG;      // the prover knows its gadget challenges when it builds the rows: numeric circuits only
   size_t n = c->n, m = c->m;
@@ -1792,7 +1801,8 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
       (rc = h2d(ctx, dz, z, nb * 32)) || (rc = h2d(ctx, dL, a_L, tot * 32)) || (rc = h2d(ctx, dR, a_R, tot * 32)) ||
       (rc = h2d(ctx, dO, a_O, tot * 32)) || (rc = h2d(ctx, dsL, s_L, tot * 32)) || (rc = h2d(ctx, dsR, s_R, tot * 32)))
     return fail(rc);
-  scalars_check(ctx->st, w, 3 * nb + 5 * tot, ctx->d_flag);
+  if (ark) scalars_from_ark(ctx->st, w, w, 3 * nb + 5 * tot, ctx->d_flag);
+  else scalars_check(ctx->st, w, 3 * nb + 5 * tot, ctx->d_flag);
   if (hipMemcpyAsync(s->y, dy, nb * 32, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
   CircuitDev cd = circuit_dev(c);
   zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);   // (parametric circuits are rejected above: the prover builds numeric rows)
@@ -1806,6 +1816,18 @@ int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, c
   if (hipStreamSynchronize(ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
   *out = s;
   return BPGPU_OK;
+}
+int bpgpu_r1cs_prover_polys(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
+                            const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
+                            const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
+                            bpgpu_prover **out) {
+  return prover_polys_impl(ctx, c, nb, y, y_inv, z, a_L, a_R, a_O, s_L, s_R, t_coeffs, wV, out, false);
+}
+int bpgpu_r1cs_prover_polys_ark(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
+                                const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
+                                const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
+                                bpgpu_prover **out) {
+  return prover_polys_impl(ctx, c, nb, y, y_inv, z, a_L, a_R, a_O, s_L, s_R, t_coeffs, wV, out, true);
 }
 int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, const uint8_t *x, uint8_t *l_vec,
                            uint8_t *r_vec) {

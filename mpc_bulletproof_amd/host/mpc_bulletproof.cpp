@@ -7,6 +7,9 @@
 #include <chrono>
 #include <exception>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 
@@ -185,6 +188,72 @@ StarkPoint StarkPoint::generator() {
 }
 
 // ================================================================ host parallelism ================
+// A persistent pool: creating and joining 16 threads costs ~0.4 ms, and one prove_batch call runs a dozen parallel loops.
+// Worker t always takes the t-th contiguous slice of a loop, so the thread that built a prover's constraint system is the
+// one that later packs and frees it (its allocations stay in that thread's malloc arena).  A loop started from inside a
+// worker runs serially.
+namespace {
+class Pool {
+ public:
+  explicit Pool(unsigned n) : nworkers_(n > 1 ? n - 1 : 0) {
+    for (unsigned t = 0; t < nworkers_; t++) th_.emplace_back([this, t] { worker(t + 1); });
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> lk(mu_); stop_ = true; gen_++; }
+    cv_.notify_all();
+    for (auto &x : th_) x.join();
+  }
+  unsigned width() const { return nworkers_ + 1; }
+  static bool in_worker() { return tl_worker_; }
+  // slices [n t / nt, n (t + 1) / nt) for t < nt = min(n, width); the caller takes slice 0
+  void run(size_t n, const std::function<void(size_t)> &f) {
+    std::lock_guard<std::mutex> one(run_mu_);             // one loop at a time (callers on other threads queue up)
+    const size_t nt = n < width() ? n : width();
+    std::vector<std::exception_ptr> err(nt);
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      n_ = n; nt_ = nt; f_ = &f; err_ = err.data(); pending_ = nt - 1; gen_++;
+    }
+    cv_.notify_all();
+    slice(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return pending_ == 0; });
+    f_ = nullptr;
+    lk.unlock();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+  }
+ private:
+  void slice(size_t t) {
+    try { for (size_t i = n_ * t / nt_; i < n_ * (t + 1) / nt_; i++) (*f_)(i); } catch (...) { err_[t] = std::current_exception(); }
+  }
+  void worker(unsigned t) {
+    tl_worker_ = true;
+    uint64_t seen = 0;
+    for (;;) {
+      std::unique_lock<std::mutex> lk(mu_);
+      cv_.wait(lk, [&] { return gen_ != seen; });
+      seen = gen_;
+      if (stop_) return;
+      if (t >= nt_) continue;                              // this loop is narrower than the pool
+      lk.unlock();
+      slice(t);
+      lk.lock();
+      if (--pending_ == 0) done_.notify_one();
+    }
+  }
+  unsigned nworkers_;
+  std::vector<std::thread> th_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_;
+  uint64_t gen_ = 0;
+  bool stop_ = false;
+  size_t n_ = 0, nt_ = 0, pending_ = 0;
+  const std::function<void(size_t)> *f_ = nullptr;
+  std::exception_ptr *err_ = nullptr;
+  static thread_local bool tl_worker_;
+};
+thread_local bool Pool::tl_worker_ = false;
+}  // namespace
 void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t min_n) {
   static const unsigned nthreads = [] {
     unsigned hw = std::thread::hardware_concurrency();
@@ -192,16 +261,16 @@ void parallel_for(size_t n, const std::function<void(size_t)> &f, size_t min_n) 
     if (const char *e = getenv("BPH_THREADS")) { int v = atoi(e); if (v > 0) t = (unsigned)v; }
     return t;
   }();
-  if (n < min_n || nthreads <= 1) { for (size_t i = 0; i < n; i++) f(i); return; }
-  const size_t nt = n < nthreads ? n : nthreads;
-  std::vector<std::thread> th;
-  std::vector<std::exception_ptr> err(nt);
-  for (size_t t = 0; t < nt; t++)
-    th.emplace_back([&, t] {
-      try { for (size_t i = n * t / nt; i < n * (t + 1) / nt; i++) f(i); } catch (...) { err[t] = std::current_exception(); }
-    });
-  for (auto &x : th) x.join();
-  for (auto &e : err) if (e) std::rethrow_exception(e);
+  if (n < min_n || nthreads <= 1 || Pool::in_worker()) { for (size_t i = 0; i < n; i++) f(i); return; }
+  // lives until process exit (no static-destruction-order races with worker threads); a forked child starts its own
+  static std::mutex pool_mu;
+  static Pool *pool = nullptr;
+  static pid_t pool_pid = 0;
+  {
+    std::lock_guard<std::mutex> lk(pool_mu);
+    if (!pool || pool_pid != getpid()) { pool = new Pool(nthreads); pool_pid = getpid(); }
+  }
+  pool->run(n, f);
 }
 
 // ================================================================ byte packing helpers ============
@@ -230,6 +299,8 @@ struct RawBuf {
   }
 };
 inline void pack_range(uint8_t *dst, const Scalar *src, size_t n) { for (size_t i = 0; i < n; i++) src[i].to_bytes_le(dst + 32 * i); }
+// the bulk operands of the prover (witness and blinding vectors) go to the device in their in-memory Montgomery form
+inline void pack_range_ark(uint8_t *dst, const Scalar *src, size_t n) { for (size_t i = 0; i < n; i++) src[i].to_ark_le(dst + 32 * i); }
 constexpr size_t PACK_CHUNK = 4096;   // scalars per parallel work item
 std::vector<uint8_t> pack_scalars(const std::vector<Scalar> &v) {
   std::vector<uint8_t> o(v.size() * 32);
@@ -1002,16 +1073,16 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
         memset(row(w) + 64, 0, lo * 32);                             // G_0..G_{lo-1}
         memset(row(w) + (2 + n) * 32, 0, lo * 32);                   // H_0..H_{lo-1}
       }
-      ib[p].to_bytes_le(row(0) + 32); ob[p].to_bytes_le(row(1) + 32); sb[p].to_bytes_le(row(2) + 32);
-      pack_range(row(0) + (2 + lo) * 32, cs[p]->a_L.data() + lo, hi - lo);
-      pack_range(row(0) + (2 + n + lo) * 32, cs[p]->a_R.data() + lo, hi - lo);
-      pack_range(row(1) + (2 + lo) * 32, cs[p]->a_O.data() + lo, hi - lo);
+      ib[p].to_ark_le(row(0) + 32); ob[p].to_ark_le(row(1) + 32); sb[p].to_ark_le(row(2) + 32);
+      pack_range_ark(row(0) + (2 + lo) * 32, cs[p]->a_L.data() + lo, hi - lo);
+      pack_range_ark(row(0) + (2 + n + lo) * 32, cs[p]->a_R.data() + lo, hi - lo);
+      pack_range_ark(row(1) + (2 + lo) * 32, cs[p]->a_O.data() + lo, hi - lo);
       memset(row(1) + (2 + n + lo) * 32, 0, (hi - lo) * 32);
-      pack_range(row(2) + (2 + lo) * 32, s_L[p].data() + lo, hi - lo);
-      pack_range(row(2) + (2 + n + lo) * 32, s_R[p].data() + lo, hi - lo);
+      pack_range_ark(row(2) + (2 + lo) * 32, s_L[p].data() + lo, hi - lo);
+      pack_range_ark(row(2) + (2 + n + lo) * 32, s_R[p].data() + lo, hi - lo);
     });
     std::vector<uint8_t> o(nb * 3 * 64);
-    d.check(bpgpu_msm_gens(d.ctx(), gens, nb * 3, n, bytes, o.data()), "bpgpu_msm_gens");
+    d.check(bpgpu_msm_gens_ark(d.ctx(), gens, nb * 3, n, bytes, o.data()), "bpgpu_msm_gens_ark");   // zero limbs = 0 in either form
     for (size_t p = 0; p < nb; p++) {
       StarkPoint *dst[3] = {which_phase == 1 ? &proofs[p].A_I1 : &proofs[p].A_I2, which_phase == 1 ? &proofs[p].A_O1 : &proofs[p].A_O2,
                             which_phase == 1 ? &proofs[p].S1 : &proofs[p].S2};
@@ -1066,16 +1137,17 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     uint8_t *wit = buf.ensure(5 * plane + 1);
     uint8_t *paL = wit, *paR = wit + plane, *paO = wit + 2 * plane, *psL = wit + 3 * plane, *psR = wit + 4 * plane;
     parallel_for(nb, [&](size_t p) {
-      pack_range(paL + p * n * 32, cs[p]->a_L.data(), n);
-      pack_range(paR + p * n * 32, cs[p]->a_R.data(), n);
-      pack_range(paO + p * n * 32, cs[p]->a_O.data(), n);
-      pack_range(psL + p * n * 32, s_L[p].data(), n);
-      pack_range(psR + p * n * 32, s_R[p].data(), n);
+      pack_range_ark(paL + p * n * 32, cs[p]->a_L.data(), n);
+      pack_range_ark(paR + p * n * 32, cs[p]->a_R.data(), n);
+      pack_range_ark(paO + p * n * 32, cs[p]->a_O.data(), n);
+      pack_range_ark(psL + p * n * 32, s_L[p].data(), n);
+      pack_range_ark(psR + p * n * 32, s_R[p].data(), n);
     });
-    auto by = pack_scalars(y), byi = pack_scalars(y_inv), bz = pack_scalars(z);
-    int rc = bpgpu_r1cs_prover_polys(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), paL, paR, paO, psL, psR,
-                                     tco.data(), wVb.data(), &ps);
-    if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys"); }
+    std::vector<uint8_t> by(nb * 32), byi(nb * 32), bz(nb * 32);
+    pack_range_ark(by.data(), y.data(), nb); pack_range_ark(byi.data(), y_inv.data(), nb); pack_range_ark(bz.data(), z.data(), nb);
+    int rc = bpgpu_r1cs_prover_polys_ark(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), paL, paR, paO, psL, psR,
+                                         tco.data(), wVb.data(), &ps);
+    if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys_ark"); }
   }
   lap("prove: prover_polys");
   auto t = unpack_scalars(tco.data(), nb * 6);   // per prover: t1 t2 t3 t4 t5 t6

@@ -42,6 +42,9 @@ class Scalar {
   static Scalar from_bytes_le(const uint8_t b[32]);        // canonical; throws ProofException(FormatError)
   static Scalar from_le_bytes_mod_order_wide(const uint8_t b[64]);
   void to_bytes_le(uint8_t out[32]) const;
+  // the limbs as they lie in memory (= ark-ff's Fp256<MontBackend<_, 4>>: x * 2^256 mod n, little endian): what the
+  // *_ark entry points of the C ABI take -- no de-Montgomery on the host
+  void to_ark_le(uint8_t out[32]) const { memcpy(out, v_, 32); }
   void to_bytes_be(uint8_t out[32]) const;                 // Scalar::to_bytes_be (proof wire format)
   static Scalar from_be_bytes_mod_order(const uint8_t b[32]);
   std::array<uint8_t, 32> to_bytes() const { std::array<uint8_t, 32> o; to_bytes_le(o.data()); return o; }

@@ -9,9 +9,9 @@ SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
     "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
-    "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_fold_witness",
+    "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
-    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
@@ -254,9 +254,11 @@ class BpGpu:
     def gens_destroy(self, h):
         _lib.bpgpu_gens_destroy(self.ctx, h)
 
-    def msm_gens(self, gens, nb, n, scalars):
+    def msm_gens(self, gens, nb, n, scalars, ark=False):
+        """ark=True: the scalars are ark-ff Montgomery limbs (x * 2^256 mod n), converted on the device"""
         o = _out(64 * nb)
-        self._ck(_lib.bpgpu_msm_gens(self.ctx, gens, C.c_size_t(nb), C.c_size_t(n), _buf(scalars), o))
+        fn = _lib.bpgpu_msm_gens_ark if ark else _lib.bpgpu_msm_gens
+        self._ck(fn(self.ctx, gens, C.c_size_t(nb), C.c_size_t(n), _buf(scalars), o))
         return bytes(o)[:64 * nb]
 
     # ---- IPP
@@ -366,14 +368,16 @@ class BpGpu:
 
         return cut(wL, n_mul), cut(wR, n_mul), cut(wO, n_mul), cut(wV, m), bytes(wc)[:32 * nb]
 
-    def r1cs_prover_polys(self, circuit, nb, n, m, y, y_inv, z, a_L, a_R, a_O, s_L, s_R):
-        """prover.rs:587-619 for nb provers of one circuit -> (t_coeffs nb x 6 x 32 B, wV nb x m x 32 B, prover handle)"""
+    def r1cs_prover_polys(self, circuit, nb, n, m, y, y_inv, z, a_L, a_R, a_O, s_L, s_R, ark=False):
+        """prover.rs:587-619 for nb provers of one circuit -> (t_coeffs nb x 6 x 32 B, wV nb x m x 32 B, prover handle);
+        ark=True: every input scalar in ark-ff Montgomery form"""
         for v in (a_L, a_R, a_O, s_L, s_R):
             if len(v) != 32 * nb * n:
                 raise BpGpuError(E_LEN, "r1cs_prover_polys: length mismatch")
         t, wv, h = _out(32 * 6 * nb), _out(32 * nb * max(m, 1)), C.c_void_p()
-        self._ck(_lib.bpgpu_r1cs_prover_polys(self.ctx, circuit, C.c_size_t(nb), _buf(y), _buf(y_inv), _buf(z), _buf(a_L), _buf(a_R),
-                                              _buf(a_O), _buf(s_L), _buf(s_R), t, wv, C.byref(h)))
+        fn = _lib.bpgpu_r1cs_prover_polys_ark if ark else _lib.bpgpu_r1cs_prover_polys
+        self._ck(fn(self.ctx, circuit, C.c_size_t(nb), _buf(y), _buf(y_inv), _buf(z), _buf(a_L), _buf(a_R),
+                    _buf(a_O), _buf(s_L), _buf(s_R), t, wv, C.byref(h)))
         return bytes(t)[:32 * 6 * nb], bytes(wv)[:32 * nb * m], h
 
     def r1cs_prover_eval(self, prover, nb, padded_n, x):

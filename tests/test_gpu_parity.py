@@ -167,6 +167,12 @@ def test_msm_gens(gpu, c):
             pts = B + B + Gp[:64 * n] + Hp[:64 * n]
             want = o.msm_batch(sc, pts * nb, nb, 2 + 2 * n)
             assert gpu.msm_gens(g, nb, n, sc) == want
+            # ark-ff Montgomery limbs in (x * 2^256 mod n), same sums out; a limb vector >= n is rejected
+            sc_ark = b"".join((int.from_bytes(sc[i:i + 32], "little") * (1 << 256) % N).to_bytes(32, "little") for i in range(0, len(sc), 32))
+            assert gpu.msm_gens(g, nb, n, sc_ark, ark=True) == want
+        import mpc_bulletproof_amd as m
+        with pytest.raises(m.BpGpuError):
+            gpu.msm_gens(g, 1, 0, N.to_bytes(32, "little") + bytes(32), ark=True)
         # edge scalars: 0, 1, n-1 and equal scalars on B == B_blinding (duplicate points)
         sc = o.scalars([5, 5] + [0, 1, N - 1, 2] * 8)
         assert gpu.msm_gens(g, 1, 16, sc) == o.msm(sc, B + B + Gp + Hp)
@@ -474,6 +480,13 @@ def test_prover_polys_and_eval_unit_parity(gpu, kind, param, nb):
                                          pk(wit["aL"]), pk(wit["aR"]), pk(wit["aO"]), pk(wit["sL"]), pk(wit["sR"]))
         lv, rv = gpu.r1cs_prover_eval(h, nb, padded, pk([xs]))
         gpu.prover_destroy(h)
+        # the same call with every input in ark-ff Montgomery form (x * 2^256 mod n as 32 little-endian bytes)
+        ark = lambda rows: b"".join((v * (1 << 256) % N_).to_bytes(32, "little") for r in rows for v in r)       # noqa: E731
+        t2, wv2, h2 = gpu.r1cs_prover_polys(circ, nb, n, m, ark([ys]), ark([[pow(y, -1, N_) for y in ys]]), ark([zs]),
+                                            ark(wit["aL"]), ark(wit["aR"]), ark(wit["aO"]), ark(wit["sL"]), ark(wit["sR"]), ark=True)
+        lv2, rv2 = gpu.r1cs_prover_eval(h2, nb, padded, pk([xs]))
+        gpu.prover_destroy(h2)
+        assert (t2, wv2, lv2, rv2) == (t, wv, lv, rv)
         for p in range(nb):
             y, z, x = ys[p], zs[p], xs[p]
             wL, wR, wO, wV, _ = s.flatten(o.s2b(z))
