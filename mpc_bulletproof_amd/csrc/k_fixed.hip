@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
 }
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
   size_t total = (1 + n0) * (252 / c + 1);
-  size_t by_work = (total + 511) / 512, by_fill = (2048 + nmsm - 1) / (nmsm ? nmsm : 1);
+  static const size_t fill = getenv("BPGPU_IPP_FILL") ? (size_t)atoi(getenv("BPGPU_IPP_FILL")) : 1024;   // blocks wanted on the chip (2 048: 7 % slower rounds for 256 provers -- the 7-level block sum weighs more on shorter lanes)
+  size_t by_work = (total + 511) / 512, by_fill = (fill + nmsm - 1) / (nmsm ? nmsm : 1);
   size_t ch = by_work < by_fill ? by_work : by_fill;
   return ch ? ch : 1;
 }
