@@ -130,7 +130,9 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_
 // into 256 coarse bins (top 8 bits of the bucket id) with per-tile histograms and ranks kept in LDS -- a tile writes
 // ~8 consecutive entries per bin -- and every (segment, bin) is then counting-sorted by one block entirely in LDS
 // (<= 128 fine buckets), which also yields the per-bucket counts.  Order inside a bucket is irrelevant (the sum commutes).
-constexpr int RS_BINS = 256, RS_TPB = 256, RS_PER = 8, RS_TILE = RS_TPB * RS_PER;
+// Tile = 8 192 keys: a tile writes ~32 consecutive entries per bin (128-byte runs; with 2 048-key tiles the 32-byte runs made
+// every store a partial line).
+constexpr int RS_BINS = 256, RS_TPB = 256, RS_PER = 32, RS_TILE = RS_TPB * RS_PER;
 __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys, size_t n, int half, int shift, size_t tiles,
                                                             uint32_t *gh) {
   __shared__ uint32_t h[RS_BINS];
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys
   h[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t base = (uint32_t)(seg * (size_t)half);
-#pragma unroll
+#pragma unroll 8
   for (int j = 0; j < RS_PER; j++) {
     size_t r = tile * RS_TILE + (size_t)j * RS_TPB + threadIdx.x;
     if (r < n) {
@@ -156,7 +158,7 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *k
   cur[threadIdx.x] = goff[(seg * RS_BINS + threadIdx.x) * tiles + tile];
   __syncthreads();
   const uint32_t base = (uint32_t)(seg * (size_t)half), fmask = (1u << shift) - 1;
-#pragma unroll
+#pragma unroll 8
   for (int j = 0; j < RS_PER; j++) {
     size_t r = tile * RS_TILE + (size_t)j * RS_TPB + threadIdx.x;
     if (r < n) {
@@ -207,11 +209,59 @@ __global__ void __launch_bounds__(256) k_pip_taskdesc(const uint32_t *toffsets, 
   if (b >= nb) return;
   for (uint32_t t = toffsets[b]; t < toffsets[b + 1]; t++) task_bucket[t] = (uint32_t)b;
 }
+// Tasks of equal length side by side.  Bucket sizes scatter around n / 2^(c-1) (2^20 terms at c = 16: 32 +- 6), so in
+// bucket order the 64 tasks of a wave held anything from 1 to 16 entries and the wave ran for the longest: a third of the
+// lane-time of the biggest launch of a large MSM was idle.  A counting sort of the task ids by length (17 classes, longest
+// first, block-local histograms in LDS) makes the waves uniform; partial[] stays indexed by task id, so the merge is unchanged.
+constexpr int TL_TPB = 256, TL_CLASSES = PIP_TASK + 1;
+__device__ __forceinline__ uint32_t pip_task_len(uint32_t t, const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket) {
+  const uint32_t b = task_bucket[t], slice = t - toffsets[b];
+  const uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1];
+  const uint32_t len = lo < end ? end - lo : 0;             // (an empty bucket still owns one, empty, task)
+  return len < PIP_TASK ? len : PIP_TASK;
+}
+// a block walks a tile of TL_TILE tasks: 17 global atomics per 4 096 tasks (one block per 256 tasks spent 60 us of a
+// 2^20-term MSM queueing on the 17 counters)
+constexpr int TL_TILE = 4096;
+__global__ void __launch_bounds__(TL_TPB) k_pip_tasklen_hist(const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket,
+                                                             size_t nbk, uint32_t *hist) {
+  __shared__ uint32_t h[TL_CLASSES];
+  if (threadIdx.x < TL_CLASSES) h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t ntasks = toffsets[nbk], t0 = (size_t)blockIdx.x * TL_TILE;
+  for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB)
+    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket)], 1u);
+  __syncthreads();
+  if (threadIdx.x < TL_CLASSES && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// cursor: TL_CLASSES zeroed counters; perm[position] = task id, classes in descending length
+__global__ void __launch_bounds__(TL_TPB) k_pip_task_scatter(const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket,
+                                                             size_t nbk, const uint32_t *hist, uint32_t *cursor, uint32_t *perm) {
+  __shared__ uint32_t h[TL_CLASSES], base[TL_CLASSES];
+  if (threadIdx.x < TL_CLASSES) h[threadIdx.x] = 0;
+  __syncthreads();
+  const size_t ntasks = toffsets[nbk], t0 = (size_t)blockIdx.x * TL_TILE;
+  for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB)
+    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket)], 1u);
+  __syncthreads();
+  if (threadIdx.x < TL_CLASSES) {
+    uint32_t before = 0;
+    for (int k = TL_CLASSES - 1; k > (int)threadIdx.x; k--) before += hist[k];
+    base[threadIdx.x] = before + (h[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]) : 0u);
+    h[threadIdx.x] = 0;                                     // second pass: ranks inside the block's reservation
+  }
+  __syncthreads();
+  for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB) {
+    const uint32_t len = pip_task_len((uint32_t)t, offsets, toffsets, task_bucket);
+    perm[base[len] + atomicAdd(&h[len], 1u)] = (uint32_t)t;
+  }
+}
 __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, const uint32_t *offsets, const uint32_t *sorted,
                                                            const uint32_t *toffsets, const uint32_t *task_bucket, size_t nbk,
-                                                           JacRaw *partial) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= toffsets[nbk]) return;
+                                                           const uint32_t *perm, JacRaw *partial) {
+  const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= toffsets[nbk]) return;
+  const size_t t = perm ? perm[id] : id;
   uint32_t b = task_bucket[t], slice = (uint32_t)t - toffsets[b];
   uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1], hi = lo + PIP_TASK < end ? lo + PIP_TASK : end;
   Jac acc = jac_inf();
@@ -261,7 +311,7 @@ __global__ void __launch_bounds__(64) k_pip_merge(const uint32_t *toffsets, cons
   raw_store(&buckets[b], acc);
 }
 // block per queued bucket (the grid is the upper bound total_tasks / PIP_HEAVY; excess blocks exit)
-constexpr int PH_TPB = 128;
+constexpr int PH_TPB = 64;    // one wave per queued bucket (128 threads: 7 tree levels for ~32 partials and twice the waves: 172 us at 2^20 terms)
 __global__ void __launch_bounds__(PH_TPB) k_pip_merge_heavy(const uint32_t *toffsets, const JacRaw *partial,
                                                             const uint32_t *heavy_list, const uint32_t *heavy_count,
                                                             JacRaw *buckets) {
@@ -346,7 +396,7 @@ static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
   size_t base = al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-                al(ninst * W * sizeof(JacRaw)) * 65 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4);
+                al(ninst * W * sizeof(JacRaw)) * 65 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(256);
   if (pip_two_level(ninst, n, c)) {
     size_t ngh = ninst * W * RS_BINS * ((n + RS_TILE - 1) / RS_TILE);
     base += al((ngh + 1) * 4) * 2 + al((ngh / SCAN_TILE + 2) * 4) + al(tot * W * 4) + al(tot * W);
@@ -379,6 +429,8 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   JacRaw *win_part = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw)) * 64;     // <= 64 chunks per window
   uint32_t *heavy = (uint32_t *)p; p += al(mt / PIP_HEAVY * 4 + 8);              // [0] = count, [2..] = bucket ids
   uint32_t *tile_tmp = (uint32_t *)p; p += al((nbk / SCAN_TILE + 2) * 4);
+  uint32_t *task_perm = (uint32_t *)p; p += al(mt * 4);
+  uint32_t *tl_hist = (uint32_t *)p; p += al(256);                               // [0, 17) histogram, [32, 49) cursors
   if (pip_two_level(ninst, n, c)) {
     // LDS-staged two-level counting sort: digits (no atomics) -> coarse histograms per tile -> scan -> coarse scatter ->
     // per-(segment, bin) fine sort, which also produces the bucket counts
@@ -406,8 +458,16 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   pip_scan(st, tcount, toffsets, nullptr, nbk, tile_tmp);
   hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
+  static const bool by_len = !(getenv("BPGPU_PIP_TASK_SORT") && atoi(getenv("BPGPU_PIP_TASK_SORT")) == 0);
+  const bool sort_tasks = by_len && tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
+  if (sort_tasks) {
+    (void)hipMemsetAsync(tl_hist, 0, 256, st);
+    hipLaunchKernelGGL(k_pip_tasklen_hist, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk, tl_hist);
+    hipLaunchKernelGGL(k_pip_task_scatter, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk,
+                       tl_hist, tl_hist + 32, task_perm);
+  }
   hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
-                     nbk, partial);
+                     nbk, sort_tasks ? task_perm : (const uint32_t *)nullptr, partial);
   (void)hipMemsetAsync(heavy, 0, 8, st);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy);
   hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy, buckets);
