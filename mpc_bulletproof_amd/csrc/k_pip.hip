@@ -350,6 +350,104 @@ __global__ void __launch_bounds__(PW_TPB) k_pip_window(PipParams pp, const JacRa
   Jac acc = block_sum<PW_TPB>(jac_add(ws, sm), smem);
   if (tid == 0) raw_store(&win_out[((size_t)inst * pp.W + w) * chunks + ch], acc);
 }
+// ---- the same weighted sum without any per-lane scalar multiplication (the default): two stages of additions only.
+// Stage A, one WAVE per chunk of 64 L buckets: lane l sums its L buckets (run_l, ws_l as above); the weight of lane l's run inside
+// the chunk is l L, and sum_l l run_l = sum_{l >= 1} Suf_l with Suf the inclusive suffix sums of run over the lanes (six
+// shuffle-add steps); so the chunk contributes  W_ch = sum_l [ws_l + L (l >= 1 ? Suf_l : 0)]  (log2 L doublings per lane, one
+// butterfly) and  R_ch = Suf_0.  Stage B, one block of 64 QUADS per window (ec29_quad.cuh; the chunks' offsets):
+// S = sum_ch W_ch + per_chunk sum_{ch >= 1} SufR_ch  -- a suffix scan over the chunks, log2(per_chunk) doublings, one tree.
+// 31 dependent lane operations + ~25 quad operations against 16 + 32 + 7 with the double-and-add offset: 0.40 -> 0.22 ms at 2^20 terms.
+__device__ __forceinline__ Jac jac_shfl_down(const Jac &a, int off) {
+  Jac r;
+#pragma unroll
+  for (int t = 0; t < NL; t++) {
+    r.X.v[t] = __shfl_down(a.X.v[t], off, 64);
+    r.Y.v[t] = __shfl_down(a.Y.v[t], off, 64);
+    r.Z.v[t] = __shfl_down(a.Z.v[t], off, 64);
+  }
+  return r;
+}
+__global__ void __launch_bounds__(64) k_pip_window_a(PipParams pp, const JacRaw *buckets, JacRaw *part, int chunks) {
+  const int w = blockIdx.x, l = threadIdx.x, ch = blockIdx.z;
+  const size_t seg = (size_t)blockIdx.y * pp.W + w;
+  const int per_chunk = pp.half / chunks, L = per_chunk / 64;      // L = 2^k >= 1
+  const JacRaw *B = buckets + seg * pp.half + (size_t)ch * per_chunk + (size_t)l * L;
+  Jac run = jac_inf(), ws = jac_inf();
+#pragma unroll 1
+  for (int j = L - 1; j >= 0; j--) {
+    run = jac_add(run, raw_load(&B[j]));
+    ws = jac_add(ws, run);
+  }
+  Jac suf = run;
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {
+    Jac v = jac_shfl_down(suf, off);
+    suf = jac_add(suf, jac_select(l + off < 64, v, jac_inf()));
+  }
+  Jac y = jac_select(l >= 1, suf, jac_inf());
+#pragma unroll 1
+  for (int i = 1; i < L; i <<= 1) y = jac_dbl(y);
+  Jac v = jac_add(ws, y);
+#pragma unroll 1
+  for (int off = 32; off > 0; off >>= 1) {
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(v.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(v.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(v.Z.v[t], off, 64);
+    }
+    v = jac_add(v, q);
+  }
+  if (l == 0) {
+    raw_store(&part[seg * 2 * chunks + ch], v);
+    raw_store(&part[seg * 2 * chunks + chunks + ch], suf);
+  }
+}
+__global__ void __launch_bounds__(256) k_pip_window_b(PipParams pp, const JacRaw *part, JacRaw *win, int chunks) {
+  __shared__ int32_t sm[27 * 64];
+  const size_t seg = blockIdx.x;
+  const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
+  const bool live = qd < chunks;
+  const int per_chunk = pp.half / chunks;
+  auto put = [&](int slot, const Jac &a) {
+#pragma unroll
+    for (int t = 0; t < NL; t++) { sm[t * 64 + slot] = a.X.v[t]; sm[(NL + t) * 64 + slot] = a.Y.v[t]; sm[(2 * NL + t) * 64 + slot] = a.Z.v[t]; }
+  };
+  auto get = [&](int slot) {
+    Jac a;
+#pragma unroll
+    for (int t = 0; t < NL; t++) { a.X.v[t] = sm[t * 64 + slot]; a.Y.v[t] = sm[(NL + t) * 64 + slot]; a.Z.v[t] = sm[(2 * NL + t) * 64 + slot]; }
+    return a;
+  };
+  const JacT Wq = jact_from_jac(live ? raw_load(&part[seg * 2 * chunks + qd]) : jac_inf());
+  JacT suf = jact_from_jac(live ? raw_load(&part[seg * 2 * chunks + chunks + qd]) : jac_inf());
+#pragma unroll 1
+  for (int off = 1; off < 64; off <<= 1) {          // inclusive suffix sums of R over the chunks (Hillis-Steele through LDS)
+    if (role == 0) put(qd, jact_to_jac(suf));
+    __syncthreads();
+    const Jac o = qd + off < 64 ? get(qd + off) : jac_inf();
+    __syncthreads();
+    suf = q4_add(suf, jact_from_jac(o), role);
+  }
+  JacT y = jact_select(qd >= 1, suf, jact_inf());
+#pragma unroll 1
+  for (int i = 1; i < per_chunk; i <<= 1) y = q4_dbl(y, role);
+  JacT v = q4_add(Wq, y, role);
+#pragma unroll 1
+  for (int s2 = 32; s2 > 0; s2 >>= 1) {
+    if (role == 0 && qd >= s2 && qd < 2 * s2) put(qd - s2, jact_to_jac(v));
+    __syncthreads();
+    if (qd < s2) v = q4_add(v, jact_from_jac(get(qd)), role);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) raw_store(&win[seg], jact_to_jac(v));
+}
+static int pip_window_ab_chunks(int half) {
+  int chunks = half / 256;                           // L = 4 buckets per lane ...
+  if (chunks > 64) chunks = 64;                      // ... more when the window has more than 64 x 256 buckets
+  return chunks < 1 ? 1 : chunks;
+}
 static int pip_window_chunks(int half, size_t ninst, int W) {
   int chunks = 1;
   while (half / (chunks * 2) >= PW_TPB * 4 && ninst * (size_t)W * (size_t)(chunks * 2) <= 8192) chunks *= 2;   // >= 4 buckets per lane
@@ -396,7 +494,7 @@ static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
   size_t base = al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-                al(ninst * W * sizeof(JacRaw)) * 65 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(256);
+                al(ninst * W * sizeof(JacRaw)) * 129 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(256);
   if (pip_two_level(ninst, n, c)) {
     size_t ngh = ninst * W * RS_BINS * ((n + RS_TILE - 1) / RS_TILE);
     base += al((ngh + 1) * 4) * 2 + al((ngh / SCAN_TILE + 2) * 4) + al(tot * W * 4) + al(tot * W);
@@ -426,7 +524,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   JacRaw *partial = (JacRaw *)p; p += al(mt * sizeof(JacRaw));
   JacRaw *buckets = (JacRaw *)p; p += al(nbk * sizeof(JacRaw));
   JacRaw *win = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw));
-  JacRaw *win_part = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw)) * 64;     // <= 64 chunks per window
+  JacRaw *win_part = (JacRaw *)p; p += al(ninst * W * sizeof(JacRaw)) * 128;    // <= 64 chunks per window, two points each
   uint32_t *heavy = (uint32_t *)p; p += al(mt / PIP_HEAVY * 4 + 8);              // [0] = count, [2..] = bucket ids
   uint32_t *tile_tmp = (uint32_t *)p; p += al((nbk / SCAN_TILE + 2) * 4);
   uint32_t *task_perm = (uint32_t *)p; p += al(mt * 4);
@@ -471,12 +569,19 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   (void)hipMemsetAsync(heavy, 0, 8, st);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy);
   hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy, buckets);
-  const int chunks = pip_window_chunks(pp.half, ninst, pp.W);
-  if (chunks > 1) {
-    hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, chunks), dim3(PW_TPB), 0, st, pp, buckets, win_part, chunks);
-    segmented_sum(st, win_part, win, ninst * W, chunks);
+  static const bool win_ab = !(getenv("BPGPU_PIP_WINDOW_AB") && atoi(getenv("BPGPU_PIP_WINDOW_AB")) == 0);
+  if (win_ab && pp.half >= 64) {
+    const int chunks = pip_window_ab_chunks(pp.half);
+    hipLaunchKernelGGL(k_pip_window_a, dim3(pp.W, ninst, chunks), dim3(64), 0, st, pp, buckets, win_part, chunks);
+    hipLaunchKernelGGL(k_pip_window_b, dim3(ninst * W), dim3(256), 0, st, pp, win_part, win, chunks);
   } else {
-    hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, 1), dim3(PW_TPB), 0, st, pp, buckets, win, 1);
+    const int chunks = pip_window_chunks(pp.half, ninst, pp.W);
+    if (chunks > 1) {
+      hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, chunks), dim3(PW_TPB), 0, st, pp, buckets, win_part, chunks);
+      segmented_sum(st, win_part, win, ninst * W, chunks);
+    } else {
+      hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, 1), dim3(PW_TPB), 0, st, pp, buckets, win, 1);
+    }
   }
   hipLaunchKernelGGL(k_pip_final, dim3((ninst * 4 + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
 }
