@@ -133,12 +133,16 @@ __global__ void __launch_bounds__(256) k_pip_scatter(PipParams pp, const uint32_
 // Tile = 8 192 keys: a tile writes ~32 consecutive entries per bin (128-byte runs; with 2 048-key tiles the 32-byte runs made
 // every store a partial line).
 constexpr int RS_BINS = 256, RS_TPB = 256, RS_PER = 32, RS_TILE = RS_TPB * RS_PER;
-__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys, size_t n, int half, int shift, size_t tiles,
-                                                            uint32_t *gh) {
+// The TOP window of a 252-bit scalar holds 252 mod c bits: its digits fill only the first 2^(252 mod c) buckets, which with the
+// common shift all land in the first coarse bins (one block then sorted a whole window's entries: 0.2 ms of a 2^17-term MSM).
+// It gets its own, smaller shift, so that its entries spread over the 256 bins as every other window's do.
+__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys, size_t n, int W, int half, int shift, int shift_top,
+                                                            size_t tiles, uint32_t *gh) {
   __shared__ uint32_t h[RS_BINS];
   const size_t seg = blockIdx.y, tile = blockIdx.x;
   h[threadIdx.x] = 0;
   __syncthreads();
+  if ((int)(seg % (size_t)W) == W - 1) shift = shift_top;
   const uint32_t base = (uint32_t)(seg * (size_t)half);
 #pragma unroll 8
   for (int j = 0; j < RS_PER; j++) {
@@ -154,8 +158,8 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_hist(const uint32_t *keys
 // The tile's entries are first placed bin by bin in LDS (ranks from LDS atomics), then written out in that order: consecutive
 // lanes store consecutive addresses of a bin's run, so a wave's store is two or three full 128-byte segments instead of 64
 // scattered 4-byte writes (0.27 -> 0.1 ms at 2^20 terms).
-__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *keys, size_t n, int W, int half, int shift, size_t tiles,
-                                                               const uint32_t *goff, uint32_t *cval, uint8_t *cfine) {
+__global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *keys, size_t n, int W, int half, int shift, int shift_top,
+                                                               size_t tiles, const uint32_t *goff, uint32_t *cval, uint8_t *cfine) {
   __shared__ uint32_t cnt[RS_BINS], loc[RS_BINS], gbase[RS_BINS];
   __shared__ uint32_t sval[RS_TILE];
   __shared__ uint8_t sfine[RS_TILE], sbin[RS_TILE];
@@ -164,6 +168,7 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *k
   cnt[tid] = 0;
   gbase[tid] = goff[(seg * RS_BINS + tid) * tiles + tile];
   __syncthreads();
+  if ((int)(seg % (size_t)W) == W - 1) shift = shift_top;
   const uint32_t base = (uint32_t)(seg * (size_t)half), fmask = (1u << shift) - 1;
 #pragma unroll 8
   for (int j = 0; j < RS_PER; j++) {
@@ -215,13 +220,14 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_coarse_scatter(const uint32_t *k
 // one block per (segment, bin): counts of its 2^shift buckets and the entries placed bucket by bucket -- in LDS when the bin's
 // entries fit (then written out contiguously), straight in global memory otherwise (skewed scalars)
 constexpr uint32_t FS_CAP = 6144;     // 31 KB of LDS per block: five blocks per CU (a uniform 2^20-term window puts ~4 100 entries in a bin)
-__global__ void __launch_bounds__(RS_TPB) k_pip_fine_sort(const uint32_t *goff, size_t tiles, size_t nseg, int half, int shift,
-                                                          const uint32_t *cval, const uint8_t *cfine, uint32_t *counts,
+__global__ void __launch_bounds__(RS_TPB) k_pip_fine_sort(const uint32_t *goff, size_t tiles, size_t nseg, int W, int half, int shift,
+                                                          int shift_top, const uint32_t *cval, const uint8_t *cfine, uint32_t *counts,
                                                           uint32_t *sorted) {
   __shared__ uint32_t h[128], start[128];
   __shared__ uint32_t stage[FS_CAP];
   __shared__ uint32_t fwords[FS_CAP / 4 + 2];
   const size_t seg = blockIdx.y, bin = blockIdx.x;
+  if ((int)(seg % (size_t)W) == W - 1) shift = shift_top;     // (the counts of the top window's unused buckets were zeroed by the caller)
   const int fb = 1 << shift, t = threadIdx.x;
   const size_t gi = (seg * RS_BINS + bin) * tiles;
   const uint32_t lo = goff[gi], hi = goff[gi + tiles];     // goff has nseg * RS_BINS * tiles + 1 entries
@@ -280,6 +286,19 @@ __global__ void __launch_bounds__(256) k_pip_taskdesc(const uint32_t *toffsets, 
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   for (uint32_t t = toffsets[b]; t < toffsets[b + 1]; t++) task_bucket[t] = (uint32_t)b;
+}
+// the same table, lane per TASK (binary search for its bucket; every bucket owns at least one task, so toffsets is strictly
+// increasing): when the top window's few buckets hold hundreds of tasks each, the lane-per-bucket loop above is a serial tail
+// (76 us of a 2^17-term MSM)
+__global__ void __launch_bounds__(256) k_pip_taskdesc_search(const uint32_t *toffsets, size_t nb, uint32_t *task_bucket) {
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= toffsets[nb]) return;
+  uint32_t lo = 0, hi = (uint32_t)nb;                      // toffsets[lo] <= t < toffsets[hi]
+  while (hi - lo > 1) {
+    const uint32_t mid = lo + (hi - lo) / 2;
+    if (toffsets[mid] <= t) lo = mid; else hi = mid;
+  }
+  task_bucket[t] = lo;
 }
 // Tasks of equal length side by side.  Bucket sizes scatter around n / 2^(c-1) (2^20 terms at c = 16: 32 +- 6), so in
 // bucket order the 64 tasks of a wave held anything from 1 to 16 entries and the wave ran for the longest: a third of the
@@ -604,7 +623,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   if (pip_two_level(ninst, n, c)) {
     // LDS-staged two-level counting sort: digits (no atomics) -> coarse histograms per tile -> scan -> coarse scatter ->
     // per-(segment, bin) fine sort, which also produces the bucket counts
-    const int shift = c - 1 - 8;
+    const int shift = c - 1 - 8, top_bits = 252 - c * (pp.W - 1), shift_top = top_bits > 8 ? top_bits - 8 : 0;   // top digits are in [0, 2^top_bits]
     const size_t nseg = ninst * W, tiles = (n + RS_TILE - 1) / RS_TILE, ngh = nseg * RS_BINS * tiles;
     uint32_t *gh = (uint32_t *)p; p += al((ngh + 1) * 4);
     uint32_t *goff = (uint32_t *)p; p += al((ngh + 1) * 4);
@@ -612,11 +631,11 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
     uint32_t *cval = (uint32_t *)p; p += al(tot * W * 4);
     uint8_t *cfine = p; p += al(tot * W);
     hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, (uint32_t *)nullptr);
-    hipLaunchKernelGGL(k_pip_coarse_hist, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.half, shift, tiles, gh);
+    hipLaunchKernelGGL(k_pip_coarse_hist, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, shift_top, tiles, gh);
     pip_scan(st, gh, goff, nullptr, ngh, gtile);
-    hipLaunchKernelGGL(k_pip_coarse_scatter, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, tiles, goff, cval, cfine);
-    hipLaunchKernelGGL(k_pip_fine_sort, dim3(RS_BINS, nseg), dim3(RS_TPB), 0, st, goff, tiles, nseg, pp.half, shift, cval, cfine, counts, sorted);
-    (void)hipMemsetAsync(counts + nbk, 0, 4, st);
+    hipLaunchKernelGGL(k_pip_coarse_scatter, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, shift_top, tiles, goff, cval, cfine);
+    (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);     // (the top windows' buckets beyond 2^top_bits are written by nobody)
+    hipLaunchKernelGGL(k_pip_fine_sort, dim3(RS_BINS, nseg), dim3(RS_TPB), 0, st, goff, tiles, nseg, pp.W, pp.half, shift, shift_top, cval, cfine, counts, sorted);
     pip_scan(st, counts, offsets, nullptr, nbk, tile_tmp);
   } else {
     (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
@@ -626,7 +645,12 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   }
   hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
   pip_scan(st, tcount, toffsets, nullptr, nbk, tile_tmp);
-  hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
+  {
+    const int top_bits = 252 - c * (pp.W - 1);
+    const size_t tasks_per_top_bucket = (n >> top_bits) / PIP_TASK;     // uniform scalars: n / 2^top_bits entries per top bucket
+    if (tasks_per_top_bucket > 64) hipLaunchKernelGGL(k_pip_taskdesc_search, dim3((mt + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
+    else hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
+  }
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
   static const bool by_len = !(getenv("BPGPU_PIP_TASK_SORT") && atoi(getenv("BPGPU_PIP_TASK_SORT")) == 0);
   const bool sort_tasks = by_len && tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
