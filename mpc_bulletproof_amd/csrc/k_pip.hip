@@ -406,13 +406,23 @@ constexpr int PH_TPB = 64;    // one wave per queued bucket (128 threads: 7 tree
 __global__ void __launch_bounds__(PH_TPB) k_pip_merge_heavy(const uint32_t *toffsets, const JacRaw *partial,
                                                             const uint32_t *heavy_list, const uint32_t *heavy_count,
                                                             JacRaw *buckets) {
-  __shared__ int32_t smem[27 * (PH_TPB / 2)];
   if (blockIdx.x >= *heavy_count) return;
   const uint32_t b = heavy_list[blockIdx.x];
   const uint32_t lo = toffsets[b], hi = toffsets[b + 1];
   Jac acc = jac_inf();
   for (uint32_t t = lo + threadIdx.x; t < hi; t += PH_TPB) acc = jac_add(acc, raw_load(&partial[t]));
-  acc = block_sum<PH_TPB>(acc, smem);
+  static_assert(PH_TPB == 64, "one wave: shuffle butterfly, no LDS round trips");
+#pragma unroll 1
+  for (int off = 32; off > 0; off >>= 1) {
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
+    }
+    acc = jac_add(acc, q);
+  }
   if (threadIdx.x == 0) raw_store(&buckets[b], acc);
 }
 // S_w = sum_{d=1}^{half} d * B_d per (window, instance), split into `chunks` blocks of half / chunks buckets each
