@@ -368,6 +368,47 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
   return BPGPU_OK;
 }
 
+// MSMs of up to 2^14 terms as a batch of independent <= 32-point sums through the window-parallel launches of the verifier
+// (k_ec.hip: point tables -> 64 window sums per group, lane = window -> Horner on quads) and one final sum per instance: no
+// sort, no buckets, and the only long dependency chain is the 252 quad doublings every MSM ends in.  64 windows x 16 points is
+// 2.4x the additions of the bucket method at these sizes, but they are a few 10^7 wave-instructions on an otherwise idle
+// chip: one call is ~0.6 ms from 2 to 2^14 terms (bucket method: 0.8-0.9 ms from 2^10 on; a Straus lane per term + a sum: 1.05 ms).
+// points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
+// Handles nb instances of n terms when the groups tile them (n <= 32, one instance, or n a multiple of 16); *done says so.
+static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done) {
+  static const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 14);
+  *done = false;
+  if (!nb || !n || n > wp_max) return BPGPU_OK;
+  size_t G, per;
+  if (n <= 32) { G = n; per = 1; }
+  else if (nb == 1 || n % 16 == 0) { G = 16; per = (n + 15) / 16; }
+  else return BPGPU_OK;
+  const size_t ng = nb * per, np = per * G;
+  if (ng > ((size_t)1 << 16)) return BPGPU_OK;
+  const void *sc = dsc, *pts = points;
+  if (np != n) {   // (one instance) ragged tail: identity points with zero scalars -- 64 zero bytes are the identity in either form
+    void *dp, *ds;
+    CK(ws_get(ctx, 7, np * 64, &dp));
+    CK(ws_get(ctx, 9, np * 32, &ds));
+    HIPCK(ctx, hipMemcpyAsync(dp, points, n * 64, hipMemcpyDeviceToDevice, ctx->st));
+    HIPCK(ctx, hipMemsetAsync((uint8_t *)dp + n * 64, 0, (np - n) * 64, ctx->st));
+    HIPCK(ctx, hipMemcpyAsync(ds, dsc, n * 32, hipMemcpyDeviceToDevice, ctx->st));
+    HIPCK(ctx, hipMemsetAsync((uint8_t *)ds + n * 32, 0, (np - n) * 32, ctx->st));
+    pts = dp; sc = ds;
+  }
+  void *dwp;
+  CK(ws_get(ctx, 12, verify_wp_scratch_bytes(ng, G), &dwp));
+  VerifyWp v{(const AffDev *)pts, ng, G, dwp, ctx->d_flag, nullptr, true, converted};
+  VerifyDims d{};
+  verify_wp_front_launch(ctx->st, v, d, nullptr, nullptr, 0, false);
+  verify_wp_windows(ctx->st, v, (const uint32_t *)sc);
+  verify_wp_groups(ctx->st, v);
+  verify_wp_back(ctx->st, v, 8, nullptr, 0, 0, nullptr, 0, nullptr);
+  if (per == 1) HIPCK(ctx, hipMemcpyAsync(dsum, verify_wp_varsum(v), nb * sizeof(JacRaw), hipMemcpyDeviceToDevice, ctx->st));
+  else segmented_sum(ctx->st, verify_wp_varsum(v), dsum, nb, per);
+  *done = true;
+  return BPGPU_OK;
+}
 /* ---------------------------------------------------------------- MSM (general points) */
 // device-resident core: dsc / dxy hold the boundary encodings in HBM, dout receives nb x 64 B; asynchronous on ctx->st
 static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *dxy, void *dout) {
@@ -381,6 +422,15 @@ static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void 
     // 32-bit bucket ids, sorted entries (term index | sign bit) and offsets: reject what they cannot address
     const size_t cW = 252 / (size_t)pippenger_window(n) + 1, chalf = (size_t)1 << (pippenger_window(n) - 1);
     if (n >= ((size_t)1 << 31) / nb || nb * cW * chalf >= ((size_t)1 << 31) || tot * cW >= ((size_t)1 << 32)) return BPGPU_E_LEN;
+  }
+  {
+    bool done = false;
+    scalars_check(ctx->st, (const Words8 *)dsc, tot, ctx->d_flag);
+    CK(msm_wp_batch(ctx, nb, n, dsc, dxy, false, (JacRaw *)dsum, &done));
+    if (done) {
+      jac_to_boundary(ctx->st, (JacRaw *)dsum, (Words8 *)dout, nb);
+      return launch_ok(ctx);
+    }
   }
   if (nb == 1 && n >= pip_min && pippenger2_supported(n)) {   // one mid-size instance: seven launches (k_pip2.hip)
     const int c2 = pippenger2_window(n);
@@ -460,6 +510,9 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
 // sum_i scalars[i] * pts[i] for validated device operands (plain canonical scalars, Montgomery affine points) -> one JacRaw
 static int msm_core_locked(bpgpu_ctx *ctx, size_t n, const uint32_t *dsc, const AffDev *dpts, JacRaw *dsum) {
   static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  bool done = false;
+  CK(msm_wp_batch(ctx, 1, n, dsc, dpts, true, dsum, &done));
+  if (done) return BPGPU_OK;
   void *dpip;
   if (n >= pip_min && pippenger2_supported(n)) {
     const int c2 = pippenger2_window(n);

@@ -201,6 +201,7 @@ struct TablesArgs {
   int32_t *scratch;         // lane-strided staging: blocks x TNP x 8 x STE x 64 int32
   int *bad;                 // context-wide diagnostic flag
   int32_t *bad_lane;        // nb x lanes: 1 = one of the lane's points is malformed (every lane writes its entry)
+  int converted;            // points are AffDev rows (validated, Montgomery form) instead of ABI bytes
 };
 template <int TNP>
 __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
@@ -225,13 +226,16 @@ __device__ __forceinline__ void tables_body(const TablesArgs &a, size_t blk) {
     P.y = fe_zero<FP>();
     if (v < a.nvar) {
       const AffDev *psrc = a.points + p * a.nvar + v;
-      uint32_t w[16];
+      if (a.converted) P = aff_load(psrc);
+      else {
+        uint32_t w[16];
 #pragma unroll
-      for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
-      if (!aff_from_boundary(P, w)) {
-        malformed = true;
-        P.x = fe_zero<FP>();
-        P.y = fe_zero<FP>();
+        for (int t = 0; t < 16; t++) w[t] = psrc->w[t];
+        if (!aff_from_boundary(P, w)) {
+          malformed = true;
+          P.x = fe_zero<FP>();
+          P.y = fe_zero<FP>();
+        }
       }
     }
     const bool inf = aff_is_inf(P);
@@ -454,7 +458,7 @@ bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n) {
 static WpLayout wp_layout(const VerifyWp &v) {
   WpLayout L{};
   const size_t tnp = wp_tnp(v);
-  L.t.points = v.points_abi; L.t.nb = v.nb; L.t.nvar = v.nvar; L.t.lanes = (v.nvar + tnp - 1) / tnp; L.t.bad = v.bad;
+  L.t.points = v.points_abi; L.t.converted = v.points_converted ? 1 : 0; L.t.nb = v.nb; L.t.nvar = v.nvar; L.t.lanes = (v.nvar + tnp - 1) / tnp; L.t.bad = v.bad;
   const size_t nblk = (v.nb * L.t.lanes + 63) / 64;
   uint8_t *sp = (uint8_t *)v.scratch;
   L.t.scratch = (int32_t *)sp; sp += al256(nblk * tnp * SE * STE * 64 * 4);
@@ -530,6 +534,7 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
   else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode);
   else launch_back<20>(st, h, hb, f, v.latency_mode);
 }
+const JacRaw *verify_wp_varsum(const VerifyWp &v) { return wp_layout(v).varsum; }
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
   WpLayout L = wp_layout(v);
   hipLaunchKernelGGL(k_verify_verdict, dim3((v.nb + 63) / 64), dim3(64), 0, st, L.varsum, fixed, v.nb, L.t.bad_lane, L.t.lanes,

@@ -59,7 +59,8 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
 // bad_sc: the per-proof canonicity bits written by verify_scalars (nullable)
 // latency_mode: more, shorter lanes in the two longest launches (1 point per table lane, 32 lanes per fixed-base MSM, a quad per group in the first Horner stage): one batch
 // alone finishes ~25 % sooner, a pipelined stream of batches runs ~5 % slower (more instructions)
-struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; };
+// points_converted: points_abi holds AffDev rows (already validated and in Montgomery form: points_from_boundary) instead of ABI bytes
+struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; bool points_converted = false; };
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */ };
 struct VsPrepArgs;
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);
@@ -72,6 +73,7 @@ void verify_wp_groups(hipStream_t st, const VerifyWp &v);
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
                     const uint32_t *fixed_scalars, size_t sc_stride_words, JacRaw *out_fixed);
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega);
+const JacRaw *verify_wp_varsum(const VerifyWp &v);   // nb sums of the proof-point halves, valid after verify_wp_back
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
 int pippenger_window(size_t n);
