@@ -374,26 +374,25 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
 // 2.4x the additions of the bucket method at these sizes, but they are a few 10^7 wave-instructions on an otherwise idle
 // chip: one call is ~0.6 ms from 2 to 2^14 terms (bucket method: 0.8-0.9 ms from 2^10 on; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
-// Handles nb instances of n terms when the groups tile them (n <= 32, one instance, or n a multiple of 16); *done says so.
+// *done: handled here (n <= 2^14 and at most 2^16 groups in all).
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done) {
   static const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 14);
   *done = false;
   if (!nb || !n || n > wp_max) return BPGPU_OK;
   size_t G, per;
   if (n <= 32) { G = n; per = 1; }
-  else if (nb == 1 || n % 16 == 0) { G = 16; per = (n + 15) / 16; }
-  else return BPGPU_OK;
+  else { G = 16; per = (n + 15) / 16; }
   const size_t ng = nb * per, np = per * G;
   if (ng > ((size_t)1 << 16)) return BPGPU_OK;
   const void *sc = dsc, *pts = points;
-  if (np != n) {   // (one instance) ragged tail: identity points with zero scalars -- 64 zero bytes are the identity in either form
+  if (np != n) {   // ragged tails: identity points with zero scalars -- 64 zero bytes are the identity in either form
     void *dp, *ds;
-    CK(ws_get(ctx, 7, np * 64, &dp));
-    CK(ws_get(ctx, 9, np * 32, &ds));
-    HIPCK(ctx, hipMemcpyAsync(dp, points, n * 64, hipMemcpyDeviceToDevice, ctx->st));
-    HIPCK(ctx, hipMemsetAsync((uint8_t *)dp + n * 64, 0, (np - n) * 64, ctx->st));
-    HIPCK(ctx, hipMemcpyAsync(ds, dsc, n * 32, hipMemcpyDeviceToDevice, ctx->st));
-    HIPCK(ctx, hipMemsetAsync((uint8_t *)ds + n * 32, 0, (np - n) * 32, ctx->st));
+    CK(ws_get(ctx, 7, nb * np * 64, &dp));
+    CK(ws_get(ctx, 9, nb * np * 32, &ds));
+    HIPCK(ctx, hipMemsetAsync(dp, 0, nb * np * 64, ctx->st));
+    HIPCK(ctx, hipMemsetAsync(ds, 0, nb * np * 32, ctx->st));
+    HIPCK(ctx, hipMemcpy2DAsync(dp, np * 64, points, n * 64, n * 64, nb, hipMemcpyDeviceToDevice, ctx->st));
+    HIPCK(ctx, hipMemcpy2DAsync(ds, np * 32, dsc, n * 32, n * 32, nb, hipMemcpyDeviceToDevice, ctx->st));
     pts = dp; sc = ds;
   }
   void *dwp;
@@ -660,7 +659,15 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
   CK(h2d(ctx, dxy, points, n * 64));
   scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, n, ctx->d_flag);   // validated and converted once
-  if (bucket) {   // one batched bucket-method launch; the instances read replicas of the converted points
+  bool wp_done = false;
+  if (!bucket || n <= ((size_t)1 << 14)) {   // window-parallel launches over replicas of the converted points (msm_wp_batch)
+    void *drep;
+    CK(ws_get(ctx, 8, tot * sizeof(AffDev), &drep));
+    gather_points(ctx->st, (AffDev *)dpts, 0, n, nsets, (AffDev *)drep, n);
+    CK(msm_wp_batch(ctx, nsets, n, dsc, drep, true, (JacRaw *)dsum, &wp_done));
+  }
+  if (wp_done) {
+  } else if (bucket) {   // one batched bucket-method launch; the instances read replicas of the converted points
     AffDev *rep = (AffDev *)dpts + n;
     gather_points(ctx->st, (AffDev *)dpts, 0, n, nsets, rep, n);
     int c = pippenger_window(n);
