@@ -368,15 +368,16 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
   return BPGPU_OK;
 }
 
-// MSMs of up to 2^14 terms as a batch of independent <= 32-point sums through the window-parallel launches of the verifier
+// MSMs of up to 2^16 terms as a batch of independent <= 32-point sums through the window-parallel launches of the verifier
 // (k_ec.hip: point tables -> 64 window sums per group, lane = window -> Horner on quads) and one final sum per instance: no
 // sort, no buckets, and the only long dependency chain is the 252 quad doublings every MSM ends in.  64 windows x 16 points is
 // 2.4x the additions of the bucket method at these sizes, but they are a few 10^7 wave-instructions on an otherwise idle
-// chip: one call is ~0.6 ms from 2 to 2^14 terms (bucket method: 0.8-0.9 ms from 2^10 on; a Straus lane per term + a sum: 1.05 ms).
+// chip: one call is 0.6-0.7 ms from 2 to 2^14 terms, 0.77 ms at 2^15, 1.05 ms at 2^16 (bucket method: 0.8-0.9 ms from 2^10 on, 1.03 /
+// 1.15 ms at 2^15 / 2^16; from 2^17 terms on the bucket method wins: 1.06 against 1.59 ms; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
-// *done: handled here (n <= 2^14 and at most 2^16 groups in all).
+// *done: handled here (n <= 2^16 and at most 2^16 groups in all).
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done) {
-  static const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 14);
+  static const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 16);
   *done = false;
   if (!nb || !n || n > wp_max) return BPGPU_OK;
   size_t G, per;
@@ -660,7 +661,7 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
   scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, n, ctx->d_flag);   // validated and converted once
   bool wp_done = false;
-  if (!bucket || n <= ((size_t)1 << 14)) {   // window-parallel launches over replicas of the converted points (msm_wp_batch)
+  if (!bucket || n <= ((size_t)1 << 16)) {   // window-parallel launches over replicas of the converted points (msm_wp_batch)
     void *drep;
     CK(ws_get(ctx, 8, tot * sizeof(AffDev), &drep));
     gather_points(ctx->st, (AffDev *)dpts, 0, n, nsets, (AffDev *)drep, n);

@@ -12,7 +12,7 @@ import oracle_lib as o            # noqa: E402
 
 gpu = mb.BpGpu(0)
 base = o.gens("G", 4096)
-for lg in (7, 10, 12, 14, 17, 20):
+for lg in [int(x) for x in os.environ.get("BENCH_MSM_LOG2", "7,10,12,14,17,20").split(",")]:
     n = 1 << lg
     pts = (base * ((n + 4095) // 4096))[:64 * n]
     sc = o.random_scalars(lg, n)
