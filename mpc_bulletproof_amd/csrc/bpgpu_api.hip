@@ -368,16 +368,16 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
   return BPGPU_OK;
 }
 
-// MSMs of up to 2^16 terms as a batch of independent <= 32-point sums through the window-parallel launches of the verifier
+// MSMs of up to 2^15 terms as a batch of independent <= 32-point sums through the window-parallel launches of the verifier
 // (k_ec.hip: point tables -> 64 window sums per group, lane = window -> Horner on quads) and one final sum per instance: no
 // sort, no buckets, and the only long dependency chain is the 252 quad doublings every MSM ends in.  64 windows x 16 points is
 // 2.4x the additions of the bucket method at these sizes, but they are a few 10^7 wave-instructions on an otherwise idle
-// chip: one call is 0.6-0.7 ms from 2 to 2^14 terms, 0.77 ms at 2^15, 1.05 ms at 2^16 (bucket method: 0.8-0.9 ms from 2^10 on, 1.03 /
-// 1.15 ms at 2^15 / 2^16; from 2^17 terms on the bucket method wins: 1.06 against 1.59 ms; a Straus lane per term + a sum: 1.05 ms).
+// chip: one call is 0.6-0.7 ms from 2 to 2^14 terms and 0.77 ms at 2^15 (the bucket launches of k_pip.hip: 0.86 ms there, and
+// ahead from 2^16 terms on: 0.96 against 1.05 ms, 1.07 against 1.59 ms at 2^17; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
-// *done: handled here (n <= 2^16 and at most 2^16 groups in all).
+// *done: handled here (n <= 2^15, BPGPU_MSM_WP_MAX overrides, and at most 2^16 groups in all).
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done) {
-  static const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 16);
+  const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 15);   // read per call: tests vary it
   *done = false;
   if (!nb || !n || n > wp_max) return BPGPU_OK;
   size_t G, per;
@@ -432,7 +432,10 @@ static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void 
       return launch_ok(ctx);
     }
   }
-  if (nb == 1 && n >= pip_min && pippenger2_supported(n)) {   // one mid-size instance: seven launches (k_pip2.hip)
+  // k_pip2.hip's one-instance pipeline carries the combined batch check; for a lone MSM the window-parallel launches (up to 2^15
+  // terms) and k_pip.hip (from 2^16) are both faster now.  BPGPU_PIP2_SINGLE=1 routes 2^8..2^16 terms through it (tests).
+  const bool pip2_single = getenv("BPGPU_PIP2_SINGLE") && atoi(getenv("BPGPU_PIP2_SINGLE")) != 0;   // read per call
+  if (pip2_single && nb == 1 && n >= pip_min && pippenger2_supported(n)) {   // one mid-size instance: seven launches (k_pip2.hip)
     const int c2 = pippenger2_window(n);
     void *dpip;
     CK(ws_get(ctx, 14, pippenger2_scratch_bytes(n, c2), &dpip));
@@ -514,7 +517,8 @@ static int msm_core_locked(bpgpu_ctx *ctx, size_t n, const uint32_t *dsc, const 
   CK(msm_wp_batch(ctx, 1, n, dsc, dpts, true, dsum, &done));
   if (done) return BPGPU_OK;
   void *dpip;
-  if (n >= pip_min && pippenger2_supported(n)) {
+  const bool pip2_single = getenv("BPGPU_PIP2_SINGLE") && atoi(getenv("BPGPU_PIP2_SINGLE")) != 0;   // read per call
+  if (pip2_single && n >= pip_min && pippenger2_supported(n)) {
     const int c2 = pippenger2_window(n);
     CK(ws_get(ctx, 14, pippenger2_scratch_bytes(n, c2), &dpip));
     pippenger2(ctx->st, dpts, dsc, n, c2, dsum, dpip, ctx->d_flag);
@@ -661,7 +665,7 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
   scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   points_from_boundary(ctx->st, (Words8 *)dxy, (AffDev *)dpts, n, ctx->d_flag);   // validated and converted once
   bool wp_done = false;
-  if (!bucket || n <= ((size_t)1 << 16)) {   // window-parallel launches over replicas of the converted points (msm_wp_batch)
+  if (!bucket || n <= ((size_t)1 << 15)) {   // window-parallel launches over replicas of the converted points (msm_wp_batch)
     void *drep;
     CK(ws_get(ctx, 8, tot * sizeof(AffDev), &drep));
     gather_points(ctx->st, (AffDev *)dpts, 0, n, nsets, (AffDev *)drep, n);

@@ -606,11 +606,16 @@ def sys_path_oracle():
 
 
 # ------------------------------------------------------------------ large MSM (bucket method)
-def test_msm_pippenger_edge_cases(gpu):
+@pytest.mark.parametrize("route", ["default", "pip2", "bucket"])
+def test_msm_pippenger_edge_cases(gpu, monkeypatch, route):
     sys_path_oracle()
-    """n >= 512 takes the bucket-method kernels: zero / one / n-1 scalars, identity points, duplicates,
-    P and -P pairs must come out exactly as the oracle's."""
+    """zero / one / n-1 scalars, identity points, duplicates, P and -P pairs must come out exactly as the oracle's, through
+    each of the three MSM routes (see test_msm_pippenger_sizes)."""
     import pymodel as pm
+    if route != "default":
+        monkeypatch.setenv("BPGPU_MSM_WP_MAX", "0")
+    if route == "pip2":
+        monkeypatch.setenv("BPGPU_PIP2_SINGLE", "1")
     n = 640
     Gp = o.gens("G", n)
     pts = bytearray(Gp)
@@ -632,10 +637,17 @@ def test_msm_pippenger_edge_cases(gpu):
     assert gpu.msm(half + neg, Gp[:64 * 300] * 2) == bytes(64)
 
 
+@pytest.mark.parametrize("route", ["default", "pip2", "bucket"])
 @pytest.mark.parametrize("n", [512, 5000, 98347])
-def test_msm_pippenger_sizes(gpu, n):
+def test_msm_pippenger_sizes(gpu, monkeypatch, n, route):
     """98 347 = the C4 verification MSM size.  Checked against the oracle-free identity
-    MSM(s_i, k_i G) = (sum s_i k_i) G and, for the smaller sizes, the oracle's own Pippenger."""
+    MSM(s_i, k_i G) = (sum s_i k_i) G and, for the smaller sizes, the oracle's own Pippenger.  Routes: default = the
+    window-parallel launches up to 2^15 terms, k_pip.hip above; pip2 = k_pip2.hip's one-instance pipeline (2^8..2^16 terms);
+    bucket = k_pip.hip / the Straus lanes at every size."""
+    if route != "default":
+        monkeypatch.setenv("BPGPU_MSM_WP_MAX", "0")
+    if route == "pip2":
+        monkeypatch.setenv("BPGPU_PIP2_SINGLE", "1")
     Gp, Gd = o.gens("G", n, dlogs=True)
     sc = o.random_scalars(1234 + n, n)
     got = gpu.msm(sc, Gp)
