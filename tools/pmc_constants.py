@@ -40,6 +40,22 @@ out = {
     # HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KB as MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE counts 64 B per 128-B request)
     "traffic_bytes_per_launch": {k: int((2 * fetch[k][0] + write.get(k, (0, 0))[0]) * 1024) for k in fetch},
 }
+# the profiled run of the driver's command (tools/profile_all.sh): the dominant kernel's average duration by rocprofv3 and by the
+# HIP events of that same run.  Under the tracer the steps in flight overlap less than in an un-profiled run, so a kernel launch
+# is SHORTER there (fewer neighbours on the chip): bench.py quotes these beside its own event average.
+try:
+    import csv
+    run = json.loads(open(os.path.join(ROOT, "profiles", f"{os.path.basename(tag)}_bench20_profiled_run.json")).read())
+    roof = run["roofline"]
+    kern = roof["kernel"].split("<")[0]
+    for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{os.path.basename(tag)}_bench20_kernel_stats.csv"))):
+        if kern in row["Name"]:
+            out["profiled_run_bench20"] = {"kernel": roof["kernel"], "rocprofv3_avg_ms": float(row["AverageNs"]) / 1e6, "rocprofv3_calls": int(row["Calls"]),
+                                           "hip_events_avg_ms": roof["avg_launch_ms"], "hip_events_launches": roof["launches"],
+                                           "source": f"profiles/{os.path.basename(tag)}_bench20_kernel_stats.csv, profiles/{os.path.basename(tag)}_bench20_profiled_run.json"}
+            break
+except (OSError, KeyError, ValueError) as e:
+    print("no profiled-run comparison:", e, file=sys.stderr)
 path = os.path.join(ROOT, "profiles", "pmc_constants.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))
