@@ -30,7 +30,7 @@ struct bpgpu_ctx {
   int *d_flag = nullptr;          // device int: bad-input flag
   void *sqrt_tab = nullptr;       // F_p square-root tables of the point codec (built on first use)
   struct bpgpu_gens *gen_tab = nullptr;   // 16-bit-window table of the curve generator (bpgpu_generator_mul)
-  Slot ws[24];                    // grow-only workspace slots
+  Slot ws[28];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
   bool latency_mode = false;      // bpgpu_set_latency_mode
@@ -376,8 +376,9 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
 // ahead from 2^16 terms on: 0.96 against 1.05 ms, 1.07 against 1.59 ms at 2^17; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
 // *done: handled here (n <= 2^15, BPGPU_MSM_WP_MAX overrides, and at most 2^16 groups in all).
-static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done) {
-  const size_t wp_max = getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 15);   // read per call: tests vary it
+static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done,
+                        int *bad = nullptr, size_t max_n = 0) {
+  const size_t wp_max = max_n ? max_n : getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 15);   // read per call: tests vary it
   *done = false;
   if (!nb || !n || n > wp_max) return BPGPU_OK;
   size_t G, per;
@@ -388,8 +389,8 @@ static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, co
   const void *sc = dsc, *pts = points;
   if (np != n) {   // ragged tails: identity points with zero scalars -- 64 zero bytes are the identity in either form
     void *dp, *ds;
-    CK(ws_get(ctx, 7, nb * np * 64, &dp));
-    CK(ws_get(ctx, 9, nb * np * 32, &ds));
+    CK(ws_get(ctx, 24, nb * np * 64, &dp));     // (slots of their own: the verifier calls this with its slot-7 / slot-9 buffers as operands)
+    CK(ws_get(ctx, 25, nb * np * 32, &ds));
     HIPCK(ctx, hipMemsetAsync(dp, 0, nb * np * 64, ctx->st));
     HIPCK(ctx, hipMemsetAsync(ds, 0, nb * np * 32, ctx->st));
     HIPCK(ctx, hipMemcpy2DAsync(dp, np * 64, points, n * 64, n * 64, nb, hipMemcpyDeviceToDevice, ctx->st));
@@ -398,7 +399,7 @@ static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, co
   }
   void *dwp;
   CK(ws_get(ctx, 12, verify_wp_scratch_bytes(ng, G), &dwp));
-  VerifyWp v{(const AffDev *)pts, ng, G, dwp, ctx->d_flag, nullptr, true, converted};
+  VerifyWp v{(const AffDev *)pts, ng, G, dwp, bad ? bad : ctx->d_flag, nullptr, true, converted};
   VerifyDims d{};
   verify_wp_front_launch(ctx->st, v, d, nullptr, nullptr, 0, false);
   verify_wp_windows(ctx->st, v, (const uint32_t *)sc);
@@ -1119,6 +1120,25 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   ar.sc[0] = (uint32_t *)dvar + vnp * lanes * 8; ar.sc_stride[0] = nvar * 8; ar.sc_outer[0] = 8;
   ar.inner = nb; ar.out_outer = 1; ar.out_stride = nres;
   bool fused = false;
+  if (nb == 1 && !no_wp && !no_fuse && nvar <= ((size_t)1 << 16)) {
+    // ONE large proof (the 2^14-shuffle: 32 809 proof points): its variable-base half as 16-point groups through the window-
+    // parallel launches (msm_wp_batch) instead of a Straus lane per 4 points, a one-point remainder launch and a 256-deep
+    // serial sum (1.9 + 0.9 + 1.15 ms -> 0.8 ms); the generator half runs on the second stream as below.
+    HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
+    HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
+    { ProfScope ps(ctx, 1, ctx->st2);
+      CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2, 23)); }
+    HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
+    bool done = false;
+    { ProfScope ps(ctx, 3, ctx->st);
+      CK(msm_wp_batch(ctx, 1, nvar, dvar, points, false, (JacRaw *)dvres, &done, (int *)dbadpt, (size_t)1 << 16)); }
+    HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
+    if (done) {
+      ProfScope ps(ctx, 4, ctx->st);
+      verify_finalize(ctx->st, (JacRaw *)dvres, 1, (JacRaw *)dfres, nb, (int32_t *)ok, (Words8 *)mega, (const int32_t *)dbadsc, dbadpt);
+      return launch_ok(ctx);
+    }
+  }
   if (!no_fuse && lanes && fixed_msm_chunks(g->c, np, nb) == 1) {
     // one launch for both halves of the MSM, reading the proof points straight from the ABI bytes
     StrausArgs af = am;
