@@ -225,6 +225,10 @@ void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c);
 int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *z,
                               uint8_t *wL, uint8_t *wR, uint8_t *wO, uint8_t *wV, uint8_t *wc);
 
+/* bpgpu_circuit_create with the coefficients as they lie in the reference's memory (ark-ff Montgomery limbs, x * 2^256 mod n):
+ * converted on the device.  The 2^14-shuffle's ~200 000 coefficients cost the host 8 ms of de-Montgomery per upload otherwise. */
+int bpgpu_circuit_create_ark(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
+                             const uint8_t *coeff_ark, size_t n_multipliers, size_t m_commitments, bpgpu_circuit **out);
 /* Circuits with RANDOMIZED (second-phase) constraints whose coefficients are affine in the gadget's challenge
  * (RandomizableConstraintSystem::specify_randomized_constraints + cs.challenge_scalar(label) -- r1cs/verifier.rs:366-385,
  * r1cs/prover.rs:383-402; the shuffle gadget (x_i - z), tests/r1cs.rs:23-62): coefficient of a term = c0 + sum_j chi_j * c_j.

@@ -149,6 +149,20 @@ __global__ void k_coeff_to_mont(Words8 *io, size_t n, int *bad) {
   bp::pack(w, x);
   for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
 }
+// the same from ark-ff Montgomery limbs (x 2^256 mod n): one multiplication by 2^266 instead of the host's de-Montgomery
+__global__ void k_coeff_ark_to_mont(Words8 *io, size_t n, int *bad) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t w[8];
+  for (int j = 0; j < 8; j++) w[j] = io[i].w[j];
+  if (!bp::words_lt_mod<bp::FN>(w)) { atomicOr(bad, 1); return; }
+  constexpr int32_t C[bp::NL] = FN_ARK_MONT;
+  bp::Fn k;
+  for (int j = 0; j < bp::NL; j++) k.v[j] = C[j];
+  bp::Fn x = bp::canon(bp::mul(bp::unpack<bp::FN>(w), k));
+  bp::pack(w, x);
+  for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
+}
 static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
                         hipStream_t st, int part_slot = 12) {
   size_t chunks = fixed_msm_chunks(g->c, n, nb);
@@ -923,7 +937,7 @@ int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t
 
 /* ---------------------------------------------------------------- R1CS */
 static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
-                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
+                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out, bool ark = false) {
   if (!ctx || !out || !row_ptr) return BPGPU_E_ARG;
   *out = nullptr;
   const size_t q = q_real * (1 + nchi);     // CSR rows: block j (rows j q_real ..) holds the chi_j parts of the coefficients
@@ -973,7 +987,8 @@ static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const
       hipMemcpyAsync(c->row, rows.data(), (nnz ? nnz : 1) * 4, hipMemcpyHostToDevice, ctx->st) != hipSuccess ||
       hipMemcpyAsync(c->coeff, cf.data(), (nnz ? nnz : 1) * 32, hipMemcpyHostToDevice, ctx->st) != hipSuccess)
     return fail(BPGPU_E_DEVICE);
-  if (nnz) hipLaunchKernelGGL(k_coeff_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, ctx->st, c->coeff, nnz, ctx->d_flag);
+  if (nnz && ark) hipLaunchKernelGGL(k_coeff_ark_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, ctx->st, c->coeff, nnz, ctx->d_flag);
+  else if (nnz) hipLaunchKernelGGL(k_coeff_to_mont, dim3((nnz + 255) / 256), dim3(256), 0, ctx->st, c->coeff, nnz, ctx->d_flag);
   int bad = 0;
   if (hipMemcpyAsync(&bad, ctx->d_flag, sizeof(int), hipMemcpyDeviceToHost, ctx->st) != hipSuccess ||
       hipStreamSynchronize(ctx->st) != hipSuccess)
@@ -985,6 +1000,10 @@ static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const
 int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
                          const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
   return circuit_create_impl(ctx, q, 0, row_ptr, kind, idx, coeff, n_mul, m, out);
+}
+int bpgpu_circuit_create_ark(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
+                             const uint8_t *coeff_ark, size_t n_mul, size_t m, bpgpu_circuit **out) {
+  return circuit_create_impl(ctx, q, 0, row_ptr, kind, idx, coeff_ark, n_mul, m, out, true);
 }
 int bpgpu_circuit_create_param(bpgpu_ctx *ctx, size_t q, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
                                const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {

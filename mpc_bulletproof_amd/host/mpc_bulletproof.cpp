@@ -935,29 +935,36 @@ class CsCore {
     return true;
   }
   // constraint rows -> CSR arrays of the C ABI (the reference's Vec<LinearCombination>)
-  void csr(std::vector<uint32_t> &rp, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx, std::vector<uint8_t> &coeff) const {
-    rp.assign(1, 0); kind.clear(); idx.clear(); coeff.clear();
+  // ark = true: coefficients in their in-memory Montgomery form (bpgpu_circuit_create_ark converts them on the device)
+  void csr(std::vector<uint32_t> &rp, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx, std::vector<uint8_t> &coeff, bool ark = false) const {
+    size_t nnz = 0;
+    for (auto &lc : constraints) nnz += lc.terms.size();
+    rp.clear(); kind.clear(); idx.clear(); coeff.clear();
+    rp.reserve(constraints.size() + 1); kind.reserve(nnz); idx.reserve(nnz); coeff.resize(nnz * 32);
+    rp.push_back(0);
+    size_t t = 0;
     for (auto &lc : constraints) {
       for (auto &kv : lc.terms) {
         if (kv.first.kind == Variable::Zero) continue;
         kind.push_back(kv.first.kind);
         idx.push_back((uint32_t)kv.first.index);
-        auto b = kv.second.to_bytes();
-        coeff.insert(coeff.end(), b.begin(), b.end());
+        if (ark) kv.second.to_ark_le(&coeff[32 * t]); else kv.second.to_bytes_le(&coeff[32 * t]);
+        t++;
       }
       rp.push_back((uint32_t)kind.size());
     }
+    coeff.resize(t * 32);
   }
   bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
     std::vector<uint32_t> rp, kind, idx;
     std::vector<uint8_t> coeff;
-    csr(rp, kind, idx, coeff);
+    csr(rp, kind, idx, coeff, true);
     Device &d = Device::default_device();
     bpgpu_circuit *c = nullptr;
     uint32_t z32 = 0; uint8_t z8 = 0;
-    d.check(bpgpu_circuit_create(d.ctx(), constraints.size(), rp.data(), kind.empty() ? &z32 : kind.data(),
-                                 idx.empty() ? &z32 : idx.data(), coeff.empty() ? &z8 : coeff.data(), n_mul, m, &c),
-            "bpgpu_circuit_create");
+    d.check(bpgpu_circuit_create_ark(d.ctx(), constraints.size(), rp.data(), kind.empty() ? &z32 : kind.data(),
+                                     idx.empty() ? &z32 : idx.data(), coeff.empty() ? &z8 : coeff.data(), n_mul, m, &c),
+            "bpgpu_circuit_create_ark");
     return c;
   }
 };

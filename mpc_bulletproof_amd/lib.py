@@ -12,7 +12,7 @@ SYMBOLS = [
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
-    "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
+    "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_ark", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
     "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev", "bpgpu_r1cs_verify_batch_param", "bpgpu_r1cs_verify_batch_fs2",
@@ -342,15 +342,16 @@ class BpGpu:
         _lib.bpgpu_prover_destroy(self.ctx, sess)
 
     # ---- R1CS
-    def circuit_create(self, row_ptr, kind, idx, coeff, n_mul, m):
+    def circuit_create(self, row_ptr, kind, idx, coeff, n_mul, m, ark=False):
+        """ark=True: coefficients as ark-ff Montgomery limbs (x * 2^256 mod n)"""
         q = len(row_ptr) - 1
         nnz = len(kind)
         h = C.c_void_p()
         rp = (C.c_uint32 * (q + 1))(*row_ptr)
         kd = (C.c_uint32 * max(nnz, 1))(*kind)
         ix = (C.c_uint32 * max(nnz, 1))(*idx)
-        self._ck(_lib.bpgpu_circuit_create(self.ctx, C.c_size_t(q), rp, kd, ix, _buf(coeff), C.c_size_t(n_mul),
-                                           C.c_size_t(m), C.byref(h)))
+        fn = _lib.bpgpu_circuit_create_ark if ark else _lib.bpgpu_circuit_create
+        self._ck(fn(self.ctx, C.c_size_t(q), rp, kd, ix, _buf(coeff), C.c_size_t(n_mul), C.c_size_t(m), C.byref(h)))
         return h
 
     def circuit_destroy(self, h):

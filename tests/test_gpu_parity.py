@@ -297,6 +297,30 @@ def test_range_verify_batch(gpu, n_bits, nb, c):
         gpu.circuit_destroy(circ)
 
 
+def test_circuit_from_arkworks_coefficients(gpu):
+    """bpgpu_circuit_create_ark: constraint coefficients as ark-ff Montgomery limbs (x * 2^256 mod n) give the same flattened
+    weights as the canonical-bytes circuit (range gadget and 2-phase shuffle rows); a limb vector >= n is rejected."""
+    import mpc_bulletproof_amd as m
+    for okind, param, label, vals in ((o.K_RANGE, 8, b"RangeProofTest", [77]), (o.K_SHUFFLE, 4, b"ShuffleProofTest", [5, 9, 2, 7, 2, 5, 7, 9])):
+        rc, proof, com = o.r1cs_prove(okind, param, label, vals, 3, 16)
+        assert rc == 0
+        s = o.VerifySession(okind, param, label, [], com, proof, 16)
+        rp, kind, idx, coeff = s.csr()
+        ark = b"".join((int.from_bytes(coeff[i:i + 32], "little") * (1 << 256) % N).to_bytes(32, "little") for i in range(0, len(coeff), 32))
+        n_mul, mm = s.n1 + s.n2, s.m
+        c1 = gpu.circuit_create(rp, kind, idx, coeff, n_mul, mm)
+        c2 = gpu.circuit_create(rp, kind, idx, ark, n_mul, mm, ark=True)
+        try:
+            z = o.s2b(0x1234567 + param)
+            assert gpu.flatten_constraints(c1, n_mul, mm, z) == gpu.flatten_constraints(c2, n_mul, mm, z)
+        finally:
+            gpu.circuit_destroy(c1)
+            gpu.circuit_destroy(c2)
+            s.close()
+        with pytest.raises(m.BpGpuError):
+            gpu.circuit_create(rp, kind, idx, N.to_bytes(32, "little") + ark[32:], n_mul, mm, ark=True)
+
+
 def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
     """The grid-split scalar assembly used for large proofs (padded_n or m >= 4096: the 2^14-shuffle of BASELINE
     configs[3]) forced onto small circuits: every MSM scalar, mega_check point and accept bit as the oracle's."""
