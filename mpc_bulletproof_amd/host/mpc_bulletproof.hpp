@@ -85,9 +85,9 @@ class OsRng final : public Rng {
   void rekey(const uint8_t *material, size_t len) override;
  private:
   void refill();
-  uint8_t key_[32], block_[32];
-  uint64_t counter_ = 0;
-  int used_ = 32;
+  uint64_t st_[25];           // Keccak-f[1600] sponge state; words 0..16 are the rate
+  uint64_t blocks_ = 0;
+  int used_ = 17;
 };
 class SeededRng final : public Rng {
  public:
