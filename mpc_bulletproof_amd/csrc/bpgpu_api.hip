@@ -762,7 +762,7 @@ int bpgpu_points_compress(bpgpu_ctx *ctx, const uint8_t *xy, size_t n, uint8_t *
 
 /* ---------------------------------------------------------------- resident generators */
 int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t cap, const uint8_t B[64],
-                      const uint8_t Bb[64], int c, bpgpu_gens **out) {
+                      const uint8_t Bb[64], int c, bpgpu_gens **out) try {
   if (!ctx || !out || !B || !Bb || (cap && (!G || !H))) return BPGPU_E_ARG;
   if (!(c == 4 || c == 8 || c == 10 || c == 12 || c == 14 || c == 16 || c == 20)) return BPGPU_E_ARG;
   *out = nullptr;
@@ -816,6 +816,8 @@ int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t
   if (bad) return fail(BPGPU_E_ARG);
   *out = g;
   return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 void bpgpu_gens_destroy(bpgpu_ctx *ctx, bpgpu_gens *g) {
   if (!g) return;
@@ -937,7 +939,7 @@ int bpgpu_verification_scalars(bpgpu_ctx *ctx, const uint8_t *challenges, size_t
 
 /* ---------------------------------------------------------------- R1CS */
 static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const uint32_t *row_ptr, const uint32_t *kind,
-                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out, bool ark = false) {
+                               const uint32_t *idx, const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out, bool ark = false) try {
   if (!ctx || !out || !row_ptr) return BPGPU_E_ARG;
   *out = nullptr;
   const size_t q = q_real * (1 + nchi);     // CSR rows: block j (rows j q_real ..) holds the chi_j parts of the coefficients
@@ -996,6 +998,8 @@ static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const
   if (bad) return fail(BPGPU_E_ARG);
   *out = c;
   return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 int bpgpu_circuit_create(bpgpu_ctx *ctx, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
                          const uint8_t *coeff, size_t n_mul, size_t m, bpgpu_circuit **out) {
@@ -1242,7 +1246,7 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
 /* ---------------------------------------------------------------- Verifier::verify with the transcript on the device */
 static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                             const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
-                            void *challenges_out, const uint8_t *gadget_label = nullptr, void *chi_out = nullptr) {
+                            void *challenges_out, const uint8_t *gadget_label = nullptr, void *chi_out = nullptr) try {
   if (k >= 32) return BPGPU_E_LEN;
   if (c->nchi > 1 || (c->nchi == 1 && !gadget_label)) return BPGPU_E_ARG;   // one gadget challenge label per schedule
   if (!nb) return BPGPU_OK;
@@ -1269,6 +1273,8 @@ static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, chp, ok, mega, nullptr, dchi));
   and_not(ctx->st, (int32_t *)ok, (const int32_t *)dbad, nb);
   return launch_ok(ctx);
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 int bpgpu_r1cs_verify_batch_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                    const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
@@ -1716,7 +1722,7 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
   jac_to_boundary(st, s->sums, out_xy, nb * 2);
   return launch_ok(ctx);
 }
-int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
+int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) try {
   if (!ctx || !s || !L || !R) return BPGPU_E_ARG;
   if (s->n < 2) return BPGPU_E_LEN;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1728,6 +1734,8 @@ int bpgpu_ipp_round(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *L, uint8_t *R) {
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   for (size_t p = 0; p < nb; p++) { memcpy(L + 64 * p, &tmp[128 * p], 64); memcpy(R + 64 * p, &tmp[128 * p + 64], 64); }
   return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 /* fold_witness with the round's challenges -- inner_product_proof.rs:125-146 (first) / :183-184 */
 // device part of the fold: du / dui = the round's challenges and their inverses (nb each) already in HBM
@@ -1798,7 +1806,7 @@ int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t
  * L, R MSMs, transcript.append_point("L"), ("R"), challenge_scalar("u") (inner_product_proof.rs:119-123,177-181)
  * with the keccak hash chain in a kernel, u^-1 and the fold -- no host round trip between rounds. */
 int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uint8_t *L_out, uint8_t *R_out,
-                     uint8_t *a_out, uint8_t *b_out, uint8_t *states_out) {
+                     uint8_t *a_out, uint8_t *b_out, uint8_t *states_out) try {
   if (!ctx || !s || !states_in || !a_out || !b_out) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -1832,12 +1840,14 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
       memcpy(R_out + (p * k + r) * 64, &tmp[(r * nb + p) * 128 + 64], 64);
     }
   return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 /* final a, b -- inner_product_proof.rs:187-192 */
 // The generators a resident-generator session has folded SO FAR, as points: G'_t = sum_{i = t mod n} cG[i] G_i (and H'), n = the
 // session's current length.  For n == 1 this is the pair (G', H') the remaining state (a, b) refers to -- what a rank of a
 // vector-sharded IPP (sharding.sharded_ipp_create: SURVEY 8e.2) hands to the final log2(ranks) rounds.  Only n == 1 is exposed.
-int bpgpu_ipp_folded_gens(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *G_out, uint8_t *H_out) {
+int bpgpu_ipp_folded_gens(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *G_out, uint8_t *H_out) try {
   if (!ctx || !s || !G_out || !H_out || !s->gens) return BPGPU_E_ARG;
   if (s->n != 1) return BPGPU_E_LEN;
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1855,6 +1865,8 @@ int bpgpu_ipp_folded_gens(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *G_out, uint8_t 
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   for (size_t p = 0; p < nb; p++) { memcpy(G_out + 64 * p, &tmp[128 * p], 64); memcpy(H_out + 64 * p, &tmp[128 * p + 64], 64); }
   return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
 }
 int bpgpu_ipp_finish(bpgpu_ctx *ctx, bpgpu_ipp *s, uint8_t *a_out, uint8_t *b_out) {
   if (!ctx || !s || !a_out || !b_out) return BPGPU_E_ARG;
