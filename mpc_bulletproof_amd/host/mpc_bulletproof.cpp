@@ -193,6 +193,20 @@ Scalar Rng::scalar() {
   return Scalar::from_le_bytes_mod_order_wide(b);
 }
 
+void Rng::scalars(Scalar *out, size_t count) {
+  if (count < 4096) { for (size_t i = 0; i < count; i++) out[i] = scalar(); return; }
+  std::vector<uint64_t> w(4 * count);
+  for (auto &x : w) x = next_u64();
+  const size_t chunks = 64;
+  parallel_for(chunks, [&](size_t c) {
+    for (size_t i = count * c / chunks; i < count * (c + 1) / chunks; i++) {
+      uint8_t b[64] = {0};
+      memcpy(b, &w[4 * i], 32);           // little-endian host
+      out[i] = Scalar::from_le_bytes_mod_order_wide(b);
+    }
+  });
+}
+
 StarkPoint StarkPoint::generator() {
   static const uint8_t GEN[64] = {0xca,0xcf,0x43,0xc9,0x8b,0x3d,0x72,0x3d,0xe0,0x19,0x18,0x0d,0x9b,0xfd,0xac,0xde,0xc7,0xf0,0x40,0x5a,0x41,0xed,0xec,0x7b,0x1b,0x97,0x99,0x85,0xc1,0x15,0xef,0x01,
                                   0x1f,0xdc,0xe8,0x36,0x0c,0x00,0x73,0x28,0xa3,0x43,0xbe,0x1a,0xd1,0xec,0x53,0xde,0x62,0xec,0x46,0xdf,0x01,0x48,0xbe,0xb7,0x30,0x97,0xa4,0x0a,0x06,0x68,0x56,0x00};
@@ -1097,8 +1111,8 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   parallel_for(nb, [&](size_t p) {                                                       // :457-462
     i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
     s_L[p].resize(n1); s_R[p].resize(n1);
-    for (auto &x : s_L[p]) x = rngs[p]->scalar();
-    for (auto &x : s_R[p]) x = rngs[p]->scalar();
+    rngs[p]->scalars(s_L[p].data(), n1);     // (inside a pool worker, i.e. for nb >= 2, the inner loop runs serially)
+    rngs[p]->scalars(s_R[p].data(), n1);
   });
   // three commitments per prover over [B, B_blinding, G_0.., H_0..] -- :465-494 / :532-565
   auto commit3 = [&](size_t lo, size_t hi, const std::vector<Scalar> &ib, const std::vector<Scalar> &ob,
@@ -1143,8 +1157,8 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   parallel_for(nb, [&](size_t p) {
     if (n2 > 0) { i_b2[p] = rngs[p]->scalar(); o_b2[p] = rngs[p]->scalar(); s_b2[p] = rngs[p]->scalar(); }   // :519-527
     s_L[p].resize(n); s_R[p].resize(n);
-    for (size_t i = n1; i < n; i++) s_L[p][i] = rngs[p]->scalar();
-    for (size_t i = n1; i < n; i++) s_R[p][i] = rngs[p]->scalar();
+    rngs[p]->scalars(s_L[p].data() + n1, n - n1);
+    rngs[p]->scalars(s_R[p].data() + n1, n - n1);
   });
   if (n2 > 0) commit3(n1, n, i_b2, o_b2, s_b2, 2);                                        // else identity, :566-576
   lap("prove: randomize + phase-2 commit");

@@ -77,6 +77,9 @@ class Rng {
   virtual uint64_t next_u64() = 0;
   virtual void rekey(const uint8_t *material, size_t len) = 0;
   Scalar scalar();            // 4 x u64 little-endian limbs (+ 4 zero limbs) reduced mod n
+  // count scalars, the same stream as count calls of scalar(): the words are drawn in order, the reductions mod n run on the
+  // thread pool (one prover drawing 2 x 32 766 blinding factors spent 6 ms in them)
+  void scalars(Scalar *out, size_t count);
 };
 class OsRng final : public Rng {
  public:
