@@ -75,6 +75,34 @@ def test_msm_batch(gpu):
     assert gpu.msm_batch(nb, n, sc, pts) == o.msm_batch(sc, pts, nb, n)
 
 
+@pytest.mark.parametrize("nb,n", [(1, 1), (1, 2), (3, 16), (4, 32), (3, 37), (2, 600), (1, 32767), (1, 32768), (1, 32769)])
+def test_msm_window_parallel_group_shapes(gpu, nb, n):
+    """The window-parallel MSM launches (msm_wp_batch: groups of 16 points, <= 32 for a small instance, identity-padded tails,
+    one final sum per instance) at the shapes where the grouping changes, and on either side of the 2^15-term limit above which
+    k_pip.hip takes over.  Identity points, zero scalars and a P / -P pair are mixed in.  Checked against the oracle for the small
+    shapes and against MSM(s_i, k_i G) = (sum s_i k_i) G for the large ones."""
+    sys_path_oracle()
+    import pymodel as pm
+    Gp, Gd = o.gens("G", n, dlogs=True)
+    pts, sc = bytearray(Gp * nb), bytearray(o.random_scalars(400 + n, nb * n))
+    dl = list(o.unscalars(Gd)) * nb
+    if n >= 16:
+        for inst in range(nb):
+            b = inst * n
+            pts[64 * (b + 3):64 * (b + 4)] = bytes(64); dl[b + 3] = 0                           # identity point
+            sc[32 * (b + 5):32 * (b + 6)] = bytes(32)                                           # zero scalar
+            pts[64 * (b + 7):64 * (b + 8)] = pm.p2b(pm.pt_neg(pm.b2p(bytes(pts[64 * (b + 6):64 * (b + 7)]))))   # -P next to P
+            dl[b + 7] = (N - dl[b + 6]) % N
+            sc[32 * (b + 7):32 * (b + 8)] = sc[32 * (b + 6):32 * (b + 7)]
+    got = gpu.msm_batch(nb, n, bytes(sc), bytes(pts)) if nb > 1 else gpu.msm(bytes(sc), bytes(pts))
+    svals = o.unscalars(bytes(sc))
+    for inst in range(nb):
+        tot = sum(svals[inst * n + i] * dl[inst * n + i] for i in range(n)) % N
+        assert got[64 * inst:64 * inst + 64] == o.point_mul(o.s2b(tot), o.generator()), (nb, n, inst)
+    if nb * n <= 2000:
+        assert got == o.msm_batch(bytes(sc), bytes(pts), nb, n)
+
+
 @pytest.mark.parametrize("n", [3, 29, 700])
 def test_msm_shared_points(gpu, n):
     """The three local MSMs of msm_authenticated_iter (shares, MACs, public modifiers) over one point vector:
