@@ -598,7 +598,9 @@ def main():
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs),
-                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"])},
+                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "untimed_before_the_timed_region": f"max(warmup, steps_in_flight) steps, result check, {warm_s:.1f} s of further untimed "
+                                                          "steps (clocks, event pools), one hand-over step per context"},
             "roofline": roof,
             "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "variable-base + fixed-base halves of one step's mega_check MSMs / wall time per step",
                              "achieved": (fp_var + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
