@@ -151,9 +151,24 @@ def _spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    sys.exit(rc)
+    try:
+        while any(p.poll() is None for p in procs):
+            failed = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if failed:                      # the other ranks would wait for the dead one in the next collective
+                rc = abs(failed[0])
+                break
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    sys.exit(max([rc] + [abs(p.returncode or 0) for p in procs]) if rc == 0 else rc)
 
 
 def _lib_hash():

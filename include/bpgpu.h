@@ -53,8 +53,26 @@ void *bpgpu_stream(bpgpu_ctx *ctx);             /* hipStream_t of the ctx (for e
  * 1: more, shorter lanes in the two longest launches of a batch's kernel chain -- one batch alone completes ~25 % sooner
  * (0.8 instead of 1.05 ms for 1024 x 64-bit range proofs), a saturated pipeline runs ~5 % slower.  Results are identical. */
 int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
-/* synchronise and report whether any input since the last read was malformed (1); reading clears the flag.  A diagnostic:
- * the verification entry points reject a malformed proof on its own (ok[p] = 0) and never fail the call for it. */
+/* Launch-route options of ONE context (results never depend on them: every route computes the same bytes; the parity tests
+ * walk all of them through this setter).  The environment variables BPGPU_<NAME> of the same names only seed a new context's
+ * defaults, once, inside bpgpu_create -- nothing reads the environment per call.  BPGPU_E_ARG for an unknown option or a
+ * value outside its range. */
+#define BPGPU_OPT_MSM_WP_MAX 1             /* MSMs of up to this many terms take the window-parallel launches (default 2^15; 0 = never) */
+#define BPGPU_OPT_MSM_PIP2_SINGLE 2        /* 1: one mid-size MSM through k_pip2.hip's one-instance bucket pipeline (default 0) */
+#define BPGPU_OPT_VERIFY_NO_FUSE 3         /* 1: verification as separate point-import / Straus / fixed-base / finalize launches (default 0) */
+#define BPGPU_OPT_VERIFY_WINDOW_PARALLEL 4 /* 0: the fused Straus + fixed-base launch instead of the window-parallel chain (default 1) */
+#define BPGPU_OPT_VERIFY_STRAUS_NP 5       /* points per Straus lane on those paths, 1..4 (default 4) */
+#define BPGPU_OPT_IPP_LITERAL 6            /* 1: bpgpu_ipp_begin always runs the reference's literal schedule (generators folded every round) */
+#define BPGPU_OPT_VS_LARGE_MIN 7           /* padded n / m from which the verifier's scalar assembly is split over the grid (default 4096) */
+#define BPGPU_OPT_TABLE_NP 8               /* proof points per table lane of the window-parallel chain: 1, 2, 4, 8; 0 = by latency mode */
+#define BPGPU_OPT_IPP_TABLE_MAX_N 9        /* bpgpu_ipp_begin builds per-session generator tables up to this n (default 2^16), literal schedule above */
+#define BPGPU_OPT_COUNT 10
+int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
+int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);
+/* synchronise and report whether an operand of the `_dev` (device-resident, asynchronous) calls issued since the last read -- or
+ * since the last synchronous entry point on this context, each of which uses and clears the flag for its own BPGPU_E_ARG -- was
+ * malformed (1); reading clears the flag.  A diagnostic: the verification entry points reject a malformed proof on its own
+ * (ok[p] = 0; that includes a non-canonical gadget challenge of bpgpu_r1cs_verify_batch_param) and never fail the call for it. */
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
 
 /* Per-kernel timing with HIP events recorded on the stream each kernel is launched on (the numbers

@@ -34,6 +34,9 @@ struct bpgpu_ctx {
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
   bool latency_mode = false;      // bpgpu_set_latency_mode
+  // bpgpu_set_option: launch-route selectors of THIS context (tests walk every route through them; a multi-tenant host gives
+  // each tenant its own context).  The BPGPU_* environment variables of the same names only seed the defaults, once, in bpgpu_create.
+  int64_t opt[BPGPU_OPT_COUNT] = {};
   std::vector<hipEvent_t> prof_ev[BPGPU_PROF_KINDS];
   std::vector<hipEvent_t> prof_pool;   // recycled events
   bool prof_skip[BPGPU_PROF_KINDS] = {};
@@ -199,6 +202,15 @@ int bpgpu_create(int device, bpgpu_ctx **out) {
   bpgpu_ctx *ctx = new (std::nothrow) bpgpu_ctx();
   if (!ctx) return BPGPU_E_OOM;
   ctx->device = device;
+  {
+    static const struct { int opt; const char *env; int64_t dflt; } seed[] = {
+        {BPGPU_OPT_MSM_WP_MAX, "BPGPU_MSM_WP_MAX", (int64_t)1 << 15}, {BPGPU_OPT_MSM_PIP2_SINGLE, "BPGPU_PIP2_SINGLE", 0},
+        {BPGPU_OPT_VERIFY_NO_FUSE, "BPGPU_NO_FUSE", 0},               {BPGPU_OPT_VERIFY_WINDOW_PARALLEL, "BPGPU_WINDOW_PARALLEL", 1},
+        {BPGPU_OPT_VERIFY_STRAUS_NP, "BPGPU_STRAUS_NP", 4},           {BPGPU_OPT_IPP_LITERAL, "BPGPU_IPP_LITERAL", 0},
+        {BPGPU_OPT_VS_LARGE_MIN, "BPGPU_VS_LARGE_MIN", 4096},         {BPGPU_OPT_TABLE_NP, "BPGPU_TABLE_NP", 0},
+        {BPGPU_OPT_IPP_TABLE_MAX_N, "BPGPU_IPP_TABLE_MAX_N", (int64_t)1 << 16}};
+    for (auto &s : seed) { const char *e = getenv(s.env); ctx->opt[s.opt] = e ? atoll(e) : s.dflt; }
+  }
   // BPGPU_SINGLE_STREAM=1: one stream per context (deeply pipelined callers overlap ACROSS contexts and
   // hardware queues are a limited resource: GPU_MAX_HW_QUEUES, 4 by default)
   const bool single = getenv("BPGPU_SINGLE_STREAM") && atoi(getenv("BPGPU_SINGLE_STREAM")) != 0;
@@ -242,6 +254,26 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on) {
   if (!ctx) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->latency_mode = on != 0;
+  return BPGPU_OK;
+}
+int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value) {
+  if (!ctx || option <= 0 || option >= BPGPU_OPT_COUNT) return BPGPU_E_ARG;
+  switch (option) {
+    case BPGPU_OPT_MSM_WP_MAX: if (value < 0) return BPGPU_E_ARG; break;                    // 0 = never
+    case BPGPU_OPT_VERIFY_STRAUS_NP: if (value < 1 || value > 4) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_VS_LARGE_MIN: if (value < 1) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_TABLE_NP: if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_IPP_TABLE_MAX_N: if (value < 0) return BPGPU_E_ARG; break;
+    default: if (value != 0 && value != 1) return BPGPU_E_ARG; break;
+  }
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->opt[option] = value;
+  return BPGPU_OK;
+}
+int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value) {
+  if (!ctx || !value || option <= 0 || option >= BPGPU_OPT_COUNT) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  *value = ctx->opt[option];
   return BPGPU_OK;
 }
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on) {
@@ -389,10 +421,10 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
 // chip: one call is 0.6-0.7 ms from 2 to 2^14 terms and 0.77 ms at 2^15 (the bucket launches of k_pip.hip: 0.86 ms there, and
 // ahead from 2^16 terms on: 0.96 against 1.05 ms, 1.07 against 1.59 ms at 2^17; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
-// *done: handled here (n <= 2^15, BPGPU_MSM_WP_MAX overrides, and at most 2^16 groups in all).
+// *done: handled here (n <= 2^15, BPGPU_OPT_MSM_WP_MAX overrides, and at most 2^16 groups in all).
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done,
                         int *bad = nullptr, size_t max_n = 0) {
-  const size_t wp_max = max_n ? max_n : getenv("BPGPU_MSM_WP_MAX") ? (size_t)atoll(getenv("BPGPU_MSM_WP_MAX")) : ((size_t)1 << 15);   // read per call: tests vary it
+  const size_t wp_max = max_n ? max_n : (size_t)ctx->opt[BPGPU_OPT_MSM_WP_MAX];
   *done = false;
   if (!nb || !n || n > wp_max) return BPGPU_OK;
   size_t G, per;
@@ -414,6 +446,7 @@ static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, co
   void *dwp;
   CK(ws_get(ctx, 12, verify_wp_scratch_bytes(ng, G), &dwp));
   VerifyWp v{(const AffDev *)pts, ng, G, dwp, bad ? bad : ctx->d_flag, nullptr, true, converted};
+  if (!verify_wp_layout_fits(v)) { ctx->err = "internal: window-parallel scratch layout exceeds its buffer (msm)"; return BPGPU_E_DEVICE; }
   VerifyDims d{};
   verify_wp_front_launch(ctx->st, v, d, nullptr, nullptr, 0, false);
   verify_wp_windows(ctx->st, v, (const uint32_t *)sc);
@@ -448,8 +481,8 @@ static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void 
     }
   }
   // k_pip2.hip's one-instance pipeline carries the combined batch check; for a lone MSM the window-parallel launches (up to 2^15
-  // terms) and k_pip.hip (from 2^16) are both faster now.  BPGPU_PIP2_SINGLE=1 routes 2^8..2^16 terms through it (tests).
-  const bool pip2_single = getenv("BPGPU_PIP2_SINGLE") && atoi(getenv("BPGPU_PIP2_SINGLE")) != 0;   // read per call
+  // terms) and k_pip.hip (from 2^16) are both faster now.  BPGPU_OPT_MSM_PIP2_SINGLE routes 2^8..2^16 terms through it (tests).
+  const bool pip2_single = ctx->opt[BPGPU_OPT_MSM_PIP2_SINGLE] != 0;
   if (pip2_single && nb == 1 && n >= pip_min && pippenger2_supported(n)) {   // one mid-size instance: seven launches (k_pip2.hip)
     const int c2 = pippenger2_window(n);
     void *dpip;
@@ -532,7 +565,7 @@ static int msm_core_locked(bpgpu_ctx *ctx, size_t n, const uint32_t *dsc, const 
   CK(msm_wp_batch(ctx, 1, n, dsc, dpts, true, dsum, &done));
   if (done) return BPGPU_OK;
   void *dpip;
-  const bool pip2_single = getenv("BPGPU_PIP2_SINGLE") && atoi(getenv("BPGPU_PIP2_SINGLE")) != 0;   // read per call
+  const bool pip2_single = ctx->opt[BPGPU_OPT_MSM_PIP2_SINGLE] != 0;
   if (pip2_single && n >= pip_min && pippenger2_supported(n)) {
     const int c2 = pippenger2_window(n);
     CK(ws_get(ctx, 14, pippenger2_scratch_bytes(n, c2), &dpip));
@@ -769,11 +802,11 @@ int bpgpu_gens_create(bpgpu_ctx *ctx, const uint8_t *G, const uint8_t *H, size_t
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
   size_t ng = 2 + 2 * cap;
+  std::vector<uint8_t> host(ng * 64);   // (before `g`: a bad_alloc here must not leak it)
   bpgpu_gens *g = new (std::nothrow) bpgpu_gens();
   if (!g) return BPGPU_E_OOM;
   g->cap = cap;
   g->c = c;
-  std::vector<uint8_t> host(ng * 64);
   memcpy(&host[0], B, 64);
   memcpy(&host[64], Bb, 64);
   if (cap) { memcpy(&host[128], G, cap * 64); memcpy(&host[128 + cap * 64], H, cap * 64); }
@@ -1075,20 +1108,20 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   CK(ws_get(ctx, 7, nb * nvar * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, nb * nvar * 32, &dvar));
-  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m, (const Words8 *)chi}) * 4, &dzp));
+  VerifyDims d{nb, n1, n, np, k, m, (const Words8 *)chi, (size_t)ctx->opt[BPGPU_OPT_VS_LARGE_MIN]};
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), d) * 4, &dzp));
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
   CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
   void *dstr;
   CK(straus_ws(ctx, 4, nb * nvar, &dstr));
-  VerifyDims d{nb, n1, n, np, k, m, (const Words8 *)chi};
   // per-proof canonicity bits of the scalar assembly (every entry is written by the kernel: no reset)
   void *dbadsc;
   CK(ws_get(ctx, 20, 2 * nb * sizeof(int32_t), &dbadsc));
   int32_t *dbadpt = (int32_t *)dbadsc + nb;   // per-proof malformed-point bits of the Straus / separate-launch paths
   // default: window-parallel variable-base part -- front [tables | inversion pass], scalars, windows, groups,
   // back [Horner | fixed-base MSMs], verdict (k_ec.hip).  Every launch is on ctx->st.
-  const bool no_fuse = getenv("BPGPU_NO_FUSE") && atoi(getenv("BPGPU_NO_FUSE")) != 0;
-  const bool no_wp = getenv("BPGPU_WINDOW_PARALLEL") && atoi(getenv("BPGPU_WINDOW_PARALLEL")) == 0;
+  const bool no_fuse = ctx->opt[BPGPU_OPT_VERIFY_NO_FUSE] != 0;
+  const bool no_wp = ctx->opt[BPGPU_OPT_VERIFY_WINDOW_PARALLEL] == 0;
   // The generator half rides in the back launch when it is small (<= 16 384 (generator, window) pairs per proof, one chunk);
   // otherwise -- few proofs of a mid-size circuit, or a table window the fused kernel is not built for -- it is its own
   // chunked launch ahead of the Horner pass.  The window kernel walks a proof's points serially in every window lane: up to
@@ -1097,7 +1130,8 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   if (!no_fuse && !no_wp && nvar && (fused_fixed || nvar <= 256)) {
     void *dwp;
     CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
-    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc, ctx->latency_mode};
+    VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc, ctx->latency_mode, false, (int)ctx->opt[BPGPU_OPT_TABLE_NP]};
+    if (!verify_wp_layout_fits(v)) { ctx->err = "internal: window-parallel scratch layout exceeds its buffer (verify)"; return BPGPU_E_DEVICE; }
     int32_t *aux = nullptr;
     size_t aux_stride = 0;
     const bool fuse_prep = verify_scalars_aux(circuit_dev(c), d, (int32_t *)dzp, &aux, &aux_stride);
@@ -1129,8 +1163,8 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
   // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
   // so the identity points of 1-phase proofs (A_I2, A_O2, S2) are skipped wave-uniformly inside k_straus.
-  const int vnp_env = getenv("BPGPU_STRAUS_NP") ? atoi(getenv("BPGPU_STRAUS_NP")) : 4;   // read per call: tests vary it
-  const int vnp = vnp_env < 1 ? 1 : (vnp_env > 4 ? 4 : vnp_env);
+  const int vnp_opt = (int)ctx->opt[BPGPU_OPT_VERIFY_STRAUS_NP];
+  const int vnp = vnp_opt < 1 ? 1 : (vnp_opt > 4 ? 4 : vnp_opt);
   const size_t lanes = nvar / vnp, rem = nvar - lanes * vnp;   // `rem` leftover points run one per lane
   const size_t nres = lanes + rem;
   StrausArgs am{}, ar{};
@@ -1331,8 +1365,15 @@ int bpgpu_r1cs_verify_batch_param(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(h2d(ctx, dP, points, nb * nvar * 64));
   CK(h2d(ctx, dS, scalars, nb * 5 * 32));
   CK(h2d(ctx, dC, challenges, nb * (6 + k) * 32));
-  if (dchi) scalars_check(ctx->st, (const Words8 *)dchi, nb * c->nchi, ctx->d_flag);
+  // a non-canonical gadget challenge rejects ITS proof (ok[p] = 0), like any other non-canonical scalar or challenge
+  void *dchibad = nullptr;
+  if (dchi) {
+    CK(ws_get(ctx, 18, nb * 4, &dchibad));
+    HIPCK(ctx, hipMemsetAsync(dchibad, 0, nb * 4, ctx->st));
+    scalars_check_proof(ctx->st, (const Words8 *)dchi, nb * c->nchi, c->nchi, ctx->d_flag, (int32_t *)dchibad);
+  }
   CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, dP, dS, dC, dok, mega ? dmega : nullptr, dfull, dchi));
+  if (dchibad) and_not(ctx->st, (int32_t *)dok, (const int32_t *)dchibad, nb);
   CK(d2h(ctx, ok, dok, nb * 4));
   if (mega) CK(d2h(ctx, mega, dmega, nb * 64));
   if (msm_scalars) CK(d2h(ctx, msm_scalars, dfull, nb * nterms * 32));
@@ -1465,12 +1506,12 @@ static int verify_combined_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   CK(ws_get(ctx, 8, nb * nfix * 32, &dfix));
   CK(ws_get(ctx, 9, tot * 32, &dvar));
   if (c->nchi) return BPGPU_E_ARG;
-  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), VerifyDims{nb, n1, n, np, k, m, nullptr}) * 4, &dzp));
+  VerifyDims d{nb, n1, n, np, k, m, nullptr, (size_t)ctx->opt[BPGPU_OPT_VS_LARGE_MIN]};
+  CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), d) * 4, &dzp));
   CK(ws_get(ctx, 10, nfix * 32, &dfsum));
   CK(ws_get(ctx, 11, 2 * sizeof(JacRaw), &dtwo));
   CK(ws_get(ctx, 15, sizeof(JacRaw), &dsum));
   CK(ws_get(ctx, 14, pippenger_scratch_bytes(tot, cw), &dpip));
-  VerifyDims d{nb, n1, n, np, k, m, nullptr};
   CK(flag_reset(ctx));
   if (verify_combined2_supported(nb, nvar, g->c, np)) {   // eight launches on one stream (k_pip2.hip)
     void *dc2;
@@ -1552,18 +1593,35 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   // ONE proof over arbitrary generators (the reference's `ipp-prover` criterion bench, benches/inner_product.rs:34-64; the tail of a
   // vector-sharded proof): the literal schedule folds G and H every round -- two dependent 252-doubling chains, ~2.8 ms per round
   // however small n is.  Instead build fixed-base tables for THESE generators once (B = B_blinding = Q, w = 1) and run the
-  // resident-generator session: a round becomes table lookups.  Same group elements, same bytes.  BPGPU_IPP_LITERAL=1 keeps the
-  // literal schedule (nb > 1 with per-proof Q always takes it).
-  const int literal = getenv("BPGPU_IPP_LITERAL") ? atoi(getenv("BPGPU_IPP_LITERAL")) : 0;   // read per call: tests vary it
-  if (nb == 1 && n >= 2 && !literal) {
-    bpgpu_gens *g = nullptr;
-    int rc = bpgpu_gens_create(ctx, G, H, n, Q, Q, n <= 1024 ? 8 : 4, &g);
-    if (rc) return rc;
-    uint8_t one[32] = {1};
-    rc = bpgpu_ipp_begin_gens(ctx, g, 1, n, one, G_factors, H_factors, a, b, out);
-    if (rc) { bpgpu_gens_destroy(ctx, g); return rc; }
-    (*out)->own_gens = g;
-    return BPGPU_OK;
+  // resident-generator session: a round becomes table lookups.  Same group elements, same bytes.  BPGPU_OPT_IPP_LITERAL keeps the
+  // literal schedule (nb > 1 with per-proof Q always takes it).  The tables are per session (256 KB per generator at c = 8 up to
+  // n = 1024, 32 KB at c = 4 above: 2 GB at n = 2^15) and their build grows with n, so the route is bounded: n <=
+  // BPGPU_OPT_IPP_TABLE_MAX_N (default 2^16), tables + staging within half of the free device memory, and a table build that
+  // runs out of memory falls back to the literal schedule, whose footprint is O(n).
+  int64_t literal = 0, table_max_n = 0;
+  (void)bpgpu_get_option(ctx, BPGPU_OPT_IPP_LITERAL, &literal);
+  (void)bpgpu_get_option(ctx, BPGPU_OPT_IPP_TABLE_MAX_N, &table_max_n);
+  if (nb == 1 && n >= 2 && !literal && n <= (size_t)table_max_n) {
+    const int c = n <= 1024 ? 8 : 4;
+    const size_t per_gen = (252 / c + 1) * ((size_t)1 << (c - 1)), ng = 2 + 2 * n;
+    size_t stage_gens = ((size_t)8 << 30) / ((per_gen + 252 / c + 1) * sizeof(JacRaw));
+    if (stage_gens > ng) stage_gens = ng;
+    const size_t need = ng * per_gen * sizeof(AffDev) + stage_gens * (per_gen + 252 / c + 1) * sizeof(JacRaw) + ng * 192;
+    size_t free_b = 0, total_b = 0;
+    bool fits = false;
+    { std::lock_guard<std::mutex> lk(ctx->mu);
+      fits = hipSetDevice(ctx->device) == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && need <= free_b / 2; }
+    if (fits) {
+      bpgpu_gens *g = nullptr;
+      int rc = bpgpu_gens_create(ctx, G, H, n, Q, Q, c, &g);
+      if (rc == BPGPU_OK) {
+        uint8_t one[32] = {1};
+        rc = bpgpu_ipp_begin_gens(ctx, g, 1, n, one, G_factors, H_factors, a, b, out);
+        if (rc == BPGPU_OK) { (*out)->own_gens = g; return BPGPU_OK; }
+        bpgpu_gens_destroy(ctx, g);
+      }
+      if (rc != BPGPU_E_OOM) return rc;     // out of memory: the literal schedule below
+    }
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));

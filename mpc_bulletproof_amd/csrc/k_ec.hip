@@ -429,13 +429,12 @@ __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, con
 }
 // points per table lane: 8 = fewest instructions (one inversion per 8 points), 4 (default) = half the dependency chain of
 // the front launch for +1.3 % instructions per batch, 1 (latency mode) = 7 additions + one inversion per lane, the shortest
-// chain (a lone batch: 0.665 ms against 0.715 ms with 2).  BPGPU_TABLE_NP overrides.
+// chain (a lone batch: 0.665 ms against 0.715 ms with 2).  VerifyWp::table_np (BPGPU_OPT_TABLE_NP) overrides.
 static int wp_tnp(const VerifyWp &v) {
-  static const int env = getenv("BPGPU_TABLE_NP") ? atoi(getenv("BPGPU_TABLE_NP")) : 0;
-  const int t = env ? env : (v.latency_mode ? 1 : 4);
+  const int t = v.table_np ? v.table_np : (v.latency_mode ? 1 : 4);
   return t == 8 ? 8 : (t == 2 ? 2 : (t == 1 ? 1 : 4));
 }
-struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; };
+struct WpLayout { TablesArgs t; JacRaw *winsum, *varsum; unsigned blocks; size_t bytes; };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar) {
   // the layout depends on the points per table lane (wp_tnp): fewer points per lane = more lanes, but the staging is per
@@ -467,12 +466,10 @@ static WpLayout wp_layout(const VerifyWp &v) {
   L.varsum = (JacRaw *)sp; sp += al256(v.nb * sizeof(JacRaw));
   L.t.bad_lane = (int32_t *)sp; sp += al256(v.nb * L.t.lanes * 4);
   L.blocks = (unsigned)nblk;
-  if ((size_t)(sp - (uint8_t *)v.scratch) > verify_wp_scratch_bytes(v.nb, v.nvar)) {   // the caller sized the buffer with that function
-    fprintf(stderr, "bpgpu: verification scratch layout exceeds verify_wp_scratch_bytes\n");
-    abort();
-  }
+  L.bytes = (size_t)(sp - (uint8_t *)v.scratch);
   return L;
 }
+bool verify_wp_layout_fits(const VerifyWp &v) { return wp_layout(v).bytes <= verify_wp_scratch_bytes(v.nb, v.nvar); }
 // tables of the proof points | inversion pass of the scalar assembly (with_prep = false: tables only)
 void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
                             size_t aux_stride, bool with_prep) {

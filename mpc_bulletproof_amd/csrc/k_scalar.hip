@@ -33,6 +33,10 @@ void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad) {
   if (!n) return;
   hipLaunchKernelGGL(k_scalars_check, dim3((n + 255) / 256), dim3(256), 0, st, in, n, bad);
 }
+void scalars_check_proof(hipStream_t st, const Words8 *in, size_t n, size_t per_unit, int *bad, int32_t *bad_unit) {
+  if (!n) return;
+  hipLaunchKernelGGL(k_scalars_check_proof, dim3((n + 255) / 256), dim3(256), 0, st, in, n, per_unit, bad, bad_unit);
+}
 
 // Scalar::batch_inverse: Montgomery's trick, RUN elements per lane, one Fermat inversion per lane
 template <int RUN>
@@ -762,7 +766,7 @@ __global__ void __launch_bounds__(VSL_TPB) k_vsl_tail(CircuitDev c, VerifyDims d
 }
 
 static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
-  const size_t thr = getenv("BPGPU_VS_LARGE_MIN") ? (size_t)atol(getenv("BPGPU_VS_LARGE_MIN")) : 4096;
+  const size_t thr = d.vs_large_min ? d.vs_large_min : 4096;
   return d.padded_n >= thr || d.m >= thr || c.q >= 4 * thr;
 }
 size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d) {

@@ -60,11 +60,17 @@ bool verify_msm_fused(hipStream_t st, int np, const StrausArgs &a, JacRaw *out_v
 // latency_mode: more, shorter lanes in the two longest launches (1 point per table lane, 32 lanes per fixed-base MSM, a quad per group in the first Horner stage): one batch
 // alone finishes ~25 % sooner, a pipelined stream of batches runs ~5 % slower (more instructions)
 // points_converted: points_abi holds AffDev rows (already validated and in Montgomery form: points_from_boundary) instead of ABI bytes
-struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; bool points_converted = false; };
-struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */ };
+// table_np: points per table lane (1, 2, 4, 8; 0 = by mode: 4, or 1 in latency mode) -- BPGPU_OPT_TABLE_NP
+struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* verify_wp_scratch_bytes */; int *bad; const int32_t *bad_sc; bool latency_mode; bool points_converted = false; int table_np = 0; };
+struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */
+                    size_t vs_large_min = 0; /* padded_n / m from which the scalar assembly is split over the grid (0 = 4096) -- BPGPU_OPT_VS_LARGE_MIN */ };
 struct VsPrepArgs;
 size_t verify_wp_scratch_bytes(size_t nb, size_t nvar);
 bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n);
+// the launches below carve v.scratch up by (nb, nvar, table_np): true when that layout stays inside verify_wp_scratch_bytes(nb, nvar).
+// The caller checks it once after sizing the buffer and fails the call (BPGPU_E_DEVICE) otherwise -- an internal sizing bug must
+// not become an out-of-bounds write on the device, nor end the host process.
+bool verify_wp_layout_fits(const VerifyWp &v);
 // prep_* describe the inversion pass to fuse (vs_prep.cuh; prep_nb == 0: tables only)
 void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
                             size_t aux_stride, bool with_prep);
@@ -132,6 +138,8 @@ void verify_finalize(hipStream_t st, const JacRaw *var, size_t nvar, const JacRa
 
 // ---- scalar field (k_scalar.hip) ---------------------------------------------------------------
 void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad);   // canonical (< n)?
+// the same with per-unit attribution: bad_unit[i / per_unit] = 1 for a non-canonical scalar i (bad_unit zeroed by the caller)
+void scalars_check_proof(hipStream_t st, const Words8 *in, size_t n, size_t per_unit, int *bad, int32_t *bad_unit);
 void batch_inverse(hipStream_t st, Words8 *io, size_t n, int *bad_zero);
 void inner_product(hipStream_t st, const Words8 *a, const Words8 *b, size_t n, Words8 *out, void *scratch);
 size_t inner_product_scratch_bytes(size_t n);

@@ -135,8 +135,9 @@ uint64_t SeededRng::next_u64() {
 }
 // Keccak sponge DRBG: the 1600-bit state is seeded with 32 bytes of getrandom(2); output is squeezed 136 bytes per permutation
 // (17 words; the first version hashed twice per 32 bytes, and 256 provers drawing 525 000 blinding scalars spent 150 ms in it);
-// rekey() absorbs its material into the rate and permutes; every 64th block the rate is zeroed before the permutation, so a
-// captured state does not reveal the output before the last such point.
+// rekey() absorbs its material into the rate and permutes.  Forward secrecy: the rate is zeroed before EVERY permutation (the
+// sponge "forget" step: the next state depends on the 512-bit capacity only), so a captured state reveals nothing of the
+// blocks already handed out -- Keccak-f is invertible, but the inverse needs the rate words that were overwritten.
 namespace { void permute_words(uint64_t s[25]); }
 OsRng::OsRng() {
   uint8_t key[32];
@@ -159,7 +160,8 @@ OsRng::OsRng() {
   used_ = 0;
 }
 void OsRng::refill() {
-  if ((++blocks_ & 63) == 0) for (int i = 0; i < 17; i++) st_[i] = 0;   // forget
+  ++blocks_;
+  for (int i = 0; i < 17; i++) st_[i] = 0;   // forget: every block (17 stores against a 24-round permutation)
   permute_words(st_);
   used_ = 0;
 }
@@ -219,7 +221,8 @@ StarkPoint StarkPoint::generator() {
 // A persistent pool: creating and joining 16 threads costs ~0.4 ms, and one prove_batch call runs a dozen parallel loops.
 // Worker t always takes the t-th contiguous slice of a loop, so the thread that built a prover's constraint system is the
 // one that later packs and frees it (its allocations stay in that thread's malloc arena).  A loop started from inside a
-// worker runs serially.
+// running loop -- on a worker OR on the calling thread while it runs its own slice -- runs serially (the caller holds the
+// non-recursive run_mu_ during its slice: a nested run() from there would lock it again).
 namespace {
 class Pool {
  public:
@@ -243,7 +246,10 @@ class Pool {
       n_ = n; nt_ = nt; f_ = &f; err_ = err.data(); pending_ = nt - 1; gen_++;
     }
     cv_.notify_all();
-    slice(0);
+    {
+      struct InLoop { bool was; InLoop() : was(tl_worker_) { tl_worker_ = true; } ~InLoop() { tl_worker_ = was; } } in_loop;
+      slice(0);
+    }
     std::unique_lock<std::mutex> lk(mu_);
     done_.wait(lk, [&] { return pending_ == 0; });
     f_ = nullptr;
@@ -1111,7 +1117,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   parallel_for(nb, [&](size_t p) {                                                       // :457-462
     i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
     s_L[p].resize(n1); s_R[p].resize(n1);
-    rngs[p]->scalars(s_L[p].data(), n1);     // (inside a pool worker, i.e. for nb >= 2, the inner loop runs serially)
+    rngs[p]->scalars(s_L[p].data(), n1);     // (inside a running loop, i.e. for nb >= 2, the inner loop runs serially)
     rngs[p]->scalars(s_R[p].data(), n1);
   });
   // three commitments per prover over [B, B_blinding, G_0.., H_0..] -- :465-494 / :532-565

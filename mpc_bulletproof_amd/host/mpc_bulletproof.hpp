@@ -65,9 +65,10 @@ class Scalar {
 // Randomness of the prover (blinding factors).  The reference builds it from the transcript, re-keyed with the
 // witness blindings and finalized with thread_rng() (src/r1cs/prover.rs:435-445): Prover::prove re-keys whatever Rng
 // it is given the same way (rekey() with the transcript state and every v_blinding) before the first draw.
-//   OsRng      -- the default and the only one for production use: a keccak-256 hash-DRBG keyed with 32 bytes from
-//                 getrandom(2) (/dev/urandom as the fallback), forward-secure (the key is ratcheted after every block),
-//                 rekey() mixes caller material into the key.
+//   OsRng      -- the default and the only one for production use: a Keccak-f[1600] sponge keyed with 32 bytes from
+//                 getrandom(2) (/dev/urandom as the fallback), 136 output bytes per permutation; forward-secure: the rate
+//                 is zeroed before every permutation, so a captured state does not reveal earlier output blocks;
+//                 rekey() absorbs caller material into the state.
 //   SeededRng  -- TEST / BENCH ONLY: the splitmix64 stream of a 64-bit seed, so that proofs can be replayed and
 //                 compared byte for byte with the CPU oracle; rekey() is a no-op.  Proofs made with it are NOT
 //                 zero-knowledge (64 bits of non-cryptographic state).

@@ -7,7 +7,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
+    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_set_option", "bpgpu_get_option", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
@@ -59,6 +59,9 @@ def host_alloc(nbytes, data=None):
 def host_free(p):
     _lib.bpgpu_host_free(p)
 E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
+# bpgpu_set_option (include/bpgpu.h BPGPU_OPT_*)
+OPT = {"msm_wp_max": 1, "msm_pip2_single": 2, "verify_no_fuse": 3, "verify_window_parallel": 4, "verify_straus_np": 5,
+       "ipp_literal": 6, "vs_large_min": 7, "table_np": 8, "ipp_table_max_n": 9}
 # bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
 PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
               "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_front_scalars_digits",
@@ -104,6 +107,32 @@ class BpGpu:
             raise BpGpuError(rc, _lib.bpgpu_strerror(rc).decode() + " | " + _lib.bpgpu_last_error(self.ctx).decode())
 
     # ---- plumbing
+    def set_option(self, name, value):
+        """launch-route option of this context (OPT keys; include/bpgpu.h BPGPU_OPT_*)"""
+        self._ck(_lib.bpgpu_set_option(self.ctx, C.c_int(OPT[name]), C.c_int64(int(value))))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        self._ck(_lib.bpgpu_get_option(self.ctx, C.c_int(OPT[name]), C.byref(v)))
+        return v.value
+
+    def options(self, **kw):
+        """context manager: set options, restore the previous values on exit"""
+        gpu = self
+
+        class _Scope:
+            def __enter__(s):
+                s.old = {k: gpu.get_option(k) for k in kw}
+                for k, v in kw.items():
+                    gpu.set_option(k, v)
+                return gpu
+
+            def __exit__(s, *exc):
+                for k, v in s.old.items():
+                    gpu.set_option(k, v)
+                return False
+        return _Scope()
+
     def sync(self):
         self._ck(_lib.bpgpu_sync(self.ctx))
 

@@ -82,3 +82,29 @@ def test_host_harness_lives_under_tests():
     host = os.path.join(ROOT, "mpc_bulletproof_amd", "host")
     assert sorted(f for f in os.listdir(host) if f.endswith((".cpp", ".hpp"))) == ["mpc_bulletproof.cpp", "mpc_bulletproof.hpp"]
     assert os.path.exists(os.path.join(ROOT, "tests", "host", "capi.cpp"))
+
+
+def test_thread_pool_nested_loops_do_not_deadlock():
+    """The host mirror's persistent pool: a parallel_for started from inside a running loop -- on a worker or on the calling
+    thread while it runs its own slice -- must run serially instead of re-locking the pool (Prover::prove_batch with nb >= 2
+    provers of >= 4096 multipliers draws its blinding vectors that way).  CPU only: no device call."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "host", "pool_test")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    for threads in ("4", "2"):
+        r = subprocess.run([exe], env=dict(os.environ, BPH_THREADS=threads), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0 and "all passed" in r.stdout, r.stdout + r.stderr
+
+
+def test_options_are_per_context_and_validated():
+    """bpgpu_set_option / bpgpu_get_option need a context, i.e. a device: without one only the argument checks can run."""
+    import ctypes as C
+    import mpc_bulletproof_amd as m
+    lib = C.CDLL(m.lib.SO_PATH)
+    v = C.c_int64()
+    assert lib.bpgpu_set_option(None, 1, C.c_int64(0)) == m.lib.E_ARG
+    assert lib.bpgpu_get_option(None, 1, C.byref(v)) == m.lib.E_ARG
+    # every option of the header has a name in the binding
+    hdr = open(os.path.join(ROOT, "include", "bpgpu.h")).read()
+    ids = {int(x) for x in re.findall(r"#define BPGPU_OPT_(?!COUNT)[A-Z_0-9]+ (\d+)", hdr)}
+    assert ids == set(m.lib.OPT.values()) and max(ids) + 1 == int(re.search(r"#define BPGPU_OPT_COUNT (\d+)", hdr).group(1))

@@ -138,6 +138,49 @@ def test_prove_verify_64bit_and_errors(host):
     assert _verify(host, o.K_DUMMY, 8, b"test", [], o.generator(), proof, 8)[0] == -1
 
 
+@pytest.mark.parametrize("lg", range(1, 11))
+def test_dummy_circuit_single_proof_prove_and_verify(host, lg):
+    """The reference's r1cs benches (benches/r1cs.rs:24-55,57-108): ONE prover / verifier of the dummy circuit with 2^lg
+    multipliers, lg = 1..10 -- the single-proof shapes that hit the round-2 scratch overrun.  Proof bytes and commitment as
+    the oracle's; accepted by the GPU verifier and the oracle; a tampered proof is rejected with the oracle's mega_check."""
+    n = 1 << lg
+    rc, proof, com = _prove(host, o.K_DUMMY, n, b"test", [], 60 + lg, n)
+    assert rc == 0
+    rc_o, proof_o, com_o = o.r1cs_prove(o.K_DUMMY, n, b"test", [], 60 + lg, n)
+    assert rc_o == 0 and (proof, com) == (proof_o, com_o)
+    rc, mega = _verify(host, o.K_DUMMY, n, b"test", [], com, proof, n)
+    assert rc == 0 and mega == bytes(64)
+    assert o.r1cs_verify(o.K_DUMMY, n, b"test", [], com, proof, n) == 0
+    bad = bytearray(proof)
+    bad[-40] ^= 2                                             # ipp a
+    s = o.VerifySession(o.K_DUMMY, n, b"test", [], com, bytes(bad), n)
+    rc, mega = _verify(host, o.K_DUMMY, n, b"test", [], com, bytes(bad), n)
+    assert rc == -1 and s.rc != 0 and mega == s.mega_check()
+    s.close()
+
+
+def test_prove_batch_two_provers_of_4096_multipliers(host):
+    """Two lock-step provers whose blinding vectors are >= 4096 scalars each: Rng::scalars spreads its reductions over the
+    thread pool from INSIDE prove_batch's per-prover loop (a nested parallel_for, which deadlocked the pool before round 3).
+    Proofs as the oracle's."""
+    nb, nvals, n_bits = 2, 64, 64
+    n = nvals * n_bits
+    label = b"RangeProofTest"
+    vals = [((0x9E3779B97F4A7C15 * (i + 3 + 7 * p)) & ((1 << 64) - 1)) for p in range(nb) for i in range(nvals)]
+    arr = (C.c_uint64 * len(vals))(*vals)
+    proofs = (C.c_uint8 * (nb * 4096))()
+    plen = C.c_size_t(0)
+    com = (C.c_uint8 * (nb * nvals * 64))()
+    rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(nvals), C.c_size_t(n_bits), o._buf(label), C.c_size_t(len(label)),
+                                    arr, C.c_uint64(31), C.c_size_t(n), proofs, C.byref(plen), com)
+    assert rc == 0
+    L = plen.value
+    param = n_bits | (nvals << 16)
+    rc_o, proof_o, com_o = o.r1cs_prove(o.K_RANGE_MULTI, param, label, vals[nvals:], 32, n)
+    assert rc_o == 0 and bytes(proofs)[L:2 * L] == proof_o and bytes(com)[nvals * 64:] == com_o
+    assert _verify(host, o.K_RANGE_MULTI, param, label, [], bytes(com)[:nvals * 64], bytes(proofs)[:L], n)[0] == 0
+
+
 def test_reference_tests_restated_in_cpp():
     exe = os.path.join(ROOT, "tests", "host", "host_tests")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)

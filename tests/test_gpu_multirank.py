@@ -24,17 +24,40 @@ def _free_port():
     return p
 
 
+def _run_ranks(tmp_path, world, args, port, timeout=600):
+    """start `world` rank_worker.py children (output to files: a full pipe must never stall a rank that the other one is waiting
+    for in a collective), wait for all of them, and kill whatever is left on a timeout or a failure -- no orphan keeps the GPU"""
+    import time
+    procs, logs = [], []
+    try:
+        for r in range(world):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            logs.append(open(tmp_path / f"rank{r}.log", "w"))
+            procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py")] + args, env=env,
+                                          stdout=logs[-1], stderr=subprocess.STDOUT))
+        deadline = time.time() + timeout
+        while any(p.poll() is None for p in procs):
+            if any(p.poll() not in (None, 0) for p in procs) or time.time() > deadline:
+                break                      # one rank failed (its peers would wait for it forever) or time is up
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+        for f in logs:
+            f.close()
+    outs = [(tmp_path / f"rank{r}.log").read_text() for r in range(world)]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    return outs
+
+
 def test_sharded_msm_and_combined_check_two_ranks_one_gpu(tmp_path):
     world, n_terms, n_bits, nb = 2, 2999, 8, 9
     port = _free_port()
     prefix = str(tmp_path / "rank")
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "rank_worker.py"), prefix, str(n_terms), str(n_bits), str(nb)],
-                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
-    outs = [p.communicate(timeout=600)[0] for p in procs]
-    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    outs = _run_ranks(tmp_path, world, [prefix, str(n_terms), str(n_bits), str(nb)], port)
     res = [json.load(open(f"{prefix}.{r}")) for r in range(world)]
     # term-range-sharded MSM: host-buffer and resident-operand forms, both ranks, == the oracle's single MSM
     sc = o.random_scalars(4100, n_terms)

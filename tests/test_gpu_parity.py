@@ -18,6 +18,20 @@ def gpu():
     g.close()
 
 
+@pytest.fixture
+def opts(gpu):
+    """set launch-route options of the shared context for ONE test (bpgpu_set_option); the previous values come back afterwards"""
+    old = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            old.setdefault(k, gpu.get_option(k))
+            gpu.set_option(k, v)
+    yield set_
+    for k, v in old.items():
+        gpu.set_option(k, v)
+
+
 def J(c, k):
     return b"".join(map(H, c[k]))
 
@@ -325,6 +339,59 @@ def test_range_verify_batch(gpu, n_bits, nb, c):
         gpu.circuit_destroy(circ)
 
 
+@pytest.mark.parametrize("tnp", [1, 2, 4, 8])
+@pytest.mark.parametrize("nb", [1, 2, 3, 5])
+def test_verify_handful_of_proofs_every_table_lane_shape(gpu, opts, nb, tnp):
+    """Regression for the round-2 device fault: a handful of proofs through the window-parallel launches at every
+    points-per-table-lane setting (the staging is per BLOCK of 64 lanes, so for few proofs the block rounding decides the
+    scratch layout: verify_wp_scratch_bytes takes the maximum over the lane shapes, and the entry point refuses a layout that
+    does not fit instead of launching).  Accept bits, mega_check points (tampered proofs included) and all MSM scalars as the
+    oracle's."""
+    opts(table_np=tnp)
+    test_range_verify_batch(gpu, 8, nb, 8)
+
+
+@pytest.mark.parametrize("lg", [1, 2, 3, 5, 7, 10])
+@pytest.mark.parametrize("tnp", [0, 8])
+def test_verify_single_dummy_circuit_proof(gpu, opts, lg, tnp):
+    """ONE proof of the reference's bench circuit (benches/r1cs.rs:24-33: n = 2^lg multipliers in a chain) -- the shape of the
+    round-2 fault (nb = 1, window-parallel launches with the generator half as its own chunked launch for the larger sizes):
+    verdict, mega_check point and every MSM scalar as the oracle's, for the proof and for a tampered copy."""
+    n = 1 << lg
+    opts(table_np=tnp)
+    rc, proof, com = o.r1cs_prove(o.K_DUMMY, n, b"test", [], 40 + lg, n)
+    assert rc == 0
+    bad = bytearray(proof)
+    bad[8 + 11 * 64 + 3] ^= 4                                  # t_x
+    g = _gens(gpu, n, 8)
+    try:
+        for pr in (proof, bytes(bad)):
+            s = o.VerifySession(o.K_DUMMY, n, b"test", [], com, pr, n)
+            rp, kind, idx, coeff = s.csr()
+            circ = gpu.circuit_create(rp, kind, idx, coeff, s.n1 + s.n2, s.m)
+            try:
+                k, pts, sc = bh.verify_inputs(pr, com)
+                ok, mega, full = gpu.r1cs_verify_batch(g, circ, 1, s.n1, s.k, s.m, pts, sc, s.challenges(), True, True)
+                assert ok == [1 if pr is proof else 0] and (s.rc == 0) == (pr is proof)
+                assert mega == s.mega_check() and full == s.msm_terms()[0]
+            finally:
+                gpu.circuit_destroy(circ)
+                s.close()
+    finally:
+        gpu.gens_destroy(g)
+
+
+def test_options_setter_rejects_bad_values(gpu):
+    import mpc_bulletproof_amd as m
+    for name, bad in (("verify_straus_np", 5), ("table_np", 3), ("vs_large_min", 0), ("ipp_literal", 2), ("msm_wp_max", -1)):
+        with pytest.raises(m.BpGpuError):
+            gpu.set_option(name, bad)
+    assert gpu.get_option("msm_wp_max") == 1 << 15 and gpu.get_option("verify_window_parallel") == 1
+    with gpu.options(msm_wp_max=7):
+        assert gpu.get_option("msm_wp_max") == 7
+    assert gpu.get_option("msm_wp_max") == 1 << 15
+
+
 def test_circuit_from_arkworks_coefficients(gpu):
     """bpgpu_circuit_create_ark: constraint coefficients as ark-ff Montgomery limbs (x * 2^256 mod n) give the same flattened
     weights as the canonical-bytes circuit (range gadget and 2-phase shuffle rows); a limb vector >= n is rejected."""
@@ -349,10 +416,10 @@ def test_circuit_from_arkworks_coefficients(gpu):
             gpu.circuit_create(rp, kind, idx, N.to_bytes(32, "little") + ark[32:], n_mul, mm, ark=True)
 
 
-def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
+def test_verify_scalars_large_proof_path(gpu, golden_r1cs, opts):
     """The grid-split scalar assembly used for large proofs (padded_n or m >= 4096: the 2^14-shuffle of BASELINE
     configs[3]) forced onto small circuits: every MSM scalar, mega_check point and accept bit as the oracle's."""
-    monkeypatch.setenv("BPGPU_VS_LARGE_MIN", "1")
+    opts(vs_large_min=1)
     g = _gens(gpu, 16)
     try:
         for rec in golden_r1cs["range"]:
@@ -398,16 +465,13 @@ def test_verify_scalars_large_proof_path(gpu, golden_r1cs, monkeypatch):
 
 @pytest.mark.parametrize("np_,fuse,wp,c", [(4, True, 1, 8), (4, True, 1, 16), (4, True, 0, 8), (3, True, 0, 8), (2, True, 0, 8),
                                            (4, False, 0, 8), (1, False, 0, 8)])
-def test_verify_batch_launch_variants(gpu, monkeypatch, np_, fuse, wp, c):
+def test_verify_batch_launch_variants(gpu, opts, np_, fuse, wp, c):
     """Batches of >= 64 proofs take the window-parallel path (tables | windows | Horner + verdict, 18 proof points =
-    4.5 table lanes per proof); BPGPU_WINDOW_PARALLEL=0 selects the fused Straus launch (role-major lanes + small
-    fixed-base MSMs in one kernel, a remainder launch for 18 mod 4 points), BPGPU_NO_FUSE=1 the separate launches.
+    4.5 table lanes per proof); option verify_window_parallel = 0 selects the fused Straus launch (role-major lanes + small
+    fixed-base MSMs in one kernel, a remainder launch for 18 mod 4 points), verify_no_fuse = 1 the separate launches.
     Accept bits, mega_check points (tampered proofs included) and all MSM scalars must equal the oracle's in every
     variant."""
-    monkeypatch.setenv("BPGPU_STRAUS_NP", str(np_))
-    monkeypatch.setenv("BPGPU_WINDOW_PARALLEL", str(wp))
-    if not fuse:
-        monkeypatch.setenv("BPGPU_NO_FUSE", "1")
+    opts(verify_straus_np=np_, verify_window_parallel=wp, verify_no_fuse=0 if fuse else 1)
     test_range_verify_batch(gpu, 8, 70, c)
 
 
@@ -424,13 +488,13 @@ def test_verify_batch_latency_mode(gpu, n_bits, nb, c):
 
 
 @pytest.mark.parametrize("wp", [1, 0])
-def test_verify_batch_rejects_malformed_proofs_one_by_one(gpu, monkeypatch, wp):
+def test_verify_batch_rejects_malformed_proofs_one_by_one(gpu, opts, wp):
     """An off-curve proof point, a non-canonical proof scalar or a non-canonical challenge makes THAT proof's accept bit
     0 and leaves the other verdicts of a 70-proof batch alone (the reference rejects a malformed proof with
     FormatError / VerificationError on its own: r1cs/proof.rs:128-207, verifier.rs:401-444); the call itself
     succeeds.  Both the window-parallel launches (validation inside the table lanes / the scalar assembly) and the
     fused Straus launch.  The context-wide input flag is raised as a diagnostic and cleared by reading it."""
-    monkeypatch.setenv("BPGPU_WINDOW_PARALLEL", str(wp))
+    opts(verify_window_parallel=wp)
     recs, cap = bh.make_range_batch(8, 70)
     s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
     rp, kind, idx, coeff = s0.csr()
@@ -591,12 +655,15 @@ def _ipp_create_gpu(gpu, label, nb, n, Q, Gf, Hf, G, H, shared, a, b, gens=None,
     return Ls, Rs, aa, bb, chs
 
 
-@pytest.mark.parametrize("literal", [0, 1])
-def test_ipp_create_golden(gpu, golden_ipp, monkeypatch, literal):
+@pytest.mark.parametrize("literal", [0, 1, 2])
+def test_ipp_create_golden(gpu, golden_ipp, opts, literal):
     """InnerProductProof::create of ONE proof over arbitrary generators: through tables built for the session (default: rounds are
-    table lookups) and through the literal generator-folding schedule (BPGPU_IPP_LITERAL=1) -- the same bytes."""
+    table lookups) and through the literal generator-folding schedule (option ipp_literal = 1) -- the same bytes."""
     sys_path_oracle()
-    monkeypatch.setenv("BPGPU_IPP_LITERAL", str(literal))
+    if literal == 2:            # above the bound of the table route (ipp_table_max_n): the O(n)-memory literal schedule takes over
+        opts(ipp_table_max_n=1)
+    else:
+        opts(ipp_literal=literal)
     for c in golden_ipp["create"]:
         n = c["n"]
         Gp, Hp = o.gens("G", n), o.gens("H", n)
@@ -659,15 +726,15 @@ def sys_path_oracle():
 
 # ------------------------------------------------------------------ large MSM (bucket method)
 @pytest.mark.parametrize("route", ["default", "pip2", "bucket"])
-def test_msm_pippenger_edge_cases(gpu, monkeypatch, route):
+def test_msm_pippenger_edge_cases(gpu, opts, route):
     sys_path_oracle()
     """zero / one / n-1 scalars, identity points, duplicates, P and -P pairs must come out exactly as the oracle's, through
     each of the three MSM routes (see test_msm_pippenger_sizes)."""
     import pymodel as pm
     if route != "default":
-        monkeypatch.setenv("BPGPU_MSM_WP_MAX", "0")
+        opts(msm_wp_max=0)
     if route == "pip2":
-        monkeypatch.setenv("BPGPU_PIP2_SINGLE", "1")
+        opts(msm_pip2_single=1)
     n = 640
     Gp = o.gens("G", n)
     pts = bytearray(Gp)
@@ -691,15 +758,15 @@ def test_msm_pippenger_edge_cases(gpu, monkeypatch, route):
 
 @pytest.mark.parametrize("route", ["default", "pip2", "bucket"])
 @pytest.mark.parametrize("n", [512, 5000, 98347])
-def test_msm_pippenger_sizes(gpu, monkeypatch, n, route):
+def test_msm_pippenger_sizes(gpu, opts, n, route):
     """98 347 = the C4 verification MSM size.  Checked against the oracle-free identity
     MSM(s_i, k_i G) = (sum s_i k_i) G and, for the smaller sizes, the oracle's own Pippenger.  Routes: default = the
     window-parallel launches up to 2^15 terms, k_pip.hip above; pip2 = k_pip2.hip's one-instance pipeline (2^8..2^16 terms);
     bucket = k_pip.hip / the Straus lanes at every size."""
     if route != "default":
-        monkeypatch.setenv("BPGPU_MSM_WP_MAX", "0")
+        opts(msm_wp_max=0)
     if route == "pip2":
-        monkeypatch.setenv("BPGPU_PIP2_SINGLE", "1")
+        opts(msm_pip2_single=1)
     Gp, Gd = o.gens("G", n, dlogs=True)
     sc = o.random_scalars(1234 + n, n)
     got = gpu.msm(sc, Gp)
@@ -1204,7 +1271,7 @@ def test_ipp_rounds_with_device_transcript(gpu, resident):
     ("multi", 4 | (3 << 16), lambda i: [i % 16, (5 * i + 3) % 16, (11 * i + 7) % 16], 0),   # m = 3, n = 12 -> padded 16, 22 points
     ("example", 0, lambda i: [3 + i, 4, 6, 1, 0, 9], 1),        # m = 5, n = 1, k = 0 -> 16 points (c2 = 9 is public: one circuit)
 ])
-def test_verify_batch_other_circuits_all_launch_variants(gpu, monkeypatch, kind, param, values_fn, nverify):
+def test_verify_batch_other_circuits_all_launch_variants(gpu, opts, kind, param, values_fn, nverify):
     """Batches of 70 proofs of circuits with several commitments / padding / k = 0 through the window-parallel, fused
     and separate launch paths: accept bits, mega_check points and MSM scalars as the oracle's (tampered included)."""
     nb = 70
@@ -1236,19 +1303,17 @@ def test_verify_batch_other_circuits_all_launch_variants(gpu, monkeypatch, kind,
         ch += s.challenges()
     want_ok = [1 if s.rc == 0 else 0 for s in sessions]
     assert want_ok.count(0) == 2
-    for env in ({}, {"BPGPU_WINDOW_PARALLEL": "0"}, {"BPGPU_NO_FUSE": "1"}):
-        for kk in ("BPGPU_WINDOW_PARALLEL", "BPGPU_NO_FUSE"):
-            monkeypatch.delenv(kk, raising=False)
-        for kk, vv in env.items():
-            monkeypatch.setenv(kk, vv)
+    for route in ({}, {"verify_window_parallel": 0}, {"verify_no_fuse": 1}):
+        opts(verify_window_parallel=1, verify_no_fuse=0)
+        opts(**route)
         circ = gpu.circuit_create(rp, kd, ix, coeff, s0.n1 + s0.n2, s0.m)
         g = _gens(gpu, cap, 8)
         try:
             ok, mega, full = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, True, True)
-            assert ok == want_ok, env
+            assert ok == want_ok, route
             for i, s in enumerate(sessions):
-                assert mega[64 * i:64 * i + 64] == s.mega_check(), (env, i)
-                assert full[32 * s.nterms * i:32 * s.nterms * (i + 1)] == s.msm_terms()[0], (env, i)
+                assert mega[64 * i:64 * i + 64] == s.mega_check(), (route, i)
+                assert full[32 * s.nterms * i:32 * s.nterms * (i + 1)] == s.msm_terms()[0], (route, i)
         finally:
             gpu.gens_destroy(g)
             gpu.circuit_destroy(circ)
