@@ -284,6 +284,27 @@ int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_gen
                                 const uint8_t *x, const uint8_t *u, const uint8_t *y_inv, const uint8_t *w,
                                 bpgpu_ipp **out);
 void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s);
+/* Resident-witness prover sessions: the same Prover::prove arithmetic with the witness crossing the bus ONCE and, optionally, the
+ * blinding vectors never crossing it at all (256 provers x 1024 multipliers: 25 MB up instead of 92 MB, no 525 000 host-side
+ * scalar draws).  All scalars in ark-ff Montgomery form unless stated.
+ *
+ * bpgpu_r1cs_prover_commit -- r1cs/prover.rs:457-494 (first call: *session == NULL, phase-1 multipliers) and :519-565 (second call
+ *   on the same session: the n_new multipliers the randomized constraints added; skip it when there are none -- the reference sets
+ *   A_I2 = A_O2 = S2 = identity, :566-576).  a_L, a_R, a_O: nb x n_new.  Blinding vectors s_L, s_R (:461-462, :526-527): either
+ *   explicit (nb x n_new each; vector_keys NULL) or drawn on the device from vector_keys (nb x 32 raw bytes the caller takes from
+ *   its RNG where the reference draws the vectors; s_L = s_R = NULL): "BlindVec v1",
+ *     block(key, v, j) = first 128 bytes of Keccak-f[1600] over the padded 48-byte message key || u64le(v) || u64le(j)   (v = 0: s_L, 1: s_R)
+ *     s_v[i] = int_LE(block(key, v, i / 2)[64 (i mod 2) .. +64]) mod n
+ *   (the CPU oracle restates the stream, so such proofs replay under a test RNG).  blindings: nb x 3 (i_blinding, o_blinding,
+ *   s_blinding).  commitments out: nb x 3 x 64 B (A_I, A_O, S).  BPGPU_E_GENS when the multipliers exceed the generators.
+ * bpgpu_r1cs_prover_session_polys -- :587-619 on the session's planes: y^-1 (:593, on the device), flattened constraints, l / r
+ *   coefficient vectors, t_1..t_6.  y, z: nb x 32 B canonical LE (fresh transcript challenges); outputs as bpgpu_r1cs_prover_polys.
+ *   Continue with bpgpu_r1cs_prover_ipp_begin, whose y_inv may then be NULL (the session's own). */
+int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover **session, size_t nb, size_t n_new,
+                             const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O, const uint8_t *s_L, const uint8_t *s_R,
+                             const uint8_t *vector_keys, const uint8_t *blindings, uint8_t *commitments);
+int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                    uint8_t *t_coeffs, uint8_t *wV);
 /* out[i] = scalars[i] * (curve generator) -- GeneratorsChain::next (generators.rs:112-124),
  * Q = w * B (prover.rs:687), PedersenGens::commit with B = B_blinding (generators.rs:41-43,61-70) */
 int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out);

@@ -41,6 +41,10 @@ struct bpgpu_ctx {
   std::vector<hipEvent_t> prof_pool;   // recycled events
   bool prof_skip[BPGPU_PROF_KINDS] = {};
   uint32_t prof_mask = 0xffffffffu;    // bpgpu_profile_select
+  // Device buffers of the prover / IPP sessions, recycled between sessions: hipFree waits for the WHOLE device to idle, which
+  // serialises two contexts that pipeline batches (one host thread each), and a session is a dozen allocations.
+  struct PoolBlk { void *p; size_t cap; bool used; };
+  std::vector<PoolBlk> pool;
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
@@ -111,6 +115,43 @@ struct bpgpu_circuit {
     if (rc__ != BPGPU_OK) return rc__; \
   } while (0)
 
+// session buffers (ctx->mu held): best fit among the free blocks of at most twice the size, else a new allocation; released blocks
+// stay with the context (at most 48 free ones: beyond that the largest goes back to the device)
+static bool pool_alloc(bpgpu_ctx *ctx, void **out, size_t bytes) {
+  *out = nullptr;
+  bytes = (bytes + 255) & ~(size_t)255;
+  if (!bytes) bytes = 256;
+  int best = -1;
+  for (size_t i = 0; i < ctx->pool.size(); i++) {
+    auto &b = ctx->pool[i];
+    if (!b.used && b.cap >= bytes && b.cap <= 2 * bytes + 4096 && (best < 0 || b.cap < ctx->pool[best].cap)) best = (int)i;
+  }
+  if (best >= 0) { ctx->pool[best].used = true; *out = ctx->pool[best].p; return true; }
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) {   // give the cached blocks back and try once more
+    for (auto &b : ctx->pool) if (!b.used && b.p) { (void)hipFree(b.p); b.p = nullptr; }
+    std::vector<bpgpu_ctx::PoolBlk> keep;
+    for (auto &b : ctx->pool) if (b.p) keep.push_back(b);
+    ctx->pool.swap(keep);
+    if (hipMalloc(&p, bytes) != hipSuccess) return false;
+  }
+  try { ctx->pool.push_back({p, bytes, true}); } catch (const std::bad_alloc &) { (void)hipFree(p); return false; }
+  *out = p;
+  return true;
+}
+static void pool_release(bpgpu_ctx *ctx, void *p) {
+  if (!p) return;
+  size_t nfree = 0, largest = (size_t)-1;
+  for (size_t i = 0; i < ctx->pool.size(); i++) {
+    auto &b = ctx->pool[i];
+    if (b.p == p) b.used = false;
+    if (!b.used) { nfree++; if (largest == (size_t)-1 || b.cap > ctx->pool[largest].cap) largest = i; }
+  }
+  if (nfree > 48 && largest != (size_t)-1) {
+    (void)hipFree(ctx->pool[largest].p);
+    ctx->pool.erase(ctx->pool.begin() + (long)largest);
+  }
+}
 static int ws_get(bpgpu_ctx *ctx, int slot, size_t bytes, void **out) {
   Slot &s = ctx->ws[slot];
   if (bytes < 256) bytes = 256;
@@ -231,6 +272,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   hipStreamSynchronize(ctx->st);
   hipStreamSynchronize(ctx->st2);
   for (auto &s : ctx->ws) if (s.p) hipFree(s.p);
+  for (auto &b : ctx->pool) if (b.p) hipFree(b.p);
   hipFree(ctx->d_flag);
   hipFree(ctx->sqrt_tab);
   if (ctx->gen_tab) { hipFree(ctx->gen_tab->points); hipFree(ctx->gen_tab->table); delete ctx->gen_tab; }
@@ -1577,11 +1619,11 @@ int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
 }
 
 /* ---------------------------------------------------------------- IPP prover session */
-static void ipp_free_all(bpgpu_ipp *s) {
-  for (int i = 0; i < 2; i++) { hipFree(s->a[i]); hipFree(s->b[i]); hipFree(s->G[i]); hipFree(s->H[i]); }
-  hipFree(s->Q); hipFree(s->Gf); hipFree(s->Hf); hipFree(s->t1); hipFree(s->t2); hipFree(s->t3); hipFree(s->t4);
-  hipFree(s->cLR); hipFree(s->uu); hipFree(s->res); hipFree(s->sums); hipFree(s->out_xy); hipFree(s->mpts); hipFree(s->msc);
-  hipFree(s->cG); hipFree(s->cH); hipFree(s->w);
+// (ctx->mu held) the session's buffers go back to the context's pool
+static void ipp_free_all(bpgpu_ctx *ctx, bpgpu_ipp *s) {
+  void *all[] = {s->a[0], s->a[1], s->b[0], s->b[1], s->G[0], s->G[1], s->H[0], s->H[1], s->Q, s->Gf, s->Hf, s->t1, s->t2, s->t3, s->t4,
+                 s->cLR, s->uu, s->res, s->sums, s->out_xy, s->mpts, s->msc, s->cG, s->cH, s->w};
+  for (void *p : all) pool_release(ctx, p);
   delete s;
 }
 int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const uint8_t *G_factors,
@@ -1631,7 +1673,7 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   size_t tot = nb * n, gtot = shared_gens ? n : tot, half = nb * (n > 1 ? n / 2 : 1);
   void *stage = nullptr;
   bool okk = true;
-  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  auto M = [&](void **p, size_t bytes) { if (okk && !pool_alloc(ctx, p, bytes)) okk = false; };
   M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
   M((void **)&s->G[0], (gtot > half ? gtot : half) * sizeof(AffDev)); M((void **)&s->H[0], (gtot > half ? gtot : half) * sizeof(AffDev));
   M((void **)&s->G[1], half * sizeof(AffDev)); M((void **)&s->H[1], half * sizeof(AffDev));
@@ -1642,7 +1684,7 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
   M((void **)&s->out_xy, nb * 2 * 64);
   M((void **)&s->mpts, nb * 2 * (n + 1) * sizeof(AffDev)); M((void **)&s->msc, nb * 2 * (n + 1) * 32);
   M(&stage, (2 * gtot + nb) * 64);
-  if (!okk) { hipFree(stage); ipp_free_all(s); return BPGPU_E_OOM; }
+  if (!okk) { pool_release(ctx, stage); ipp_free_all(ctx, s); return BPGPU_E_OOM; }
   int rc = BPGPU_OK;
   do {
     if ((rc = flag_reset(ctx))) break;
@@ -1663,8 +1705,9 @@ int bpgpu_ipp_begin(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *Q, const
     if ((rc = flag_read(ctx, &bad))) break;
     if (bad) rc = BPGPU_E_ARG;
   } while (0);
-  hipFree(stage);
-  if (rc) { ipp_free_all(s); return rc; }
+  (void)hipStreamSynchronize(ctx->st);   // the staging buffer goes back to the pool: its conversion launches have completed
+  pool_release(ctx, stage);
+  if (rc) { ipp_free_all(ctx, s); return rc; }
   *out = s;
   return BPGPU_OK;
 }
@@ -1682,13 +1725,13 @@ int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t 
   s->nb = nb; s->n0 = s->n = n; s->gens = g;
   size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
   bool okk = true;
-  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  auto M = [&](void **p, size_t bytes) { if (okk && !pool_alloc(ctx, p, bytes)) okk = false; };
   M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
   M((void **)&s->cG, tot * 32); M((void **)&s->cH, tot * 32); M((void **)&s->w, nb * 32);
   M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
   M((void **)&s->sums, nb * 2 * sizeof(JacRaw)); M((void **)&s->out_xy, nb * 2 * 64);
   M((void **)&s->msc, nb * 2 * (2 + 2 * n) * 32);
-  if (!okk) { ipp_free_all(s); return BPGPU_E_OOM; }
+  if (!okk) { ipp_free_all(ctx, s); return BPGPU_E_OOM; }
   int rc = BPGPU_OK;
   do {
     if ((rc = flag_reset(ctx))) break;
@@ -1705,15 +1748,14 @@ int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t 
     if ((rc = flag_read(ctx, &bad))) break;
     if (bad) rc = BPGPU_E_ARG;
   } while (0);
-  if (rc) { ipp_free_all(s); return rc; }
+  if (rc) { ipp_free_all(ctx, s); return rc; }
   *out = s;
   return BPGPU_OK;
 }
 void bpgpu_ipp_destroy(bpgpu_ctx *ctx, bpgpu_ipp *s) {
-  if (!s) return;
-  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
+  if (!s || !ctx) return;        // (a session belongs to the context it was opened on)
   bpgpu_gens *own = s->own_gens;
-  ipp_free_all(s);
+  { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); ipp_free_all(ctx, s); }
   if (own) bpgpu_gens_destroy(ctx, own);
 }
 size_t bpgpu_ipp_len(const bpgpu_ipp *s) { return s ? s->n : 0; }
@@ -1944,7 +1986,17 @@ struct bpgpu_prover {
   size_t nb = 0, n = 0, m = 0;
   int32_t *polys = nullptr;   // [6][nb][n][9]
   Words8 *y = nullptr;        // nb
+  // resident-witness sessions (bpgpu_r1cs_prover_commit): the witness and blinding planes, nb x wn plain canonical words, stay in
+  // HBM from the phase commitments to the polynomial build
+  size_t wn = 0;
+  Words8 *aL = nullptr, *aR = nullptr, *aO = nullptr, *sL = nullptr, *sR = nullptr;
+  Words8 *yinv = nullptr;     // nb (set by bpgpu_r1cs_prover_session_polys)
 };
+static void prover_free_all(bpgpu_ctx *ctx, bpgpu_prover *s) {   // ctx->mu held
+  void *all[] = {s->polys, s->y, s->aL, s->aR, s->aO, s->sL, s->sR, s->yinv};
+  for (void *p : all) pool_release(ctx, p);
+  delete s;
+}
 static int prover_polys_impl(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, const uint8_t *y, const uint8_t *y_inv,
                              const uint8_t *z, const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O,
                              const uint8_t *s_L, const uint8_t *s_R, uint8_t *t_coeffs, uint8_t *wV,
@@ -1959,8 +2011,8 @@ static int prover_polys_impl(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, 
   bpgpu_prover *s = new (std::nothrow) bpgpu_prover();
   if (!s) return BPGPU_E_OOM;
   s->nb = nb; s->n = n; s->m = m;
-  auto fail = [&](int rc) { hipFree(s->polys); hipFree(s->y); delete s; return rc; };
-  if (hipMalloc((void **)&s->polys, (6 * nb * (n ? n : 1) * 9) * 4) != hipSuccess || hipMalloc((void **)&s->y, nb * 32) != hipSuccess)
+  auto fail = [&](int rc) { prover_free_all(ctx, s); return rc; };
+  if (!pool_alloc(ctx, (void **)&s->polys, (6 * nb * (n ? n : 1) * 9) * 4) || !pool_alloc(ctx, (void **)&s->y, nb * 32))
     return fail(BPGPU_E_OOM);
   void *din, *dzp, *dout;
   size_t tot = nb * n;
@@ -2032,7 +2084,7 @@ int bpgpu_r1cs_prover_eval(bpgpu_ctx *ctx, bpgpu_prover *s, size_t padded_n, con
 int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_gens *g, size_t padded_n, size_t n1,
                                 const uint8_t *x, const uint8_t *u, const uint8_t *y_inv, const uint8_t *w,
                                 bpgpu_ipp **out) {
-  if (!ctx || !ps || !g || !x || !u || !y_inv || !w || !out) return BPGPU_E_ARG;
+  if (!ctx || !ps || !g || !x || !u || (!y_inv && !ps->yinv) || !w || !out || !ps->polys) return BPGPU_E_ARG;
   if (!padded_n || padded_n < ps->n || (padded_n & (padded_n - 1)) || n1 > ps->n) return BPGPU_E_LEN;
   if (padded_n > g->cap) return BPGPU_E_GENS;
   *out = nullptr;
@@ -2044,21 +2096,22 @@ int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_ge
   s->nb = nb; s->n0 = s->n = n; s->gens = g;
   size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
   bool okk = true;
-  auto M = [&](void **p, size_t bytes) { if (okk && hipMalloc(p, bytes ? bytes : 4) != hipSuccess) okk = false; };
+  auto M = [&](void **p, size_t bytes) { if (okk && !pool_alloc(ctx, p, bytes)) okk = false; };
   M((void **)&s->a[0], tot * 32); M((void **)&s->b[0], tot * 32); M((void **)&s->a[1], half * 32); M((void **)&s->b[1], half * 32);
   M((void **)&s->cG, tot * 32); M((void **)&s->cH, tot * 32); M((void **)&s->w, nb * 32);
   M((void **)&s->cLR, nb * 2 * 32); M((void **)&s->uu, nb * 2 * 32);
   M((void **)&s->sums, nb * 2 * sizeof(JacRaw)); M((void **)&s->out_xy, nb * 2 * 64);
   M((void **)&s->msc, nb * 2 * (2 + 2 * n) * 32);
-  if (!okk) { ipp_free_all(s); return BPGPU_E_OOM; }
+  if (!okk) { ipp_free_all(ctx, s); return BPGPU_E_OOM; }
   int rc = BPGPU_OK;
   do {
     void *din;
     if ((rc = ws_get(ctx, 0, 3 * nb * 32, &din))) break;
     Words8 *dx = (Words8 *)din, *du = dx + nb, *dyi = du + nb;
     if ((rc = flag_reset(ctx))) break;
-    if ((rc = h2d(ctx, dx, x, nb * 32)) || (rc = h2d(ctx, du, u, nb * 32)) || (rc = h2d(ctx, dyi, y_inv, nb * 32)) ||
-        (rc = h2d(ctx, s->w, w, nb * 32))) break;
+    if ((rc = h2d(ctx, dx, x, nb * 32)) || (rc = h2d(ctx, du, u, nb * 32)) || (rc = h2d(ctx, s->w, w, nb * 32))) break;
+    if (y_inv) { if ((rc = h2d(ctx, dyi, y_inv, nb * 32))) break; }
+    else if (hipMemcpyAsync(dyi, ps->yinv, nb * 32, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) { rc = BPGPU_E_DEVICE; break; }
     scalars_check(ctx->st, dx, 3 * nb, ctx->d_flag);
     scalars_check(ctx->st, s->w, nb, ctx->d_flag);
     prover_eval(ctx->st, nb, ps->n, n, dx, ps->y, ps->polys, s->a[0], s->b[0]);
@@ -2068,16 +2121,131 @@ int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_ge
     if ((rc = flag_read(ctx, &bad))) break;
     if (bad) rc = BPGPU_E_ARG;
   } while (0);
-  if (rc) { ipp_free_all(s); return rc; }
+  if (rc) { ipp_free_all(ctx, s); return rc; }
   *out = s;
   return BPGPU_OK;
 }
 void bpgpu_prover_destroy(bpgpu_ctx *ctx, bpgpu_prover *s) {
-  if (!s) return;
-  if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); }
-  hipFree(s->polys);
-  hipFree(s->y);
-  delete s;
+  if (!s || !ctx) return;        // (a session belongs to the context it was opened on)
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipStreamSynchronize(ctx->st);
+  prover_free_all(ctx, s);
+}
+
+/* ---- resident-witness prover sessions: prover.rs:457-494 / :519-565 (phase commitments) and :587-619 (polynomials) with the
+ * witness uploaded ONCE and the blinding vectors optionally drawn on the device ------------------------------------------ */
+int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover **session, size_t nb, size_t n_new,
+                             const uint8_t *a_L, const uint8_t *a_R, const uint8_t *a_O, const uint8_t *s_L, const uint8_t *s_R,
+                             const uint8_t *vector_keys, const uint8_t *blindings, uint8_t *commitments) {
+  if (!ctx || !g || !session || !nb || !blindings || !commitments) return BPGPU_E_ARG;
+  if (n_new && (!a_L || !a_R || !a_O)) return BPGPU_E_ARG;
+  const bool explicit_vec = s_L && s_R;
+  if (n_new && (explicit_vec == (vector_keys != nullptr) || (!s_L) != (!s_R))) return BPGPU_E_ARG;   // exactly one source of s_L, s_R
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  bpgpu_prover *s = *session;
+  const bool fresh = s == nullptr;
+  if (!fresh && s->nb != nb) return BPGPU_E_LEN;
+  const size_t wn0 = fresh ? 0 : s->wn, wn = wn0 + n_new;
+  if (wn > g->cap) return BPGPU_E_GENS;
+  if (fresh) {
+    s = new (std::nothrow) bpgpu_prover();
+    if (!s) return BPGPU_E_OOM;
+    s->nb = nb;
+  }
+  auto fail = [&](int rc) { if (fresh) prover_free_all(ctx, s); return rc; };
+  // new planes of nb x wn; the multipliers of the earlier phase are carried over
+  Words8 *pl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  Words8 **old[5] = {&s->aL, &s->aR, &s->aO, &s->sL, &s->sR};
+  const size_t tot_new = nb * n_new;
+  void *din = nullptr, *drows = nullptr, *dres = nullptr, *dout = nullptr;
+  int rc;
+  if ((rc = ws_get(ctx, 0, (5 * tot_new + 4 * nb) * 32, &din)) || (rc = ws_get(ctx, 1, nb * 3 * (2 + 2 * wn) * 32, &drows)) ||
+      (rc = ws_get(ctx, 4, nb * 3 * sizeof(JacRaw), &dres)) || (rc = ws_get(ctx, 5, nb * 3 * 64, &dout)))
+    return fail(rc);
+  if (n_new) {
+    bool okk = true;
+    for (int i = 0; i < 5; i++) okk = okk && pool_alloc(ctx, (void **)&pl[i], nb * wn * 32);
+    if (!okk) { for (auto p : pl) pool_release(ctx, p); return fail(BPGPU_E_OOM); }
+    if (wn0) for (int i = 0; i < 5; i++)
+      if (hipMemcpy2DAsync(pl[i], wn * 32, *old[i], wn0 * 32, wn0 * 32, nb, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) {
+        for (auto p : pl) pool_release(ctx, p);
+        return fail(BPGPU_E_DEVICE);
+      }
+    for (int i = 0; i < 5; i++) { pool_release(ctx, *old[i]); *old[i] = pl[i]; }   // (stream-ordered: any reuse runs after the copies)
+    s->wn = wn;
+  }
+  // staging: [a_L | a_R | a_O | (s_L | s_R)] nb x n_new each, then blindings nb x 3 (all ark), then the keys nb x 32 bytes (raw)
+  Words8 *w = (Words8 *)din;
+  const size_t nvec = explicit_vec ? 5 : 3;
+  Words8 *dbl = w + nvec * tot_new, *dkeys = dbl + 3 * nb;
+  const uint8_t *src[5] = {a_L, a_R, a_O, s_L, s_R};
+  if ((rc = flag_reset(ctx))) return fail(rc);
+  for (size_t i = 0; i < nvec && n_new; i++) if ((rc = h2d(ctx, w + i * tot_new, src[i], tot_new * 32))) return fail(rc);
+  if ((rc = h2d(ctx, dbl, blindings, nb * 3 * 32))) return fail(rc);
+  if (n_new && !explicit_vec && (rc = h2d(ctx, dkeys, vector_keys, nb * 32))) return fail(rc);
+  if (n_new) {
+    if (wn0 == 0) {          // contiguous planes: convert straight into them
+      for (size_t i = 0; i < nvec; i++) scalars_from_ark(ctx->st, w + i * tot_new, *old[i], tot_new, ctx->d_flag);
+    } else {
+      scalars_from_ark(ctx->st, w, w, nvec * tot_new, ctx->d_flag);
+      for (size_t i = 0; i < nvec; i++)
+        if (hipMemcpy2DAsync(*old[i] + wn0, wn * 32, w + i * tot_new, n_new * 32, n_new * 32, nb, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess)
+          return fail(BPGPU_E_DEVICE);
+    }
+    if (!explicit_vec) blind_vectors(ctx->st, dkeys, nb, n_new, s->sL, s->sR, wn, wn0);
+  }
+  scalars_from_ark(ctx->st, dbl, dbl, 3 * nb, ctx->d_flag);
+  commit_rows(ctx->st, nb, wn, wn0, wn, s->aL, s->aR, s->aO, s->sL, s->sR, dbl, (Words8 *)drows);
+  if ((rc = msm_gens_dev(ctx, g, nb * 3, wn, (const uint32_t *)drows, (JacRaw *)dres, ctx->st))) return fail(rc);
+  jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb * 3);
+  if ((rc = launch_ok(ctx))) return fail(rc);
+  int bad = 0;
+  if ((rc = flag_read(ctx, &bad))) return fail(rc);
+  if (bad) return fail(BPGPU_E_ARG);
+  if ((rc = d2h(ctx, commitments, dout, nb * 3 * 64))) return fail(rc);
+  if (hipStreamSynchronize(ctx->st) != hipSuccess) return fail(BPGPU_E_DEVICE);
+  *session = s;
+  return BPGPU_OK;
+}
+int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                    uint8_t *t_coeffs, uint8_t *wV) {
+  if (!ctx || !s || !c || !y || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  if (c->n != s->wn || s->polys) return BPGPU_E_LEN;     // the circuit's multipliers are the session's; one polynomial build per session
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t nb = s->nb, n = c->n, m = c->m;
+  if (!pool_alloc(ctx, (void **)&s->polys, (6 * nb * (n ? n : 1) * 9) * 4) || !pool_alloc(ctx, (void **)&s->y, nb * 32) ||
+      !pool_alloc(ctx, (void **)&s->yinv, nb * 32)) {
+    pool_release(ctx, s->polys); pool_release(ctx, s->y); pool_release(ctx, s->yinv);
+    s->polys = nullptr; s->y = s->yinv = nullptr;
+    return BPGPU_E_OOM;
+  }
+  s->n = n; s->m = m;
+  void *din, *dzp, *dout;
+  CK(ws_get(ctx, 0, 2 * nb * 32, &din));
+  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 1, (nb * 6 + nb * m) * 32, &dout));
+  Words8 *dz = (Words8 *)din, *dt = (Words8 *)dout, *dwV = dt + nb * 6;
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, s->y, y, nb * 32));
+  CK(h2d(ctx, dz, z, nb * 32));
+  scalars_check(ctx->st, s->y, nb, ctx->d_flag);
+  scalars_check(ctx->st, dz, nb, ctx->d_flag);
+  HIPCK(ctx, hipMemcpyAsync(s->yinv, s->y, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
+  batch_inverse(ctx->st, s->yinv, nb, ctx->d_flag);       // y^-1, prover.rs:593 (a zero challenge raises the flag: E_ARG)
+  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);
+  prover_polys(ctx->st, circuit_dev(c), nb, s->y, s->yinv, s->aL, s->aR, s->aO, s->sL, s->sR, (const int32_t *)dzp, s->polys, dwV);
+  prover_tcoeffs(ctx->st, nb, n, s->polys, dt);
+  CK(launch_ok(ctx));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;
+  CK(d2h(ctx, t_coeffs, dt, nb * 6 * 32));
+  if (m) CK(d2h(ctx, wV, dwV, nb * m * 32));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
 }
 /* scalars[i] * (curve generator): GeneratorsChain::next (generators.rs:112-124), Q = w * B (prover.rs:687) */
 int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out) {

@@ -33,6 +33,32 @@ void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad) {
   if (!n) return;
   hipLaunchKernelGGL(k_scalars_check, dim3((n + 255) / 256), dim3(256), 0, st, in, n, bad);
 }
+// rows of the commitment MSMs from the witness planes (see kernels.h): one lane per row element
+__global__ void __launch_bounds__(256) k_commit_rows(size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR,
+                                                     const Words8 *aO, const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows) {
+  const size_t per = 2 + 2 * n;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * 3 * per) return;
+  const size_t e = t % per, w = (t / per) % 3, p = t / (3 * per);
+  const Words8 *src = nullptr;
+  if (e == 1) src = blinds + p * 3 + w;
+  else if (e >= 2) {
+    const size_t i = (e - 2) % n;
+    const bool h = e - 2 >= n;
+    if (i >= lo) {
+      const Words8 *pl = w == 0 ? (h ? aR : aL) : (w == 1 ? (h ? nullptr : aO) : (h ? sR : sL));
+      if (pl) src = pl + p * stride + i;
+    }
+  }
+  Words8 v{};
+  if (src) v = *src;
+  rows[t] = v;
+}
+void commit_rows(hipStream_t st, size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR, const Words8 *aO,
+                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows) {
+  const size_t tot = nb * 3 * (2 + 2 * n);
+  if (tot) hipLaunchKernelGGL(k_commit_rows, dim3((tot + 255) / 256), dim3(256), 0, st, nb, n, lo, stride, aL, aR, aO, sL, sR, blinds, rows);
+}
 void scalars_check_proof(hipStream_t st, const Words8 *in, size_t n, size_t per_unit, int *bad, int32_t *bad_unit) {
   if (!n) return;
   hipLaunchKernelGGL(k_scalars_check_proof, dim3((n + 255) / 256), dim3(256), 0, st, in, n, per_unit, bad, bad_unit);

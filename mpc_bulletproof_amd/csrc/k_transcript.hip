@@ -120,11 +120,8 @@ __device__ __forceinline__ void keccak256_32(const uint64_t in[4], uint64_t out[
   for (int i = 0; i < 4; i++) out[i] = st[i];
 }
 
-// challenge_scalar: challenge_bytes then hash_to_scalar = int_LE(low || keccak256(low)) mod n  (util.rs:252-267)
-__device__ __forceinline__ void tr_challenge_scalar(uint64_t st[4], const Label &l, Words8 *out) {
-  chain_hash<0>(st, 0x01, l, nullptr);
-  uint64_t hi[4];
-  keccak256_32(st, hi);
+// int_LE(lo || hi) mod n as plain canonical words (Scalar::from_le_bytes_mod_order of 64 bytes)
+__device__ __forceinline__ void wide_to_scalar(const uint64_t st[4], const uint64_t hi[4], Words8 *out) {
   uint32_t lw[8], hw[8];
 #pragma unroll
   for (int i = 0; i < 4; i++) { lw[2 * i] = (uint32_t)st[i]; lw[2 * i + 1] = (uint32_t)(st[i] >> 32); hw[2 * i] = (uint32_t)hi[i]; hw[2 * i + 1] = (uint32_t)(hi[i] >> 32); }
@@ -139,6 +136,13 @@ __device__ __forceinline__ void tr_challenge_scalar(uint64_t st[4], const Label 
   pack(ow, canon(mul(add(lo, hv), one)));
 #pragma unroll
   for (int i = 0; i < 8; i++) out->w[i] = ow[i];
+}
+// challenge_scalar: challenge_bytes then hash_to_scalar = int_LE(low || keccak256(low)) mod n  (util.rs:252-267)
+__device__ __forceinline__ void tr_challenge_scalar(uint64_t st[4], const Label &l, Words8 *out) {
+  chain_hash<0>(st, 0x01, l, nullptr);
+  uint64_t hi[4];
+  keccak256_32(st, hi);
+  wide_to_scalar(st, hi, out);
 }
 
 __device__ __forceinline__ bool load64(const Words8 *p, uint64_t m[8]) {   // a point (two Words8); returns "is identity"
@@ -292,6 +296,40 @@ __global__ void __launch_bounds__(64) k_ipp_round_challenge(size_t nb, uint64_t 
   tr_challenge_scalar(st, TR_LABELS[LB_u], &u_out[p]);
 #pragma unroll
   for (int i = 0; i < 4; i++) states[p * 4 + i] = st[i];
+}
+// The prover's blinding vectors s_L, s_R (r1cs/prover.rs:457-462, 519-527: n random scalars each) drawn ON THE DEVICE from a
+// 32-byte key per prover and phase that the host takes from its RNG at the point where the reference draws the vectors: "BlindVec v1",
+//   block(key, v, j) = the first 128 bytes of Keccak-f[1600] over the 48-byte message key || u64le(v) || u64le(j), padded as keccak256
+//                      pads (0x01 after the message, 0x80 at byte 135): a keyed Keccak in counter mode, 512-bit capacity
+//   s_v[i]           = int_LE(block(key, v, i / 2)[64 (i mod 2) .. +64]) mod n        (v = 0: s_L, v = 1: s_R)
+// 512 bits per scalar: the reduction mod n is unbiased to 2^-260 (four words per scalar, as the host RNG draws them, leave a
+// 3 % bump on the low part of the range).  One lane per (prover, vector, block): 2 x 256 x 512 independent permutations for 256
+// provers of 1024 multipliers instead of 525 000 wide reductions and 34 MB of staging on the host.  The CPU oracle restates the
+// same stream (oracle/bpo_r1cs.c: blind_vector), so proofs made this way are replayable under the test RNG.
+__global__ void __launch_bounds__(64) k_blind_vectors(const Words8 *keys, size_t nb, size_t cnt, Words8 *sL, Words8 *sR, size_t stride,
+                                                      size_t off) {
+  const size_t blocks = (cnt + 1) / 2;
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nb * 2 * blocks) return;
+  const size_t j = t % blocks, v = (t / blocks) & 1, p = t / (2 * blocks);
+  uint64_t s[25];
+#pragma unroll
+  for (int i = 0; i < 25; i++) s[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) s[i] = (uint64_t)keys[p].w[2 * i] | ((uint64_t)keys[p].w[2 * i + 1] << 32);
+  s[4] = v;
+  s[5] = j;
+  s[6] = 0x01;
+  s[16] = 0x8000000000000000ULL;
+  keccak_f(s);
+  Words8 *dst = (v ? sR : sL) + p * stride + off + 2 * j;
+  wide_to_scalar(s, s + 4, dst);
+  if (2 * j + 1 < cnt) wide_to_scalar(s + 8, s + 12, dst + 1);
+}
+void blind_vectors(hipStream_t st, const Words8 *keys, size_t nb, size_t cnt, Words8 *sL, Words8 *sR, size_t stride, size_t off) {
+  if (!nb || !cnt) return;
+  const size_t lanes = nb * 2 * ((cnt + 1) / 2);
+  hipLaunchKernelGGL(k_blind_vectors, dim3((lanes + 63) / 64), dim3(64), 0, st, keys, nb, cnt, sL, sR, stride, off);
 }
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr, Words8 *u_out) {
   if (!nb) return;

@@ -249,6 +249,14 @@ size_t verify_combined2_scratch_bytes(size_t nb, size_t nvar, size_t nfix);
 bool verify_combined2_supported(size_t nb, size_t nvar, int c, size_t padded_n);
 void verify_combined2(hipStream_t st, const CombinedArgs &a);
 
+// the prover's blinding vectors drawn on the device from per-prover keys (k_transcript.hip, "BlindVec v1"):
+// sL / sR [p * stride + off + i] for i < cnt, plain canonical words
+void blind_vectors(hipStream_t st, const Words8 *keys, size_t nb, size_t cnt, Words8 *sL, Words8 *sR, size_t stride, size_t off);
+// MSM scalar rows of the three commitments A_I, A_O, S of nb provers over [B, B_blinding, G_0.., H_0..] (prover.rs:465-494 /
+// :532-565): rows[(3 p + w) * (2 + 2 n)] for w = 0, 1, 2 from the witness planes (nb x stride, plain canonical; multipliers
+// [lo, n) are live, the rest of a row is zero) and blinds (nb x 3: i, o, s blinding)
+void commit_rows(hipStream_t st, size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR, const Words8 *aO,
+                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows);
 // one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);
 

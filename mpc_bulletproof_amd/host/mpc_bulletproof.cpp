@@ -139,7 +139,7 @@ uint64_t SeededRng::next_u64() {
 // sponge "forget" step: the next state depends on the 512-bit capacity only), so a captured state reveals nothing of the
 // blocks already handed out -- Keccak-f is invertible, but the inverse needs the rate words that were overwritten.
 namespace { void permute_words(uint64_t s[25]); }
-OsRng::OsRng() {
+OsRng::OsRng(bool vector_keys) : vk_(vector_keys) {
   uint8_t key[32];
   size_t got = 0;
   while (got < sizeof key) {
@@ -914,6 +914,27 @@ class CsCore {
   Transcript &tr;
   RandomizedConstraintSystem *self_;
   std::vector<LinearCombination> constraints;
+  // 128-bit running hash of the rows (variables + coefficients, in row order), updated as they are pushed: lock-step provers
+  // must share their constraint rows, and comparing 255 x 2064 rows with the first prover's cost every batch as much as
+  // building them (BPH_CHECK_ROWS=1 still does it); the hash also keys the cache of uploaded circuits
+  uint64_t rows_hash[2] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL};
+  size_t rows_nnz = 0;
+  void hash_word(uint64_t x) {
+    rows_hash[0] = (rows_hash[0] ^ x) * 0x9E3779B97F4A7C15ULL; rows_hash[0] ^= rows_hash[0] >> 29;
+    rows_hash[1] = (rows_hash[1] + x) * 0xC2B2AE3D27D4EB4FULL; rows_hash[1] = (rows_hash[1] << 31) | (rows_hash[1] >> 33);
+  }
+  void push_row(LinearCombination &&lc) {
+    hash_word(0xA5A5A5A500000000ULL | lc.terms.size());
+    for (auto &kv : lc.terms) {
+      if (kv.first.kind == Variable::Zero) continue;
+      uint64_t w[4];
+      kv.second.to_ark_le((uint8_t *)w);
+      hash_word(((uint64_t)kv.first.kind << 56) ^ (uint64_t)kv.first.index);
+      hash_word(w[0]); hash_word(w[1]); hash_word(w[2]); hash_word(w[3]);
+      rows_nnz++;
+    }
+    constraints.push_back(std::move(lc));
+  }
   std::vector<Scalar> a_L, a_R, a_O, v, v_blinding;    // prover
   std::vector<StarkPoint> V;                            // both (prover keeps them for convenience)
   size_t num_vars = 0;                                  // verifier
@@ -949,8 +970,8 @@ class CsCore {
     auto vars = new_multiplier(eval(left), eval(right));
     left.add_term(vars[0], -Scalar::one());
     right.add_term(vars[1], -Scalar::one());
-    constraints.push_back(std::move(left));
-    constraints.push_back(std::move(right));
+    push_row(std::move(left));
+    push_row(std::move(right));
     return vars;
   }
   Variable allocate(const Scalar *assignment) {                                         // prover.rs:127-146 / verifier.rs:122-135
@@ -1024,6 +1045,39 @@ class CsCore {
 
 static size_t next_pow2(size_t n) { size_t p = 1; while (p < n) p <<= 1; return p; }
 
+// Uploaded circuits by row hash: a batch of provers -- and the next batch, and the one a second worker thread is preparing --
+// share ONE device copy of their constraint rows (building the CSR arrays, transposing and uploading them, and the hipFree of
+// the old copy, which waits for the whole device to idle, cost ~1.5 ms per batch of 256 x 2064 rows).  A circuit is plain
+// device memory: usable from every context of the device.  Never more than 8 idle entries.
+namespace {
+struct CircuitCache {
+  struct Entry { uint64_t h[2]; size_t n, m, q, nnz; bpgpu_circuit *c; int users; uint64_t stamp; };
+  std::mutex mu;
+  std::vector<Entry> e;
+  uint64_t clock = 0;
+  bpgpu_circuit *acquire(const CsCore &cs, size_t n, size_t m) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &x : e)
+      if (x.h[0] == cs.rows_hash[0] && x.h[1] == cs.rows_hash[1] && x.n == n && x.m == m && x.q == cs.constraints.size() && x.nnz == cs.rows_nnz) {
+        x.users++; x.stamp = ++clock;
+        return x.c;
+      }
+    bpgpu_circuit *c = cs.upload_circuit(n, m);      // (under the lock: a second thread asking for the same circuit waits for it)
+    size_t idle = 0, oldest = (size_t)-1;
+    for (size_t i = 0; i < e.size(); i++)
+      if (e[i].users == 0) { idle++; if (oldest == (size_t)-1 || e[i].stamp < e[oldest].stamp) oldest = i; }
+    if (idle >= 8) { bpgpu_circuit_destroy(Device::default_device().ctx(), e[oldest].c); e.erase(e.begin() + (long)oldest); }
+    e.push_back(Entry{{cs.rows_hash[0], cs.rows_hash[1]}, n, m, cs.constraints.size(), cs.rows_nnz, c, 1, ++clock});
+    return c;
+  }
+  void release(bpgpu_circuit *c) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto &x : e) if (x.c == c) { x.users--; return; }
+  }
+};
+CircuitCache &circuit_cache() { static CircuitCache *c = new CircuitCache(); return *c; }   // (lives until exit, like the pool)
+}  // namespace
+
 // BPH_TIMING=1: phase timings of prove_batch / verify on stderr
 struct Lap {
   bool on = getenv("BPH_TIMING") != nullptr;
@@ -1049,7 +1103,7 @@ std::array<Variable, 3> Prover::allocate_multiplier(const std::pair<Scalar, Scal
   return c_->new_multiplier(in->first, in->second);
 }
 Variable Prover::commit_public(const Scalar &v) { return commit(v, Scalar::one()).second; }   // prover.rs:171-173
-void Prover::constrain(LinearCombination lc) { c_->constraints.push_back(std::move(lc)); }
+void Prover::constrain(LinearCombination lc) { c_->push_row(std::move(lc)); }
 Scalar Prover::eval(const LinearCombination &lc) const { return c_->eval(lc); }
 void Prover::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
 Scalar Prover::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }
@@ -1090,66 +1144,74 @@ R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {
 // (1-phase gadgets, or 2-phase ones whose randomized rows happen to coincide): every device call is
 // batched over the provers; only the transcripts run per prover on the host.
 std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
-                                           std::vector<Rng *> &rngs) {
+                                           std::vector<Rng *> &rngs, Device *device) {
   const size_t nb = provers.size();
   if (!nb || rngs.size() != nb) throw std::invalid_argument("prove_batch: one Rng per prover");
-  Device &d = Device::default_device();
+  Device &d = device ? *device : Device::default_device();
   std::vector<CsCore *> cs(nb);
   for (size_t p = 0; p < nb; p++) cs[p] = provers[p]->c_.get();
   const PedersenGens &pc = cs[0]->pc_gens;
   bpgpu_gens *gens = bp_gens.device_tables(pc);
   const size_t n1 = cs[0]->a_L.size(), m = cs[0]->v.size();
-  for (auto *c : cs) {
+  const bool vkeys = rngs[0]->vector_keys();
+  for (size_t p = 0; p < nb; p++) {
+    CsCore *c = cs[p];
     if (c->a_L.size() != n1 || c->v.size() != m) throw std::invalid_argument("prove_batch: circuits differ in shape");
+    if (rngs[p]->vector_keys() != vkeys) throw std::invalid_argument("prove_batch: the provers' Rngs differ in vector_keys()");
     c->tr.append_u64("m", c->v.size());                                                  // prover.rs:420
   }
   if (bp_gens.gens_capacity < n1) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :450-452
   std::vector<R1CSProof> proofs(nb);
   Lap lap;
   std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
-  std::vector<std::vector<Scalar>> s_L(nb), s_R(nb);
   // prover.rs:435-445: the blinding RNG is bound to the transcript state and to the witness blindings
   // (build_rng().rekey_with_witness_bytes("v_blinding", ..)); the OS entropy is already in an OsRng's key
-  for (size_t p = 0; p < nb; p++) {
+  parallel_for(nb, [&](size_t p) {
     rngs[p]->rekey(cs[p]->tr.state(), 32);
     for (const Scalar &vb : cs[p]->v_blinding) { auto b = vb.to_bytes(); rngs[p]->rekey(b.data(), b.size()); }
-  }
-  parallel_for(nb, [&](size_t p) {                                                       // :457-462
-    i_b1[p] = rngs[p]->scalar(); o_b1[p] = rngs[p]->scalar(); s_b1[p] = rngs[p]->scalar();
-    s_L[p].resize(n1); s_R[p].resize(n1);
-    rngs[p]->scalars(s_L[p].data(), n1);     // (inside a running loop, i.e. for nb >= 2, the inner loop runs serially)
-    rngs[p]->scalars(s_R[p].data(), n1);
-  });
-  // three commitments per prover over [B, B_blinding, G_0.., H_0..] -- :465-494 / :532-565
-  auto commit3 = [&](size_t lo, size_t hi, const std::vector<Scalar> &ib, const std::vector<Scalar> &ob,
-                     const std::vector<Scalar> &sb, int which_phase) {
-    const size_t n = hi, per = 2 + 2 * n;
+  }, 16);
+  // One phase of commitments, prover.rs:457-494 (lo = 0) / :519-565 (lo = n1): blinding factors, then A_I, A_O, S over
+  // [B_blinding, G_lo.., H_lo..] -- the witness planes go to the device once (bpgpu_r1cs_prover_commit keeps them in the
+  // session for the polynomial build), the blinding vectors s_L, s_R either with them or, Rng::vector_keys(), as one 32-byte
+  // key per prover that the device expands
+  bpgpu_prover *ps = nullptr;
+  struct SessionGuard { Device &d; bpgpu_prover *&ps; ~SessionGuard() { if (ps) bpgpu_prover_destroy(d.ctx(), ps); } } session_guard{d, ps};
+  auto commit_phase = [&](size_t lo, size_t hi, std::vector<Scalar> &ib, std::vector<Scalar> &ob, std::vector<Scalar> &sb, int which_phase) {
+    const size_t cnt = hi - lo, plane = nb * cnt * 32;
     static thread_local RawBuf buf;
-    uint8_t *bytes = buf.ensure(nb * 3 * per * 32);
-    parallel_for(nb, [&](size_t p) {   // rows [B, B_blinding, G_0.., H_0..] of A_I, A_O, S packed straight to bytes
-      auto row = [&](size_t w) { return bytes + (p * 3 + w) * per * 32; };
-      for (size_t w = 0; w < 3; w++) {
-        memset(row(w), 0, 32);                                       // B scalar
-        memset(row(w) + 64, 0, lo * 32);                             // G_0..G_{lo-1}
-        memset(row(w) + (2 + n) * 32, 0, lo * 32);                   // H_0..H_{lo-1}
+    uint8_t *base = buf.ensure((vkeys ? 3 : 5) * plane + nb * 3 * 32 + nb * 32 + 1);
+    uint8_t *paL = base, *paR = base + plane, *paO = base + 2 * plane, *psL = base + 3 * plane, *psR = base + 4 * plane;
+    uint8_t *pbl = base + (vkeys ? 3 : 5) * plane, *pkey = pbl + nb * 3 * 32;
+    parallel_for(nb, [&](size_t p) {
+      Rng &r = *rngs[p];
+      ib[p] = r.scalar(); ob[p] = r.scalar(); sb[p] = r.scalar();                         // :457-459 / :519-521
+      ib[p].to_ark_le(pbl + (p * 3) * 32); ob[p].to_ark_le(pbl + (p * 3 + 1) * 32); sb[p].to_ark_le(pbl + (p * 3 + 2) * 32);
+      pack_range_ark(paL + p * cnt * 32, cs[p]->a_L.data() + lo, cnt);
+      pack_range_ark(paR + p * cnt * 32, cs[p]->a_R.data() + lo, cnt);
+      pack_range_ark(paO + p * cnt * 32, cs[p]->a_O.data() + lo, cnt);
+      if (!cnt) return;
+      if (vkeys) {                                                                        // :461-462 / :526-527, as a key
+        for (int i = 0; i < 4; i++) { uint64_t w = r.next_u64(); memcpy(pkey + p * 32 + 8 * i, &w, 8); }   // little-endian host
+      } else {                                                 // (inside a running loop, i.e. for nb >= 2, the inner loop runs serially)
+        std::vector<Scalar> v(cnt);
+        r.scalars(v.data(), cnt);
+        pack_range_ark(psL + p * cnt * 32, v.data(), cnt);
+        r.scalars(v.data(), cnt);
+        pack_range_ark(psR + p * cnt * 32, v.data(), cnt);
       }
-      ib[p].to_ark_le(row(0) + 32); ob[p].to_ark_le(row(1) + 32); sb[p].to_ark_le(row(2) + 32);
-      pack_range_ark(row(0) + (2 + lo) * 32, cs[p]->a_L.data() + lo, hi - lo);
-      pack_range_ark(row(0) + (2 + n + lo) * 32, cs[p]->a_R.data() + lo, hi - lo);
-      pack_range_ark(row(1) + (2 + lo) * 32, cs[p]->a_O.data() + lo, hi - lo);
-      memset(row(1) + (2 + n + lo) * 32, 0, (hi - lo) * 32);
-      pack_range_ark(row(2) + (2 + lo) * 32, s_L[p].data() + lo, hi - lo);
-      pack_range_ark(row(2) + (2 + n + lo) * 32, s_R[p].data() + lo, hi - lo);
     });
     std::vector<uint8_t> o(nb * 3 * 64);
-    d.check(bpgpu_msm_gens_ark(d.ctx(), gens, nb * 3, n, bytes, o.data()), "bpgpu_msm_gens_ark");   // zero limbs = 0 in either form
+    int rc = bpgpu_r1cs_prover_commit(d.ctx(), gens, &ps, nb, cnt, paL, paR, paO, vkeys ? nullptr : psL, vkeys ? nullptr : psR,
+                                      vkeys && cnt ? pkey : nullptr, pbl, o.data());
+    if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+    d.check(rc, "bpgpu_r1cs_prover_commit");
     for (size_t p = 0; p < nb; p++) {
       StarkPoint *dst[3] = {which_phase == 1 ? &proofs[p].A_I1 : &proofs[p].A_I2, which_phase == 1 ? &proofs[p].A_O1 : &proofs[p].A_O2,
                             which_phase == 1 ? &proofs[p].S1 : &proofs[p].S2};
       for (int k = 0; k < 3; k++) memcpy(dst[k]->xy.data(), &o[(p * 3 + k) * 64], 64);
     }
   };
-  commit3(0, n1, i_b1, o_b1, s_b1, 1);
+  commit_phase(0, n1, i_b1, o_b1, s_b1, 1);
   lap("prove: phase-1 commit");
   parallel_for(nb, [&](size_t p) {
     cs[p]->tr.append_point("A_I1", proofs[p].A_I1);
@@ -1160,15 +1222,9 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   const size_t n = cs[0]->a_L.size(), n2 = n - n1, padded_n = next_pow2(n);
   for (auto *c : cs) if (c->a_L.size() != n) throw std::invalid_argument("prove_batch: circuits differ after randomization");
   if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :511-513
-  parallel_for(nb, [&](size_t p) {
-    if (n2 > 0) { i_b2[p] = rngs[p]->scalar(); o_b2[p] = rngs[p]->scalar(); s_b2[p] = rngs[p]->scalar(); }   // :519-527
-    s_L[p].resize(n); s_R[p].resize(n);
-    rngs[p]->scalars(s_L[p].data() + n1, n - n1);
-    rngs[p]->scalars(s_R[p].data() + n1, n - n1);
-  });
-  if (n2 > 0) commit3(n1, n, i_b2, o_b2, s_b2, 2);                                        // else identity, :566-576
+  if (n2 > 0) commit_phase(n1, n, i_b2, o_b2, s_b2, 2);                                    // else identity, :566-576
   lap("prove: randomize + phase-2 commit");
-  std::vector<Scalar> y(nb), z(nb), y_inv(nb);
+  std::vector<Scalar> y(nb), z(nb);
   parallel_for(nb, [&](size_t p) {
     cs[p]->tr.append_point("A_I2", proofs[p].A_I2);
     cs[p]->tr.append_point("A_O2", proofs[p].A_O2);
@@ -1176,38 +1232,28 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     y[p] = cs[p]->tr.challenge_scalar("y");                                               // :584-585
     z[p] = cs[p]->tr.challenge_scalar("z");
   });
-  {   // y^-1 for all provers: Scalar::inverse (prover.rs:593) as one batched device inversion
-    auto by = pack_scalars(y);
-    d.check(bpgpu_batch_inverse(d.ctx(), by.data(), nb), "bpgpu_batch_inverse");
-    y_inv = unpack_scalars(by.data(), nb);
+  // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619 (y^-1, :593, on the device too).  One
+  // circuit for all provers: the constraint rows must coincide (their running hashes; BPH_CHECK_ROWS=1: row by row).
+  for (size_t p = 1; p < nb; p++)
+    if (cs[p]->rows_hash[0] != cs[0]->rows_hash[0] || cs[p]->rows_hash[1] != cs[0]->rows_hash[1] || cs[p]->rows_nnz != cs[0]->rows_nnz ||
+        cs[p]->constraints.size() != cs[0]->constraints.size())
+      throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+  if (getenv("BPH_CHECK_ROWS"))
+    parallel_for(nb, [&](size_t p) {
+      if (p && !cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+    });
+  lap("prove: transcript y z, rows");
+  bpgpu_circuit *circ = circuit_cache().acquire(*cs[0], n, m);
+  struct CircuitGuard { bpgpu_circuit *c; ~CircuitGuard() { circuit_cache().release(c); } } circuit_guard{circ};
+  lap("prove: circuit");
+  if (!ps) {   // a circuit without multipliers in either phase cannot happen after the phase-1 call; kept for clarity
+    throw std::logic_error("prove_batch: no prover session");
   }
-  // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619.  One circuit for all
-  // provers: the constraint rows must coincide (checked through their CSR bytes).
-  parallel_for(nb, [&](size_t p) {
-    if (p && !cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
-  });
-  lap("prove: transcript y z, same_rows");
-  bpgpu_circuit *circ = cs[0]->upload_circuit(n, m);
-  lap("prove: upload_circuit");
-  bpgpu_prover *ps = nullptr;
   std::vector<uint8_t> tco(nb * 6 * 32), wVb(nb * m * 32 + 1);
   {
-    static thread_local RawBuf buf;
-    const size_t plane = nb * n * 32;
-    uint8_t *wit = buf.ensure(5 * plane + 1);
-    uint8_t *paL = wit, *paR = wit + plane, *paO = wit + 2 * plane, *psL = wit + 3 * plane, *psR = wit + 4 * plane;
-    parallel_for(nb, [&](size_t p) {
-      pack_range_ark(paL + p * n * 32, cs[p]->a_L.data(), n);
-      pack_range_ark(paR + p * n * 32, cs[p]->a_R.data(), n);
-      pack_range_ark(paO + p * n * 32, cs[p]->a_O.data(), n);
-      pack_range_ark(psL + p * n * 32, s_L[p].data(), n);
-      pack_range_ark(psR + p * n * 32, s_R[p].data(), n);
-    });
-    std::vector<uint8_t> by(nb * 32), byi(nb * 32), bz(nb * 32);
-    pack_range_ark(by.data(), y.data(), nb); pack_range_ark(byi.data(), y_inv.data(), nb); pack_range_ark(bz.data(), z.data(), nb);
-    int rc = bpgpu_r1cs_prover_polys_ark(d.ctx(), circ, nb, by.data(), byi.data(), bz.data(), paL, paR, paO, psL, psR,
-                                         tco.data(), wVb.data(), &ps);
-    if (rc) { bpgpu_circuit_destroy(d.ctx(), circ); d.check(rc, "bpgpu_r1cs_prover_polys_ark"); }
+    auto by = pack_scalars(y), bz = pack_scalars(z);
+    d.check(bpgpu_r1cs_prover_session_polys(d.ctx(), ps, circ, by.data(), bz.data(), tco.data(), wVb.data()),
+            "bpgpu_r1cs_prover_session_polys");
   }
   lap("prove: prover_polys");
   auto t = unpack_scalars(tco.data(), nb * 6);   // per prover: t1 t2 t3 t4 t5 t6
@@ -1262,23 +1308,19 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   if (!getenv("BPH_IPP_FOLD_GENERATORS")) {
     // l(x), r(x), the G/H factors (:661-672, 689-697) and the IPP operands never leave the device; Q_p = w_p * B
     // (:687) and G, H = bp_gens are resident: the session runs over the generator tables
-    auto bx = pack_scalars(x), bu = pack_scalars(u), byi = pack_scalars(y_inv), bw = pack_scalars(w);
-    int rc = bpgpu_r1cs_prover_ipp_begin(d.ctx(), ps, gens, padded_n, n1, bx.data(), bu.data(), byi.data(), bw.data(), &ipp);
-    bpgpu_prover_destroy(d.ctx(), ps);
-    bpgpu_circuit_destroy(d.ctx(), circ);
+    auto bx = pack_scalars(x), bu = pack_scalars(u), bw = pack_scalars(w);
+    int rc = bpgpu_r1cs_prover_ipp_begin(d.ctx(), ps, gens, padded_n, n1, bx.data(), bu.data(), nullptr /* the session's y^-1 */, bw.data(), &ipp);
     d.check(rc, "bpgpu_r1cs_prover_ipp_begin");
   } else {   // the reference's literal schedule (operands through the host, generators folded every round), for A/B runs
     std::vector<uint8_t> lv(nb * padded_n * 32), rv(nb * padded_n * 32);
     {
       auto bx = pack_scalars(x);
       int rc = bpgpu_r1cs_prover_eval(d.ctx(), ps, padded_n, bx.data(), lv.data(), rv.data());   // :661-672
-      bpgpu_prover_destroy(d.ctx(), ps);
-      bpgpu_circuit_destroy(d.ctx(), circ);
       d.check(rc, "bpgpu_r1cs_prover_eval");
     }
     std::vector<Scalar> Gf(nb * padded_n), Hf(nb * padded_n);
     parallel_for(nb, [&](size_t p) {
-      auto exp_y_inv = util::exp_iter(y_inv[p], padded_n);
+      auto exp_y_inv = util::exp_iter(y[p].inverse(), padded_n);
       for (size_t i = 0; i < padded_n; i++) {
         Gf[p * padded_n + i] = i < n1 ? Scalar::one() : u[p];
         Hf[p * padded_n + i] = exp_y_inv[i] * Gf[p * padded_n + i];
@@ -1360,7 +1402,7 @@ std::array<Variable, 3> Verifier::multiply(LinearCombination l, LinearCombinatio
 Variable Verifier::allocate(const Scalar *a) { return c_->allocate(a); }
 std::array<Variable, 3> Verifier::allocate_multiplier(const std::pair<Scalar, Scalar> *) { return c_->new_multiplier(Scalar(), Scalar()); }
 Variable Verifier::commit_public(const Scalar &v) { return commit(c_->pc_gens.commit(v, Scalar::one())); }   // verifier.rs:153-160
-void Verifier::constrain(LinearCombination lc) { c_->constraints.push_back(std::move(lc)); }
+void Verifier::constrain(LinearCombination lc) { c_->push_row(std::move(lc)); }
 Scalar Verifier::eval(const LinearCombination &) const { return Scalar::zero(); }
 void Verifier::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
 Scalar Verifier::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }

@@ -77,6 +77,10 @@ class Rng {
   virtual ~Rng() = default;
   virtual uint64_t next_u64() = 0;
   virtual void rekey(const uint8_t *material, size_t len) = 0;
+  // true: Prover::prove does not draw the blinding VECTORS s_L, s_R (prover.rs:461-462, 526-527) scalar by scalar from this
+  // stream; it draws one 32-byte key per phase in their place and the device expands it ("BlindVec v1", include/bpgpu.h
+  // bpgpu_r1cs_prover_commit): no host-side draws, nothing to upload.  OsRng's default.
+  virtual bool vector_keys() const { return false; }
   Scalar scalar();            // 4 x u64 little-endian limbs (+ 4 zero limbs) reduced mod n
   // count scalars, the same stream as count calls of scalar(): the words are drawn in order, the reductions mod n run on the
   // thread pool (one prover drawing 2 x 32 766 blinding factors spent 6 ms in them)
@@ -84,10 +88,12 @@ class Rng {
 };
 class OsRng final : public Rng {
  public:
-  OsRng();                    // throws std::runtime_error if the OS gives no entropy
+  explicit OsRng(bool vector_keys = true);   // throws std::runtime_error if the OS gives no entropy
   uint64_t next_u64() override;
   void rekey(const uint8_t *material, size_t len) override;
+  bool vector_keys() const override { return vk_; }
  private:
+  bool vk_;
   void refill();
   uint64_t st_[25];           // Keccak-f[1600] sponge state; words 0..16 are the rate
   uint64_t blocks_ = 0;
@@ -95,11 +101,13 @@ class OsRng final : public Rng {
 };
 class SeededRng final : public Rng {
  public:
-  explicit SeededRng(uint64_t seed) : s_(seed) {}
+  explicit SeededRng(uint64_t seed, bool vector_keys = false) : s_(seed), vk_(vector_keys) {}
   uint64_t next_u64() override;
   void rekey(const uint8_t *, size_t) override {}
+  bool vector_keys() const override { return vk_; }   // (the oracle's vector-key mode replays such proofs)
  private:
   uint64_t s_;
+  bool vk_;
 };
 
 // Host-side data parallelism (the reference uses rayon): f(i) for i in [0, n) on up to BPH_THREADS threads
@@ -316,9 +324,12 @@ class Prover : public RandomizedConstraintSystem {
   Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const StarkPoint &V);
   R1CSProof prove(const BulletproofGens &bp_gens);                 // :412-727, blinding factors from a fresh OsRng
   R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // the same with the randomness injected (tests: SeededRng)
-  // the same for nb provers of one circuit in lock-step (every device call batched over the provers)
+  // the same for nb provers of one circuit in lock-step (every device call batched over the provers).  `device`: the context
+  // the batch runs on (default: the process-wide one).  A caller that streams batches gives each of its worker threads a
+  // Device of its own: while one thread waits for its batch's kernels the other builds, packs and hashes the next batch, and
+  // the kernels of the two overlap on the GPU (tests/host/capi.cpp bph_range_prove_stream; bench.py r1cs_prove).
   static std::vector<R1CSProof> prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
-                                            std::vector<Rng *> &rngs);
+                                            std::vector<Rng *> &rngs, Device *device = nullptr);
   bool constraints_satisfied() const;                              // :405-409
   Transcript &transcript() override;
   size_t num_constraints() const override;

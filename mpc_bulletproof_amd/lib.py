@@ -11,7 +11,7 @@ SYMBOLS = [
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
-    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy",
+    "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy", "bpgpu_r1cs_prover_commit", "bpgpu_r1cs_prover_session_polys",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_ark", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
     "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
@@ -415,6 +415,22 @@ class BpGpu:
         lv, rv = _out(32 * nb * padded_n), _out(32 * nb * padded_n)
         self._ck(_lib.bpgpu_r1cs_prover_eval(self.ctx, prover, C.c_size_t(padded_n), _buf(x), lv, rv))
         return bytes(lv)[:32 * nb * padded_n], bytes(rv)[:32 * nb * padded_n]
+
+    def r1cs_prover_commit(self, gens, session, nb, n_new, a_L, a_R, a_O, blindings, s_L=None, s_R=None, vector_keys=None):
+        """prover.rs:457-494 / :519-565 on a resident-witness session (None: open one) -> (session, A_I A_O S nb x 3 x 64 B).
+        All scalars in ark-ff Montgomery form; the blinding vectors explicit (s_L, s_R) or from vector_keys (nb x 32 B)."""
+        h = session if session is not None else C.c_void_p()
+        out = _out(64 * 3 * nb)
+        opt = lambda b: _buf(b) if b is not None else None     # noqa: E731
+        self._ck(_lib.bpgpu_r1cs_prover_commit(self.ctx, gens, C.byref(h), C.c_size_t(nb), C.c_size_t(n_new), opt(a_L), opt(a_R),
+                                               opt(a_O), opt(s_L), opt(s_R), opt(vector_keys), _buf(blindings), out))
+        return h, bytes(out)[:64 * 3 * nb]
+
+    def r1cs_prover_session_polys(self, session, circuit, nb, m, y, z):
+        """prover.rs:587-619 on the session's planes -> (t_coeffs nb x 6 x 32 B, wV nb x m x 32 B); y, z canonical LE"""
+        t, wv = _out(32 * 6 * nb), _out(32 * nb * max(m, 1))
+        self._ck(_lib.bpgpu_r1cs_prover_session_polys(self.ctx, session, circuit, _buf(y), _buf(z), t, wv))
+        return bytes(t)[:32 * 6 * nb], bytes(wv)[:32 * nb * m]
 
     def prover_destroy(self, prover):
         _lib.bpgpu_prover_destroy(self.ctx, prover)

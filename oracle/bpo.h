@@ -108,9 +108,15 @@ void tr_challenge_scalar(transcript *t, const char *label, sc *out);
 void gens_chain(aff *out, sc *dlog_or_null, char which, uint32_t party, size_t count);
 
 /* injectable RNG replacing thread_rng() (prover.rs:435-445) */
-typedef struct { uint64_t s; } splitmix;
+/* vec_keys != 0: the prover's blinding VECTORS s_L, s_R (prover.rs:461-462, 526-527) are not drawn scalar by scalar from the
+ * stream; a 32-byte key (four words of the stream, little endian) is drawn in their place, per phase, and expanded by
+ * blind_vector ("BlindVec v1": what include/bpgpu.h's bpgpu_r1cs_prover_commit does on the device). */
+typedef struct { uint64_t s; int vec_keys; } splitmix;
 uint64_t sm_next(splitmix *r);
 void sm_scalar(splitmix *r, sc *out);
+/* s_v[i] for i < count (v = 0: s_L, 1: s_R):  block(key, v, j) = first 128 bytes of Keccak-f[1600] over the keccak256-padded
+ * 48-byte message key || u64le(v) || u64le(j);  s_v[i] = int_LE(block(key, v, i / 2)[64 (i mod 2) .. +64]) mod n */
+void blind_vector(sc *out, const uint8_t key[32], int v, size_t count);
 
 /* ------------------------------------------------------------------ util.rs */
 void exp_iter(sc *out, const sc *x, size_t n);              /* util.rs:73-76 */

@@ -266,6 +266,15 @@ static void start_transcript(transcript *t, int kind, size_t param, const uint8_
   }
 }
 
+/* 1: provers made by bpo_r1cs_prove draw their blinding vectors as "BlindVec v1" keys (bpo.h splitmix.vec_keys) */
+static int g_vec_keys = 0;
+API void bpo_set_vector_keys(int on) { g_vec_keys = on != 0; }
+API void bpo_blind_vector(const uint8_t key[32], int v, size_t count, uint8_t *out) {
+  sc *s = (sc *)malloc((count ? count : 1) * sizeof(sc));
+  blind_vector(s, key, v, count);
+  for (size_t i = 0; i < count; i++) fe_to_le(SC, out + 32 * i, &s[i]);
+  free(s);
+}
 /* Prove one gadget instance.  values: range [v]; shuffle inputs[k] then outputs[k];
  * example [a1,a2,b1,b2,c1,c2]; dummy [] (the public value is drawn from the seed).
  * The SplitMix64 stream `seed` first yields the commitment blinding factors in commit order
@@ -277,7 +286,7 @@ API int bpo_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t labe
   start_transcript(&t, kind, param, label, label_len);
   cs_t cs;
   cs_init(&cs, 1, &t);
-  splitmix rng = {seed};
+  splitmix rng = {seed, g_vec_keys};
   sc v, bl;
   if (kind == K_RANGE) {
     if (nvalues != 1) return -3;

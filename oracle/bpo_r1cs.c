@@ -224,6 +224,24 @@ static size_t next_pow2(size_t n) {
 }
 static void set_inf(aff *a) { memset(a, 0, sizeof *a); a->inf = 1; }
 
+/* s_L then s_R, `count` scalars each (prover.rs:461-462 / :526-527): scalar by scalar from the stream, or -- rng->vec_keys --
+ * one 32-byte key from the stream expanded by blind_vector (nothing is drawn when count == 0, as a caller of the device path
+ * draws no key for an empty phase) */
+static void draw_blinding_vectors(splitmix *rng, sc *s_L, sc *s_R, size_t count) {
+  if (!rng->vec_keys) {
+    for (size_t i = 0; i < count; i++) sm_scalar(rng, &s_L[i]);
+    for (size_t i = 0; i < count; i++) sm_scalar(rng, &s_R[i]);
+    return;
+  }
+  if (!count) return;
+  uint8_t key[32];
+  for (int i = 0; i < 4; i++) {
+    uint64_t w = sm_next(rng);
+    for (int b = 0; b < 8; b++) key[8 * i + b] = (uint8_t)(w >> (8 * b));
+  }
+  blind_vector(s_L, key, 0, count);
+  blind_vector(s_R, key, 1, count);
+}
 /* prover.rs:412-727 with the RNG injected */
 int cs_prove(cs_t *cs, const aff *G, const aff *H, size_t gens_capacity, splitmix *rng, r1cs_proof *out) {
   transcript *tr = cs->tr;
@@ -234,8 +252,7 @@ int cs_prove(cs_t *cs, const aff *G, const aff *H, size_t gens_capacity, splitmi
   sc i_b1, o_b1, s_b1;
   sm_scalar(rng, &i_b1); sm_scalar(rng, &o_b1); sm_scalar(rng, &s_b1);
   sc *s_L = (sc *)malloc((n1 ? n1 : 1) * sizeof(sc)), *s_R = (sc *)malloc((n1 ? n1 : 1) * sizeof(sc));
-  for (size_t i = 0; i < n1; i++) sm_scalar(rng, &s_L[i]);
-  for (size_t i = 0; i < n1; i++) sm_scalar(rng, &s_R[i]);
+  draw_blinding_vectors(rng, s_L, s_R, n1);
   /* prover.rs:465-494 */
   {
     size_t nt = 2 * n1 + 1;
@@ -265,8 +282,7 @@ int cs_prove(cs_t *cs, const aff *G, const aff *H, size_t gens_capacity, splitmi
   if (n2 > 0) { sm_scalar(rng, &i_b2); sm_scalar(rng, &o_b2); sm_scalar(rng, &s_b2); }
   s_L = (sc *)realloc(s_L, (n ? n : 1) * sizeof(sc));
   s_R = (sc *)realloc(s_R, (n ? n : 1) * sizeof(sc));
-  for (size_t i = n1; i < n; i++) sm_scalar(rng, &s_L[i]);
-  for (size_t i = n1; i < n; i++) sm_scalar(rng, &s_R[i]);
+  draw_blinding_vectors(rng, s_L + n1, s_R + n1, n - n1);
   if (n2 > 0) { /* prover.rs:532-565 */
     size_t nt = 2 * n2 + 1;
     sc *ms = (sc *)malloc(nt * sizeof(sc));

@@ -74,6 +74,29 @@ void bpo_keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {
   for (int i = 0; i < 4; i++)
     for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(st[i] >> (8 * j));
 }
+/* BlindVec v1 (bpo.h): the device-drawn blinding vectors of the R1CS prover, restated */
+void blind_vector(sc *out, const uint8_t key[32], int v, size_t count) {
+  for (size_t j = 0; 2 * j < count; j++) {
+    uint64_t st[25];
+    memset(st, 0, sizeof st);
+    for (int i = 0; i < 4; i++) {
+      uint64_t w = 0;
+      for (int b = 7; b >= 0; b--) w = (w << 8) | key[8 * i + b];
+      st[i] = w;
+    }
+    st[4] = (uint64_t)v;
+    st[5] = (uint64_t)j;
+    st[6] = 0x01;                       /* pad: 0x01 right after the 48 message bytes ... */
+    st[16] = 0x8000000000000000ULL;     /* ... 0x80 at byte 135 (rate 136) */
+    keccak_f(st);
+    for (int h = 0; h < 2 && 2 * j + h < count; h++) {
+      uint8_t wide[64];
+      for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 8; b++) wide[8 * i + b] = (uint8_t)(st[8 * h + i] >> (8 * b));
+      fe_from_le_wide(SC, &out[2 * j + h], wide);
+    }
+  }
+}
 /* util.rs:252-267 */
 void hash_to_scalar(sc *r, const uint8_t low[32]) {
   uint8_t buf[64];

@@ -6,9 +6,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <thread>
 
 #include "gadgets.hpp"
 
@@ -26,10 +28,14 @@ enum { K_RANGE = 0, K_SHUFFLE = 1, K_EXAMPLE = 2, K_DUMMY = 3, K_RANGE_MULTI = 4
 // `seed` of the proving entry points: BPH_SEED_OS_ENTROPY (all ones) = blinding factors from OsRng (getrandom(2)-keyed DRBG,
 // what a deployment must use); any other value = the replayable SeededRng stream -- TEST / BENCH ONLY, such proofs are
 // not zero-knowledge (the parity tests and bench.py need proofs they can replay against the CPU oracle).
+// The blinding VECTORS (s_L, s_R): OsRng hands Prover::prove one key per phase and the device expands it (Rng::vector_keys;
+// BPH_HOST_VECTORS=1 keeps the scalar-by-scalar host draws, for A/B runs); the SeededRng does the same after
+// bph_set_seeded_vector_keys(1), which the oracle's vector-key mode replays.
 static const uint64_t BPH_SEED_OS_ENTROPY = ~(uint64_t)0;
+static bool g_seeded_vector_keys = false;
 static std::unique_ptr<Rng> make_rng(uint64_t seed) {
-  if (seed == BPH_SEED_OS_ENTROPY) return std::unique_ptr<Rng>(new OsRng());
-  return std::unique_ptr<Rng>(new SeededRng(seed));
+  if (seed == BPH_SEED_OS_ENTROPY) return std::unique_ptr<Rng>(new OsRng(getenv("BPH_HOST_VECTORS") == nullptr));
+  return std::unique_ptr<Rng>(new SeededRng(seed, g_seeded_vector_keys));
 }
 
 // BulletproofGens are created once and reused by a real caller (generators.rs:182); the flat batch entry points
@@ -69,6 +75,8 @@ static Transcript start_transcript(int kind, size_t param, const uint8_t *label,
 
 extern "C" {
 #pragma GCC visibility push(default)
+
+void bph_set_seeded_vector_keys(int on) { g_seeded_vector_keys = on != 0; }
 
 int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_len, const uint64_t *values,
                    size_t nvalues, uint64_t seed, size_t gens_capacity, uint8_t *proof_out, size_t *proof_len,
@@ -211,6 +219,107 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
     lap("serialise");
     parallel_for(nb, [&](size_t p) { provers[p].reset(); trs[p].reset(); });   // constraint systems: many small allocations
     lap("teardown");
+    return 0;
+  })
+}
+
+// A STREAM of prover batches (bench.py r1cs_prove; BASELINE configs[2] shape): nbatch batches of nb provers, each prover
+// range-proving nvals values of n_bits bits in one constraint system, proved by `threads` worker threads that each own a Device
+// (context + stream): while one thread waits for its batch's kernels, another builds / packs / hashes the next batch, and the
+// kernels of batches in flight overlap on the GPU.  values: nb x nvals (every batch proves the same values under fresh
+// blinding factors).  prebuild = 1: the constraint systems and commitments of ALL batches are built first, untimed -- the
+// reference's own bench times Prover::prove only (benches/r1cs.rs:36-55, 95-108: "only time proof generation") --, and the
+// timed region is the stream of prove_batch calls incl. dropping the provers (Prover::prove consumes self); prebuild = 0: circuit
+// building and commitments are inside the timed region too.  proofs_out: nbatch x nb x proof_len; commitments_out: nbatch x nb x
+// nvals x 64.  ms_out[0] = wall of the timed region, [1] = sum over batches of building, [2] = of prove_batch, [3] = of teardown.
+int bph_range_prove_stream(size_t nbatch, size_t threads, int prebuild, size_t nb, size_t nvals, size_t n_bits, const uint8_t *label,
+                           size_t label_len, const uint64_t *values, uint64_t seed0, size_t gens_capacity, uint8_t *proofs_out,
+                           size_t *proof_len, uint8_t *commitments_out, double ms_out[4]) {
+  GUARD({
+    if (!nbatch || !threads || !nb) return -3;
+    PedersenGens pc_gens;
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
+    bp_gens.device_tables(pc_gens);                    // built before the clock starts (a caller keeps its generators)
+    struct Batch {
+      std::vector<std::unique_ptr<Transcript>> trs;
+      std::vector<std::unique_ptr<Prover>> provers;
+      std::vector<std::unique_ptr<Rng>> rngs;
+      double ms_build = 0, ms_prove = 0, ms_drop = 0;
+    };
+    std::vector<Batch> batches(nbatch);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+      return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    auto build = [&](size_t bi, Device &dev) {
+      (void)dev;
+      auto t0 = now();
+      Batch &B = batches[bi];
+      std::vector<Scalar> vs(nb * nvals), bls(nb * nvals);
+      for (size_t p = 0; p < nb; p++) B.rngs.emplace_back(seed0 == BPH_SEED_OS_ENTROPY ? make_rng(seed0) : make_rng(seed0 + bi * nb + p));
+      parallel_for(nb, [&](size_t p) {
+        for (size_t j = 0; j < nvals; j++) { vs[p * nvals + j] = Scalar::from(values[p * nvals + j]); bls[p * nvals + j] = B.rngs[p]->scalar(); }
+      });
+      auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
+      for (size_t p = 0; p < nb; p++) {
+        B.trs.emplace_back(new Transcript(std::string((const char *)label, label_len)));
+        B.provers.emplace_back(new Prover(pc_gens, *B.trs.back()));
+      }
+      uint8_t *com = commitments_out + bi * nb * nvals * 64;
+      parallel_for(nb, [&](size_t p) {
+        for (size_t j = 0; j < nvals; j++) {
+          uint64_t v = values[p * nvals + j];
+          size_t ix = p * nvals + j;
+          memcpy(com + ix * 64, Vs[ix].xy.data(), 64);
+          Variable var = B.provers[p]->commit_precomputed(vs[ix], bls[ix], Vs[ix]);
+          gadgets::range_proof(*B.provers[p], LinearCombination(var), &v, n_bits);
+        }
+      });
+      B.ms_build = ms(t0, now());
+    };
+    std::mutex out_mu;
+    auto prove = [&](size_t bi, Device &dev) {
+      Batch &B = batches[bi];
+      auto t0 = now();
+      std::vector<Prover *> pp;
+      std::vector<Rng *> rr;
+      for (size_t p = 0; p < nb; p++) { pp.push_back(B.provers[p].get()); rr.push_back(B.rngs[p].get()); }
+      auto proofs = Prover::prove_batch(pp, bp_gens, rr, &dev);
+      auto t1 = now();
+      size_t plen = 0;
+      for (size_t p = 0; p < nb; p++) {
+        auto bytes = proofs[p].to_flat_bytes();
+        plen = bytes.size();
+        memcpy(proofs_out + (bi * nb + p) * plen, bytes.data(), plen);
+      }
+      { std::lock_guard<std::mutex> lk(out_mu); *proof_len = plen; }
+      parallel_for(nb, [&](size_t p) { B.provers[p].reset(); B.trs[p].reset(); });   // Prover::prove consumes the prover
+      B.ms_prove = ms(t0, t1);
+      B.ms_drop = ms(t1, now());
+    };
+    std::vector<std::unique_ptr<Device>> devs;
+    for (size_t t = 0; t < threads; t++) devs.emplace_back(new Device(0));
+    if (prebuild) for (size_t bi = 0; bi < nbatch; bi++) build(bi, *devs[0]);
+    std::atomic<size_t> next{0};
+    std::vector<std::exception_ptr> errs(threads);
+    auto T0 = now();
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < threads; t++)
+      th.emplace_back([&, t] {
+        try {
+          for (;;) {
+            size_t bi = next.fetch_add(1);
+            if (bi >= nbatch) break;
+            if (!prebuild) build(bi, *devs[t]);
+            prove(bi, *devs[t]);
+          }
+        } catch (...) { errs[t] = std::current_exception(); }
+      });
+    for (auto &x : th) x.join();
+    ms_out[0] = ms(T0, now());
+    for (auto &e : errs) if (e) std::rethrow_exception(e);
+    ms_out[1] = ms_out[2] = ms_out[3] = 0;
+    for (auto &B : batches) { ms_out[1] += B.ms_build; ms_out[2] += B.ms_prove; ms_out[3] += B.ms_drop; }
     return 0;
   })
 }

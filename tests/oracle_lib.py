@@ -174,8 +174,23 @@ def ipp_verify(label, n, Gf, Hf, Pp, Q, G, H, L, R, a, b):
                               _buf(Q), _buf(G), _buf(H), _buf(L), _buf(R), C.c_size_t(k), _buf(a), _buf(b))
 
 
-def r1cs_prove(kind, param, label, values, seed, gens_capacity):
-    """-> (rc, proof_bytes, commitments_bytes)"""
+def blind_vector(key, v, count):
+    """BlindVec v1 (oracle/bpo.h): the prover's device-drawn blinding vector s_L (v = 0) / s_R (v = 1), count x 32 B"""
+    out = _out(32 * count)
+    lib.bpo_blind_vector(_buf(key), C.c_int(v), C.c_size_t(count), out)
+    return bytes(out)[:32 * count]
+
+
+def r1cs_prove(kind, param, label, values, seed, gens_capacity, vector_keys=False):
+    """-> (rc, proof_bytes, commitments_bytes).  vector_keys: the blinding vectors as BlindVec v1 keys drawn from the stream"""
+    lib.bpo_set_vector_keys(1 if vector_keys else 0)
+    try:
+        return _r1cs_prove(kind, param, label, values, seed, gens_capacity)
+    finally:
+        lib.bpo_set_vector_keys(0)
+
+
+def _r1cs_prove(kind, param, label, values, seed, gens_capacity):
     vals = (C.c_uint64 * max(len(values), 1))(*values)
     proof = _out(lib.bpo_proof_flat_size(C.c_size_t(32)))
     plen, m = C.c_size_t(0), C.c_size_t(0)

@@ -181,6 +181,57 @@ def test_prove_batch_two_provers_of_4096_multipliers(host):
     assert _verify(host, o.K_RANGE_MULTI, param, label, [], bytes(com)[:nvals * 64], bytes(proofs)[:L], n)[0] == 0
 
 
+def test_prover_vector_key_mode_matches_oracle(host):
+    """Rng::vector_keys (OsRng's default): the blinding vectors s_L, s_R are drawn on the device from one 32-byte key per prover
+    and phase (BlindVec v1) instead of scalar by scalar on the host.  With the replayable test RNG in that mode the GPU prover's
+    proofs equal the oracle's vector-key mode byte for byte: 1-phase (range, example, dummy) and 2-phase (shuffle) circuits."""
+    host.bph_set_seeded_vector_keys(1)
+    try:
+        for kind, param, label, vals, cap in ((o.K_RANGE, 8, b"RangeProofTest", [77], 16), (o.K_RANGE, 64, b"RangeProofTest", [2**63 + 5], 64),
+                                              (o.K_SHUFFLE, 4, b"ShuffleProofTest", [5, 9, 2, 7, 2, 5, 7, 9], 16),
+                                              (o.K_SHUFFLE, 5, b"ShuffleProofTest", [1, 2, 3, 4, 5, 5, 4, 3, 2, 1], 16),
+                                              (o.K_EXAMPLE, 0, b"R1CSExampleGadget", [3, 4, 6, 1, 40, 9], 16), (o.K_DUMMY, 16, b"test", [], 16)):
+            rc, proof, com = _prove(host, kind, param, label, vals, 21, cap)
+            rc_o, proof_o, com_o = o.r1cs_prove(kind, param, label, vals, 21, cap, vector_keys=True)
+            assert rc == 0 and rc_o == 0 and (proof, com) == (proof_o, com_o), (kind, param)
+            assert proof != o.r1cs_prove(kind, param, label, vals, 21, cap)[1]
+            assert _verify(host, kind, param, label, vals[-1:] if kind == o.K_EXAMPLE else [], com, proof, cap)[0] == 0
+    finally:
+        host.bph_set_seeded_vector_keys(0)
+
+
+@pytest.mark.parametrize("prebuild", [0, 1])
+@pytest.mark.parametrize("vkeys", [0, 1])
+def test_prove_stream_over_worker_threads(host, prebuild, vkeys):
+    """bph_range_prove_stream: batches of lock-step provers proved by two worker threads, each on a Device (context) of its own,
+    sharing the generator tables and the cached circuit: every proof of every batch equals the oracle's for its seed."""
+    nbatch, threads, nb, nvals, n_bits = 3, 2, 3, 4, 8
+    n, cap, label = nvals * n_bits, 32, b"RangeProofTest"
+    vals = [(17 * (i + 1) + 101 * p) % (1 << n_bits) for p in range(nb) for i in range(nvals)]
+    arr = (C.c_uint64 * len(vals))(*vals)
+    proofs = (C.c_uint8 * (nbatch * nb * 8192))()
+    plen = C.c_size_t(0)
+    com = (C.c_uint8 * (nbatch * nb * nvals * 64))()
+    ms = (C.c_double * 4)()
+    host.bph_set_seeded_vector_keys(vkeys)
+    try:
+        rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_size_t(nb), C.c_size_t(nvals),
+                                         C.c_size_t(n_bits), o._buf(label), C.c_size_t(len(label)), arr, C.c_uint64(700), C.c_size_t(cap),
+                                         proofs, C.byref(plen), com, ms)
+    finally:
+        host.bph_set_seeded_vector_keys(0)
+    assert rc == 0 and ms[0] > 0
+    L = plen.value
+    param = n_bits | (nvals << 16)
+    for bi in range(nbatch):
+        for p in range(nb):
+            rc_o, proof_o, com_o = o.r1cs_prove(o.K_RANGE_MULTI, param, label, vals[p * nvals:(p + 1) * nvals], 700 + bi * nb + p, cap,
+                                                vector_keys=bool(vkeys))
+            i = bi * nb + p
+            assert rc_o == 0 and bytes(proofs)[i * L:(i + 1) * L] == proof_o and bytes(com)[i * nvals * 64:(i + 1) * nvals * 64] == com_o, (bi, p)
+    assert n == 32
+
+
 def test_reference_tests_restated_in_cpp():
     exe = os.path.join(ROOT, "tests", "host", "host_tests")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900)

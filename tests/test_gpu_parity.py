@@ -339,6 +339,74 @@ def test_range_verify_batch(gpu, n_bits, nb, c):
         gpu.circuit_destroy(circ)
 
 
+@pytest.mark.parametrize("vkeys", [False, True])
+def test_prover_session_commit_and_polys(gpu, vkeys):
+    """Resident-witness prover sessions (bpgpu_r1cs_prover_commit twice: 5 phase-1 + 3 phase-2 multipliers, then
+    bpgpu_r1cs_prover_session_polys): the six commitments per prover equal the oracle's MSMs of prover.rs:465-494 / :532-565 over
+    [B_blinding, G_lo.., H_lo..]; with vector_keys the blinding vectors are the oracle's BlindVec v1 expansion of the keys; the
+    polynomial outputs (t_1..t_6, wV, l(x), r(x)) equal those of bpgpu_r1cs_prover_polys on the same operands."""
+    import random
+    rnd = random.Random(4242 + vkeys)
+    N_ = o.N
+    n, nb, cap, split = 8, 3, 16, 5
+    rc, proof, com = o.r1cs_prove(o.K_RANGE, n, b"RangeProofTest", [200], 5, cap)
+    s = o.VerifySession(o.K_RANGE, n, b"RangeProofTest", [], com, proof, cap)
+    rp, kd, idx, coeff = s.csr()
+    circ = gpu.circuit_create(rp, kd, idx, coeff, n, s.m)
+    g = _gens(gpu, cap, 8)
+    Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
+    ark = lambda vals: b"".join((v * (1 << 256) % N_).to_bytes(32, "little") for v in vals)       # noqa: E731
+    pk = lambda vals: b"".join(o.s2b(v) for v in vals)                                               # noqa: E731
+    flat = lambda rows, lo, hi: [v for r in rows for v in r[lo:hi]]                                   # noqa: E731
+    wit = {k_: [[rnd.randrange(N_) if rnd.random() < 0.5 else rnd.randrange(2) for _ in range(n)] for _ in range(nb)] for k_ in ("aL", "aR", "aO")}
+    sL = [[0] * n for _ in range(nb)]
+    sR = [[0] * n for _ in range(nb)]
+    ses = None
+    try:
+        for lo, hi in ((0, split), (split, n)):
+            cnt = hi - lo
+            blinds = [[rnd.randrange(N_) for _ in range(3)] for _ in range(nb)]
+            if vkeys:
+                keys = [bytes(rnd.getrandbits(8) for _ in range(32)) for _ in range(nb)]
+                for p in range(nb):
+                    sL[p][lo:hi] = o.unscalars(o.blind_vector(keys[p], 0, cnt))
+                    sR[p][lo:hi] = o.unscalars(o.blind_vector(keys[p], 1, cnt))
+                ses, got = gpu.r1cs_prover_commit(g, ses, nb, cnt, ark(flat(wit["aL"], lo, hi)), ark(flat(wit["aR"], lo, hi)),
+                                                  ark(flat(wit["aO"], lo, hi)), ark(flat(blinds, 0, 3)), vector_keys=b"".join(keys))
+            else:
+                for p in range(nb):
+                    sL[p][lo:hi] = [rnd.randrange(N_) for _ in range(cnt)]
+                    sR[p][lo:hi] = [rnd.randrange(N_) for _ in range(cnt)]
+                ses, got = gpu.r1cs_prover_commit(g, ses, nb, cnt, ark(flat(wit["aL"], lo, hi)), ark(flat(wit["aR"], lo, hi)),
+                                                  ark(flat(wit["aO"], lo, hi)), ark(flat(blinds, 0, 3)),
+                                                  s_L=ark(flat(sL, lo, hi)), s_R=ark(flat(sR, lo, hi)))
+            gp, hp = Gp[64 * lo:64 * hi], Hp[64 * lo:64 * hi]
+            for p in range(nb):
+                want = [o.msm(pk([blinds[p][0]] + wit["aL"][p][lo:hi] + wit["aR"][p][lo:hi]), B + gp + hp),
+                        o.msm(pk([blinds[p][1]] + wit["aO"][p][lo:hi]), B + gp),
+                        o.msm(pk([blinds[p][2]] + sL[p][lo:hi] + sR[p][lo:hi]), B + gp + hp)]
+                assert [got[64 * (3 * p + w):64 * (3 * p + w + 1)] for w in range(3)] == want, (lo, p)
+        ys, zs, xs = ([rnd.randrange(1, N_) for _ in range(nb)] for _ in range(3))
+        t, wv = gpu.r1cs_prover_session_polys(ses, circ, nb, s.m, pk(ys), pk(zs))
+        lv, rv = gpu.r1cs_prover_eval(ses, nb, n, pk(xs))
+        t2, wv2, h2 = gpu.r1cs_prover_polys(circ, nb, n, s.m, pk(ys), pk([pow(y, -1, N_) for y in ys]), pk(zs), pk(flat(wit["aL"], 0, n)),
+                                            pk(flat(wit["aR"], 0, n)), pk(flat(wit["aO"], 0, n)), pk(flat(sL, 0, n)), pk(flat(sR, 0, n)))
+        lv2, rv2 = gpu.r1cs_prover_eval(h2, nb, n, pk(xs))
+        gpu.prover_destroy(h2)
+        assert (t, wv, lv, rv) == (t2, wv2, lv2, rv2)
+        import mpc_bulletproof_amd as m
+        with pytest.raises(m.BpGpuError):      # a second polynomial build on the same session
+            gpu.r1cs_prover_session_polys(ses, circ, nb, s.m, pk(ys), pk(zs))
+        with pytest.raises(m.BpGpuError):      # both sources of blinding vectors / neither
+            gpu.r1cs_prover_commit(g, None, nb, 2, ark([1] * 2 * nb), ark([1] * 2 * nb), ark([1] * 2 * nb), ark([1] * 3 * nb))
+    finally:
+        if ses is not None:
+            gpu.prover_destroy(ses)
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s.close()
+
+
 @pytest.mark.parametrize("tnp", [1, 2, 4, 8])
 @pytest.mark.parametrize("nb", [1, 2, 3, 5])
 def test_verify_handful_of_proofs_every_table_lane_shape(gpu, opts, nb, tnp):
