@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- range-proof verifications/s on MI355X (BASELINE.json configs[1]).
+"""bench.py -- range-proof verifications/s (+ R1CS constraints/s of the prover) on MI355X: BASELINE.json's metric.
 
-One step = one pass of the verification hot path (reference src/r1cs/verifier.rs:457-553: constraint
-flattening, inversions, verifier scalar assembly, the 154-term mega_check MSM, identity test) over a
-batch of 1024 proofs of the 64-bit range gadget (tests/r1cs.rs:620-652, m = 1), inputs resident in
-HBM (proof points/scalars + host-transcript challenges, boundary byte encodings of include/bpgpu.h).
-Multi-GPU: one process per GPU, each rank verifies its own 1024 proofs (independent units, no
-data-path collective) -> weak scaling; value = all ranks' proofs / max-over-ranks time.
-`python bench.py --gpus N` without a launcher starts the N rank processes itself (fresh children,
-before this process touches the GPU); under torch.distributed.run it reads RANK / WORLD_SIZE.
+One step = one pass of the verification hot path (reference src/r1cs/verifier.rs:457-553: constraint flattening, inversions,
+verifier scalar assembly, the 154-term mega_check MSM, identity test) over a batch of 1024 proofs of the 64-bit range gadget
+(tests/r1cs.rs:620-652, m = 1: BASELINE configs[1]), inputs resident in HBM (proof points / scalars + host-transcript
+challenges, boundary byte encodings of include/bpgpu.h).  Multi-GPU: one process per GPU, each rank verifies its own 1024
+proofs per step (independent units, no data-path collective) -> weak scaling; value = all ranks' proofs / max-over-ranks time.
+`python bench.py --gpus N` without a launcher starts the N rank processes itself (fresh children, before this process touches
+the GPU); under torch.distributed.run it reads RANK / WORLD_SIZE.
 
-Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline`.
+Prints ONE JSON line on rank 0 (contract in the task prompt) with `roofline` and `cpu_baseline`; the other half of the metric
+is the object `r1cs_prove` (configs[2]: 256 provers x (16 x 64 bit)), with its own `roofline` and `cpu_baseline`, and
+`shuffle_2e14` (configs[3] on one GPU).
 """
 import argparse
 import hashlib
@@ -32,10 +33,16 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 # Mix-weighted VALU issue peak: 74 % of the instructions of the elliptic-curve kernels are v_mad_i64_i32, which holds a
 # SIMD for 4.6 cycles per wave64 instruction (33.9 T lane-MAD/s measured chip-wide, profiles/r01_microbench_primitives.log);
 # the doubling / mixed-addition micro-benchmarks, which ARE this mix, issue one wave64 instruction per 4.25 cycles per
-# SIMD at 8 waves/SIMD.  1024 SIMDs x 2.4 GHz / 4.25.  (A kernel of plain 2-cycle VALU instructions would exceed it.)
-VALU_ISSUE_PEAK_MIX = 256 * 4 * 2.4e9 / 4.25
+# SIMD at 8 waves/SIMD.  Per SIMD: 2.4 GHz / 4.25; the chip has 1024 SIMDs.  (A kernel of plain 2-cycle VALU instructions
+# would exceed it.)
+SIMD_ISSUE_PEAK_MIX = 2.4e9 / 4.25
+N_SIMD = 256 * 4
+VALU_ISSUE_PEAK_MIX = N_SIMD * SIMD_ISSUE_PEAK_MIX
 MAD_PEAK_TOPS = 33.9            # measured v_mad_u64_u32 rate on MI355X (profiles/r01_microbench_primitives.log)
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_constants.json")
+# configs[2]: 256 provers, each range-proving 16 x 64-bit values in one constraint system
+P_NB, P_NVALS = 256, 16
+P_N, P_Q = P_NVALS * N_BITS, P_NVALS * (2 * N_BITS + 1)
 
 
 def _gen_workload(path, nb, seed0):
@@ -91,6 +98,8 @@ def _gen_workload(path, nb, seed0):
     os.replace(tmp, path)
 
 
+# ---- CPU legs: the oracle (tests/oracle_lib.py -> oracle/liboracle.so) runs ONLY inside these three worker functions, in
+# processes forked before this process initialises the GPU
 def _cpu_verify_chunk(args):
     import oracle_lib as o
     proofs, coms, plen = args
@@ -100,36 +109,64 @@ def _cpu_verify_chunk(args):
     return sum(ok), time.perf_counter() - t0
 
 
-def _cpu_baseline(wl, nb, ncpu):
+def _cpu_prove_chunk(args):
+    """`count` provers of configs[2]'s circuit (16 x 64-bit range gadgets in one constraint system) on the CPU oracle"""
+    import oracle_lib as o
+    seed, count = args
+    param = N_BITS | (P_NVALS << 16)
+    t0 = time.perf_counter()
+    n_ok = 0
+    for j in range(count):
+        vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * (seed + j))) & ((1 << 64) - 1)) for i in range(P_NVALS)]
+        rc, proof, com = o.r1cs_prove(o.K_RANGE_MULTI, param, LABEL, vals, 9000 + seed + j, P_N)
+        n_ok += rc == 0
+    dt = time.perf_counter() - t0
+    return n_ok, dt
+
+
+def _cpu_check_proofs(args):
+    """the CPU oracle's verdict on proofs made by the GPU prover inside a timed region: (kind, param, label, commitments, proof, cap)"""
+    import oracle_lib as o
+    return [o.r1cs_verify(kind, param, label, [], com, proof, cap) for kind, param, label, com, proof, cap in args]
+
+
+def _cpu_baseline(pool, nworkers, wl, nb):
     """The CPU oracle's Verifier::verify restatement (transcript replay + scalar assembly + 154-term Pippenger MSM) on a
-    bounded sample of the same workload: all host cores, then ONE thread.  Fork pools, before any GPU initialisation."""
+    bounded sample of the same workload: all host cores, then ONE process; then its Prover::prove restatement, one prover of
+    configs[2]'s circuit per core."""
     plen = wl["proof_len"]
-    per = (nb + ncpu - 1) // ncpu
+    per = (nb + nworkers - 1) // nworkers
     chunks = []
-    for c in range(ncpu):
+    for c in range(nworkers):
         lo, hi = c * per, min(nb, (c + 1) * per)
         if hi > lo:
             chunks.append((wl["proofs"][lo * plen:hi * plen], wl["commitments"][64 * lo:64 * hi], plen))
-    with mp.get_context("fork").Pool(len(chunks)) as pool:
-        pool.map(_cpu_verify_chunk, [(b"", b"", plen)] * len(chunks))     # start the workers, load the library
-        t0 = time.perf_counter()
-        res = pool.map(_cpu_verify_chunk, chunks, chunksize=1)
-        wall = time.perf_counter() - t0
+    pool.map(_cpu_verify_chunk, [(b"", b"", plen)] * nworkers)     # start the workers, load the library
+    t0 = time.perf_counter()
+    res = pool.map(_cpu_verify_chunk, chunks, chunksize=1)
+    wall = time.perf_counter() - t0
     assert sum(r[0] for r in res) == nb, "the CPU oracle rejects proofs made by the GPU prover"
     allc = {"value": nb / wall, "unit": "verifications/s", "cores": len(chunks), "kind": "port",
             "sample": f"{nb} proofs of the same workload, oracle cs_verify = the WHOLE of Verifier::verify (transcript replay "
                       f"+ scalar assembly + 154-term Pippenger MSM), {len(chunks)} processes, {sum(r[1] for r in res):.1f} s CPU; "
                       "the like-for-like GPU figure is `with_device_transcript`, not `value` (whose challenges are inputs)"}
     n1 = min(nb, 128)
-    with mp.get_context("fork").Pool(1) as pool:
-        pool.map(_cpu_verify_chunk, [(b"", b"", plen)])
-        t0 = time.perf_counter()
-        r1 = pool.map(_cpu_verify_chunk, [(wl["proofs"][:n1 * plen], wl["commitments"][:64 * n1], plen)])
-        wall1 = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    r1 = pool.map(_cpu_verify_chunk, [(wl["proofs"][:n1 * plen], wl["commitments"][:64 * n1], plen)])
+    wall1 = time.perf_counter() - t0
     assert r1[0][0] == n1
     one = {"value": n1 / wall1, "unit": "verifications/s", "cores": 1, "kind": "port",
            "sample": f"the first {n1} proofs of the same workload, one process (BASELINE.md's single-thread column)"}
-    return allc, one
+    t0 = time.perf_counter()
+    rp = pool.map(_cpu_prove_chunk, [(w, 1) for w in range(nworkers)], chunksize=1)
+    wallp = time.perf_counter() - t0
+    assert sum(r[0] for r in rp) == nworkers
+    prove = {"value": nworkers * P_Q / wallp, "unit": "R1CS constraints/s", "cores": nworkers, "kind": "port",
+             "proofs_per_s": nworkers / wallp,
+             "sample": f"{nworkers} provers of the same circuit (16 x 64-bit range gadgets, q = {P_Q}), one per process, the oracle's "
+                       f"Prover::prove restatement (prover.rs:412-727 incl. InnerProductProof::create), {sum(r[1] for r in rp):.1f} s CPU; "
+                       f"one process alone: {P_Q / max(r[1] for r in rp):.0f} constraints/s"}
+    return allc, one, prove
 
 
 def _free_port():
@@ -179,11 +216,23 @@ def _lib_hash():
     return h.hexdigest()[:16]
 
 
+def _union_ms(intervals):
+    """total length of the union of (start, end) intervals"""
+    busy, cs, ce = 0.0, None, None
+    for a, b in sorted(intervals):
+        if ce is None or a > ce:
+            if ce is not None:
+                busy += ce - cs
+            cs, ce = a, b
+        elif b > ce:
+            ce = b
+    return busy + (ce - cs if ce is not None else 0.0)
+
+
 def main():
-    # deep step pipelining needs hardware queues (ROCm default: 4) and one stream per context.  24 queues / 20 steps in
-    # flight: the best short-burst AND steady-state setting of tools/burst_sweep.sh (20 steps after a device sync
-    # 5.9 ms, 1024 steps 4.2 M/s); more than ~22 ACTIVE queues makes bursts erratic (24 / 24: 6 - 50 ms for 20 steps).
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    # Steps in flight: the main region rotates over `inflight` independent contexts (a stream + workspaces each).  The HIP runtime
+    # maps streams onto GPU_MAX_HW_QUEUES hardware queues; libbpgpu.so sets 24 when it is loaded (unless the process chose a
+    # value), and this script loads it before torch initialises HIP.  One stream per context.
     os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,9 +246,11 @@ def main():
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so the kernels of several batches overlap on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-combined", action="store_true", help="skip the secondary measurements (device transcript, wire format, "
-                                                               "combined batch check, H2D-inclusive, single batch)")
-    ap.add_argument("--no-prover", action="store_true", help="skip the secondary R1CS prover measurement (N = 1 only)")
+    ap.add_argument("--no-combined", action="store_true", help="skip the secondary verification measurements (one-call stream, H2D-"
+                                                               "inclusive, device transcript, wire format, combined batch check, single batch)")
+    ap.add_argument("--no-prover", action="store_true", help="skip the R1CS prover measurements (N = 1 only)")
+    ap.add_argument("--prover-threads", type=int, default=3, help="worker threads (one context each) of the prover stream")
+    ap.add_argument("--prover-batches", type=int, default=12, help="batches of 256 provers in the timed prover stream")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
     a = ap.parse_args()
@@ -217,8 +268,9 @@ def main():
 
     # ---- synthetic workload (setup, untimed), generated by the product path itself in a child process forked before
     # this process touches the GPU.  Every rank verifies the same batch (weak scaling): local rank 0 generates it
-    # once and publishes it through a file, the other ranks wait for the file.  The CPU baseline (the oracle's
-    # restatement) runs in fork pools on rank 0, also before any GPU initialisation here.
+    # once and publishes it through a file, the other ranks wait for the file.  The CPU baselines (the oracle's
+    # restatement) run in a fork pool on rank 0, created before any GPU initialisation here and kept for the oracle's
+    # verdict on proofs the GPU prover makes later.
     import pickle
     import tempfile
     ncpu = max(1, min(os.cpu_count() or 1, 32))
@@ -239,17 +291,19 @@ def main():
         time.sleep(0.5)
     with open(cache, "rb") as f:
         wl = pickle.load(f)
-    cpu = cpu1 = None
+    cpu = cpu1 = cpu_prove = None
+    pool = None
     if rank == 0 and not a.no_cpu_baseline:
-        cpu, cpu1 = _cpu_baseline(wl, nb, ncpu)
+        pool = mp.get_context("fork").Pool(ncpu)
+        cpu, cpu1, cpu_prove = _cpu_baseline(pool, ncpu, wl, nb)
     n1, n2, k, m = wl["dims"]
     rp, kind, idx, coeff = wl["csr"]
     pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
 
     # ---- GPU
+    import mpc_bulletproof_amd as mb     # (loads libbpgpu.so: hardware-queue default, before torch's first HIP call)
     import torch
     import torch.distributed as dist
-    import mpc_bulletproof_amd as mb
     if world > 1:
         if os.environ.get("BPGPU_BENCH_REHEARSAL"):
             # control-flow rehearsal of the multi-rank path on a ONE-GPU box: all ranks share device 0, gloo instead
@@ -272,18 +326,9 @@ def main():
     counter = [0]
     all_ok = (1).to_bytes(4, "little") * nb
 
-    sample_period = [0]            # > 0: step number s carries HIP-event pairs when s % sample_period == 0 (see below)
-    prof_state = [False] * len(ctxs)
-
     def step():
-        n = counter[0]
-        i = n % len(ctxs)
+        i = counter[0] % len(ctxs)
         counter[0] += 1
-        if sample_period[0]:
-            on = n % sample_period[0] == 0
-            if on != prof_state[i]:
-                ctxs[i].profile_enable(on)
-                prof_state[i] = on
         ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[i])
 
     def sync_all():
@@ -318,29 +363,6 @@ def main():
             dt = sharding.max_over_ranks(dt)
         return dt
 
-    # Per-kernel HIP-event timing (event pairs on the stream each kernel is launched on, recycled from a per-context pool).
-    # In the timed region ONE STEP in `inflight + 1` carries events, so the sampled steps rotate over the contexts (an event
-    # pair per launch on every context costs a short run a quarter of its throughput: ~12 barrier packets per step in each
-    # queue; always the same context made that context lag, and the closing fence waited for it: 3-5 % of a 2 048-step run);
-    # right after it the same K steps are REPLAYED with event pairs around every launch of every context: `roofline` is
-    # computed from the replay (>= K launches per kernel) and quotes the timed region's own sample beside it.
-    # BPGPU_PROF_EVERY overrides the sampling period.
-    prof_every = max(1, int(os.environ.get("BPGPU_PROF_EVERY", str(len(ctxs) + 1))))
-    noprof = bool(os.environ.get("BPGPU_BENCH_NOPROF"))
-    def sampling_on():
-        # in the timed region a sampled step times its dominant kernel only (bpgpu_profile_select): one event pair = two
-        # barrier packets in that step's queue instead of twelve (a fully timed step in a 20-step run cost the run 4-5 %)
-        for c in ctxs:
-            c.profile_select(["verify_back"])
-        sample_period[0] = 0 if noprof else prof_every
-
-    def sampling_off():
-        sample_period[0] = 0
-        for i, c in enumerate(ctxs):
-            c.profile_enable(False)
-            c.profile_select(None)
-            prof_state[i] = False
-
     for _ in range(max(a.warmup, len(ctxs))):
         step()
     sync_all()
@@ -349,50 +371,105 @@ def main():
     # the checks above leave the GPU idle for milliseconds: the warm-up keeps submitting steps (untimed) for
     # BPGPU_WARM_SECONDS of wall time; timed() then hands the device over busy
     warm_s = float(os.environ.get("BPGPU_WARM_SECONDS", "0.3"))
-    sampling_on()      # the warm-up also fills the sampled contexts' event pools: no hipEventCreate inside the timed region
     tw = time.perf_counter()
     while time.perf_counter() - tw < warm_s:
         for _ in range(2 * len(ctxs)):
             step()
     sync_all()
-    warm_sample = {}
-    for c in ctxs:           # the warm-up's sample (steady state, one step in 21) is kept; the events go back to the pools
-        for name, (ms, cnt) in c.profile_read().items():
-            pm, pc = warm_sample.get(name, (0.0, 0))
-            warm_sample[name] = (pm + ms, pc + cnt)
-    sampling_off()
     counter[0] = 0
-    dt = timed(lambda i: step(), a.steps, before=sampling_on)
-    sample_period[0] = 0      # (the per-context flags are cleared below, after the sample is read)
-
-    def collect():
-        acc = {}
-        for c in ctxs:
-            for name, (ms, cnt) in c.profile_read().items():
-                pm, pc = acc.get(name, (0.0, 0))
-                acc[name] = (pm + ms, pc + cnt)
-        return acc
-
-    prof_sample = collect()
+    # ======== the timed region: no event timing inside it
+    dt = timed(lambda i: step(), a.steps)
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == all_ok
-    # instrumented replay of the same K steps (capped at 256): every launch of every context timed
-    prof, replay_dt, replay_steps = prof_sample, None, 0
+
+    # ======== kernel timing, measured live with HIP events on the launch streams (bpgpu_profile_*), in two further regions:
+    #   (1) the same K steps (at most 256) REPLAYED with an event pair around every launch of every context: the union of the
+    #       intervals is the time the GPU was busy, the union per kernel kind the time that kernel was resident -- neither
+    #       can exceed the wall clock; the plain averages ("residency") are what a launch lasts among its neighbours;
+    #   (2) a few un-pipelined steps on one context: each kernel's SOLO duration -- what rocprofv3 of a solo run measures
+    #       (profiles/, tools/profile_all.sh) and the only duration that belongs to the kernel alone.  `roofline` uses it.
+    noprof = bool(os.environ.get("BPGPU_BENCH_NOPROF"))
+    replay = solo = None
     if not noprof:
         def all_on():
             for c in ctxs:
                 c.profile_enable(True)
 
-        sampling_off()
+        epoch = gpu.profile_epoch()
+        for c in ctxs:
+            c.profile_read()
         counter[0] = 0
         replay_steps = min(a.steps, 256)
-        replay_dt = timed(lambda i: step(), replay_steps, before=all_on)
-        prof = collect()
-    for c in ctxs:
-        c.profile_enable(False)
+        rdt = timed(lambda i: step(), replay_steps, before=all_on)
+        iv = []
+        for c in ctxs:
+            c.profile_enable(False)
+            iv += c.profile_intervals(epoch)
+        t_lo = min(x[1] for x in iv)
+        t_hi = max(x[2] for x in iv)
+        kinds = sorted({x[0] for x in iv})
+        busy = _union_ms([(x[1], x[2]) for x in iv])
+        replay = {"steps": replay_steps, "ms_per_step": rdt / replay_steps * 1e3,
+                  "gpu_busy_ms_per_step": busy / replay_steps, "gpu_busy_frac": busy / (t_hi - t_lo),
+                  "resident_ms_per_step": {n_: _union_ms([(x[1], x[2]) for x in iv if x[0] == n_]) / replay_steps for n_ in kinds},
+                  "residency_avg_ms": {n_: sum(x[2] - x[1] for x in iv if x[0] == n_) / max(1, sum(1 for x in iv if x[0] == n_)) for n_ in kinds},
+                  "launches": {n_: sum(1 for x in iv if x[0] == n_) for n_ in kinds},
+                  "what": f"the same {replay_steps} steps again with a HIP-event pair around EVERY launch of every context (the pairs are "
+                          "barriers in the queues: this region runs slower than the timed one).  gpu_busy = union of all launch "
+                          "intervals; resident_ms_per_step[k] = union of kernel k's intervals / steps (<= ms_per_step by construction); "
+                          "residency_avg_ms[k] = plain average of a launch's duration among its ~20 neighbours (not a roofline input)"}
+        # (2) solo
+        sync_all()
+        gpu.profile_enable(True)
+        solo_steps = 12
+        for _ in range(solo_steps):
+            gpu.r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[0])
+            gpu.sync()
+        gpu.profile_enable(False)
+        solo = {n_: (ms / cnt, cnt) for n_, (ms, cnt) in gpu.profile_read().items() if cnt}
+        assert gpu.download(d_oks[0], 4 * nb) == all_ok
 
-    fs = wire = comb = h2d = single = None
+    one_call = fs = wire = comb = h2d = single = None
     if not a.no_combined:
+        # ---- secondary: ONE context, ONE call (bpgpu_r1cs_verify_stream_dev): the library cuts the proofs into batches of 1024
+        # and spreads them over its own ring of 20 lanes -- what a Rust host's loop of Verifier::verify becomes
+        one_call = {}
+        for tag, reps in (("20k", 20), ("64k", 64), ("256k", 256)):
+            d_p2, d_s2, d_c2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps)
+            d_o2 = gpu.malloc(4 * nb * reps)
+            ts = []
+            for rep_ in range(6):
+                sync_all()
+                t0 = time.perf_counter()
+                gpu.r1cs_verify_stream_dev(gens, circ, nb * reps, n1, k, d_p2, d_s2, d_c2, d_o2)
+                gpu.sync()
+                ts.append(time.perf_counter() - t0)
+            assert gpu.download(d_o2, 4 * nb * reps) == all_ok * reps
+            for d in (d_p2, d_s2, d_c2, d_o2):
+                gpu.free(d)
+            ts = sorted(ts[1:])
+            one_call[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
+                             "best_ms": ts[0] * 1e3}
+        # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane
+        reps = 64
+        h_p, h_s, h_c = mb.lib.host_alloc(len(pts) * reps, pts * reps), mb.lib.host_alloc(len(sc) * reps, sc * reps), mb.lib.host_alloc(len(ch) * reps, ch * reps)
+        ts = []
+        for rep_ in range(5):
+            sync_all()
+            t0 = time.perf_counter()
+            ok_h = gpu.r1cs_verify_stream(gens, circ, nb * reps, n1, k, m, h_p, h_s, h_c)
+            ts.append(time.perf_counter() - t0)
+            assert all(ok_h)
+        for h_ in (h_p, h_s, h_c):
+            mb.lib.host_free(h_)
+        ts = sorted(ts[1:])
+        one_call["host_64k"] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
+                                "bytes_uploaded": (len(pts) + len(sc) + len(ch)) * reps}
+        one_call["note"] = ("bpgpu_r1cs_verify_stream(_dev): one context, one call, no environment variable exported by the caller; the library owns "
+                            "the ring of 20 lanes.  20k = a burst of 20 batches on an idle GPU (the first front launches and the last back "
+                            "launches have the chip to themselves: ~80 % of the steady state); 64k / 256k approach the steady state; host_64k "
+                            "takes operands from page-locked host memory and returns verdicts there (SURVEY 8d's metric as written).  Median of 5 calls")
+
         # ---- secondary: ONE batch at a time (no pipelining): the latency of a batch's kernel chain
         lat = []
         ctxs[0].set_latency_mode(True)      # the context-level hint for un-pipelined callers (include/bpgpu.h)
@@ -432,7 +509,8 @@ def main():
         h2d = {"value": world * nb * a.steps / hdt, "unit": "verifications/s", "ms_per_step": hdt / a.steps * 1e3,
                "bytes_per_step": len(packed),
                "note": "as `value`, plus the upload of every step's proof points, proof scalars and challenges from page-locked "
-                       "host memory inside the timed region (SURVEY 8d: 'incl. H2D of proof scalars + points'); never the headline"}
+                       "host memory inside the timed region (SURVEY 8d: 'incl. H2D of proof scalars + points').  The bench contract "
+                       "defines `value` with inputs resident in HBM, so this PCIe-inclusive rate is reported here, beside it"}
 
         # ---- secondary: the same per-proof verification with the Fiat-Shamir transcript replayed on the device
         # (SURVEY 8f N1): inputs are the proofs + one 32-byte initial chain state per proof, no host challenges
@@ -483,21 +561,7 @@ def main():
         for i in range(len(ctxs)):
             cstep(i)
         sync_all()
-        for c in ctxs:
-            c.profile_read()
-
-        def comb_on():
-            for i, c in enumerate(ctxs):
-                c.profile_enable(not noprof and i % prof_every == 0)
-
-        cdt = timed(cstep, a.steps, before=comb_on)
-        cprof = {}
-        for c in ctxs:
-            for name, (ms, cnt) in c.profile_read().items():
-                if name.startswith("combined") and cnt:
-                    pm, pc = cprof.get(name, (0.0, 0))
-                    cprof[name] = (pm + ms, pc + cnt)
-            c.profile_enable(False)
+        cdt = timed(cstep, a.steps)
         part = ctxs[0].download(d_parts[0], 64)
         if world > 1:
             from mpc_bulletproof_amd import sharding
@@ -505,90 +569,190 @@ def main():
         assert part == bytes(64), "combined batch check must be the identity for valid proofs"
         comb = {"value": world * nb * a.steps / cdt, "unit": "verifications/s", "ms_per_step": cdt / a.steps * 1e3,
                 "vs_per_proof_value": (world * nb * a.steps / cdt) / (world * nb * a.steps / dt),
-                "stage_ms_per_step": {n_: v[0] / max(v[1], 1) for n_, v in cprof.items()},
                 "note": "sum_p rho_p*mega_check_p == identity (single accept bit per batch; one fixed-base MSM over the 130 "
                         f"generators + one {nb * (11 + m + 2 * k)}-term bucket-method MSM per GPU; partial points all-gathered "
                         "over RCCL when n_gpus > 1)"}
 
-    # ---- secondary: the other half of BASELINE.json's metric, R1CS constraints/s of the prover, on configs[2]'s
-    # shape: 256 provers in lock-step, each range-proving 16 x 64-bit values in one constraint system (n = 1024
-    # multipliers, q = 2064 constraints), through the C++ host mirror (wall clock incl. circuit building,
-    # transcripts and packing on the host).  tools/bench_prove.py checks the proof bytes against the oracle.
-    prove = None
+    # ======== the other half of BASELINE.json's metric: R1CS constraints/s of the PROVER (configs[2]: 256 provers in lock-step, each
+    # range-proving 16 x 64-bit values in one constraint system: n = 1024 multipliers, q = 2064 constraints), through the C++ host
+    # mirror of the reference API over the C ABI.  A stream of batches on `prover_threads` worker threads, one context each.
+    prove = shuffle = None
     if world == 1 and not a.no_prover:
         import ctypes as C
         host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
-        pnb, nvals = 256, 16
-        pq, pn = nvals * (2 * N_BITS + 1), nvals * N_BITS
-        vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(pnb) for i in range(nvals)]
+        vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(P_NB) for i in range(P_NVALS)]
         arr = (C.c_uint64 * len(vals))(*vals)
         lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
-        pout, pcom, plen_ = (C.c_uint8 * (pnb * 4096))(), (C.c_uint8 * (pnb * nvals * 64))(), C.c_size_t(0)
+        OS_ENTROPY = (1 << 64) - 1
+
+        def stream(nbatch, threads, prebuild, profile):
+            pout, plen_ = (C.c_uint8 * (nbatch * P_NB * 4096))(), C.c_size_t(0)
+            pcom, ms_ = (C.c_uint8 * (nbatch * P_NB * P_NVALS * 64))(), (C.c_double * 12)()
+            rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_int(profile), C.c_size_t(P_NB),
+                                             C.c_size_t(P_NVALS), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr, C.c_uint64(OS_ENTROPY),
+                                             C.c_size_t(P_N), pout, C.byref(plen_), pcom, ms_)
+            assert rc == 0, f"bph_range_prove_stream rc={rc}"
+            return list(ms_), pout, plen_.value, pcom
+
+        T, NBAT = max(1, a.prover_threads), max(1, a.prover_batches)
+        stream(2, 1, 1, 0)            # generator tables (20 GB, c = 14), workspaces, pools, the cached circuit
+        stream(2 * T, T, 1, 0)        # every worker's context warm
         best = None
-        for rep in range(6):
-            t0 = time.perf_counter()
-            rc = host.bph_range_prove_batch(C.c_size_t(pnb), C.c_size_t(nvals), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)),
-                                            arr, C.c_uint64((1 << 64) - 1), C.c_size_t(pn), pout, C.byref(plen_), pcom)   # all ones = OsRng
-            pdt = time.perf_counter() - t0
-            assert rc == 0, f"bph_range_prove_batch rc={rc}"
-            best = pdt if best is None or (rep and pdt < best) else best
-        prove = {"value": pnb * pq / best, "unit": "R1CS constraints/s", "proofs_per_s": pnb / best, "ms_per_batch": best * 1e3,
-                 "workload": f"{pnb} provers x ({nvals} x 64-bit range gadgets in one constraint system: n = {pn}, q = {pq}, m = {nvals})",
-                 "note": "wall clock of Prover::prove_batch incl. host circuit building, transcripts and packing; blinding factors from the "
-                         "default RNG (OsRng: getrandom(2)-keyed Keccak sponge), best of batches 2-6 (the 1st builds the generator tables; the host phases share the box's cores with the other tenants)"}
+        for rep in range(3):
+            r = stream(NBAT, T, 1, 0)
+            if best is None or r[0][0] < best[0][0]:
+                best = r
+        ms_b, pout, plen_v, pcom = best
+        # a sample of the proofs made inside the timed region must verify: GPU verifier here, the CPU oracle in the fork pool
+        param = N_BITS | (P_NVALS << 16)
+        sample = [(bi, p) for bi in sorted({0, NBAT // 2, NBAT - 1}) for p in (0, 101, P_NB - 1)]
+        pb, cb = bytes(pout), bytes(pcom)
+        chk = []
+        for bi, p in sample:
+            i = bi * P_NB + p
+            proof_i, com_i = pb[i * plen_v:(i + 1) * plen_v], cb[i * P_NVALS * 64:(i + 1) * P_NVALS * 64]
+            mega = (C.c_uint8 * 64)()
+            vv = (C.c_uint64 * 1)()
+            rc = host.bph_r1cs_verify(4, C.c_size_t(param), lab, C.c_size_t(len(LABEL)), vv, C.c_size_t(0),
+                                      (C.c_uint8 * len(com_i)).from_buffer_copy(com_i), C.c_size_t(P_NVALS),
+                                      (C.c_uint8 * len(proof_i)).from_buffer_copy(proof_i), C.c_size_t(len(proof_i)), C.c_size_t(P_N), mega)
+            assert rc == 0, f"a proof of the timed prover stream does not verify (batch {bi}, prover {p}): rc={rc}"
+            chk.append((4, param, LABEL, com_i, proof_i, P_N))
+        oracle_checked = 0
+        if pool is not None:
+            verdicts = pool.map(_cpu_check_proofs, [chk[:2], chk[-2:]])
+            assert all(v == 0 for vs in verdicts for v in vs), "the CPU oracle rejects a proof of the timed prover stream"
+            oracle_checked = 4
+        assert len({pb[i * plen_v:(i + 1) * plen_v] for i in range(NBAT * P_NB)}) == NBAT * P_NB      # every proof is a different one
+        # the same stream with HIP-event timing of the device phases (separate region): GPU-busy share, the dominant kernel's residency;
+        # one worker alone: the dominant kernel's SOLO duration; circuit building inside the timed region
+        ms_p = stream(NBAT, T, 1, 1)[0]
+        nsolo = max(2, NBAT // 4)
+        ms_s = stream(nsolo, 1, 1, 1)[0]
+        ms_full = min((stream(NBAT, T, 0, 0)[0] for _ in range(2)), key=lambda r: r[0])
+        wall = ms_b[0]
+        per_launch_bytes = 2 * P_NB * (1 + P_N) * 96          # 512 L / R MSMs of 1 + n terms, 96 B per term
+        solo_msm_ms = ms_s[5] / max(ms_s[6], 1)
+        pmc_p = None
+        if os.path.exists(PMC_FILE):
+            with open(PMC_FILE) as f:
+                pmc_p = json.load(f).get("prover")
+        prove = {"value": NBAT * P_NB * P_Q / wall * 1e3, "unit": "R1CS constraints/s", "proofs_per_s": NBAT * P_NB / wall * 1e3,
+                 "ms_per_batch": wall / NBAT,
+                 "workload": f"{NBAT} batches x {P_NB} provers x ({P_NVALS} x 64-bit range gadgets in one constraint system: n = {P_N}, q = {P_Q}, m = {P_NVALS}), "
+                             f"{T} worker threads with a context each",
+                 "timed": "Prover::prove_batch for every batch incl. dropping the provers (Prover::prove consumes self): the reference's own bench "
+                          "times proof generation only, with the constraint system built beforehand (benches/r1cs.rs:36-55, 95-108).  Blinding factors "
+                          "from the default RNG (OsRng; the blinding vectors s_L, s_R are expanded on the device from one key per prover).  Best of 3 streams",
+                 "proofs_checked": {"gpu_verifier": len(sample), "cpu_oracle": oracle_checked, "distinct_proofs": NBAT * P_NB},
+                 "host_ms_per_batch": {"prove_batch": ms_b[2] / NBAT, "drop": ms_b[3] / NBAT, "circuit_building_untimed": ms_b[1] / NBAT},
+                 "incl_circuit_building": {"value": NBAT * P_NB * P_Q / ms_full[0] * 1e3, "unit": "R1CS constraints/s", "ms_per_batch": ms_full[0] / NBAT,
+                                           "note": "the same stream with gadget building (256 x 2064 constraint rows), the 4096 Pedersen commitments and the "
+                                                   "provers' set-up inside the timed region as well"},
+                 "single_thread": {"value": P_NB * P_Q / (ms_s[0] / nsolo) * 1e3, "unit": "R1CS constraints/s",
+                                   "ms_per_batch": ms_s[0] / nsolo, "note": "one worker thread, batches back to back (with event timing on)"},
+                 "roofline": {"bound": "hbm", "kernel": "k_fixed_msm_ipp<14,128> (+ its block sum): the L / R table-lookup MSMs of one IPP round, 512 MSMs of 1025 terms",
+                              "achieved": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_p or {}).get("traffic_bytes_round_msm"),
+                              "avg_launch_ms": solo_msm_ms, "launches": int(ms_s[6]), "algorithmic_bytes_per_launch": per_launch_bytes,
+                              "timed": "HIP-event pairs on the launch stream around the kernel, one worker thread (no other batch on the GPU)",
+                              "residency_in_the_stream_ms": ms_p[5] / max(ms_p[6], 1),
+                              "note": "VALU-integer bound like every kernel here: 19 mixed additions (~1 650 instructions each) per 96 algorithmic bytes"},
+                 "gpu_busy": {"frac": ms_p[4] / ms_p[0], "busy_ms_per_batch": ms_p[4] / NBAT, "wall_ms_per_batch": ms_p[0] / NBAT,
+                              "device_phase_ms_per_batch": {"ipp_rounds": ms_p[7] / NBAT, "phase_commitments": ms_p[8] / NBAT, "polynomials": ms_p[9] / NBAT,
+                                                            "T_commitments": ms_p[10] / NBAT, "ipp_setup": ms_p[11] / NBAT},
+                              "what": "union over the worker contexts of the device-phase intervals (HIP events, first to last launch of every call) / wall "
+                                      "clock of the stream, measured in a separate stream with event timing on"},
+                 "roofline_valu_issue": ({"bound": "VALU issue slots (mix-weighted)", "achieved": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3),
+                                          "peak": VALU_ISSUE_PEAK_MIX, "unit": "wave-instr/s",
+                                          "frac": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3) / VALU_ISSUE_PEAK_MIX,
+                                          "valu_wave_instr_per_batch": pmc_p["valu_wave_instr_per_batch"], "source": pmc_p.get("source")} if pmc_p else None),
+                 "cpu_baseline": cpu_prove}
+
+        # ---- configs[3] on ONE GPU: the k-shuffle gadget at k = 2^14 (q = 65 533 constraints, n = 32 766 multipliers, all
+        # second-phase; m = 32 768 commitments; 98 347-term mega_check): one proof, prove then verify, wall clock of
+        # Prover::prove / Verifier::verify with the circuit built beforehand (as the reference's benches/shuffle.rs times them)
+        if not os.environ.get("BPGPU_BENCH_NO_SHUFFLE"):
+            ks = 1 << 14
+            rnd = __import__("random").Random(77)
+            xs = [rnd.getrandbits(64) for _ in range(ks)]
+            ys = list(xs)
+            rnd.shuffle(ys)
+            sarr = (C.c_uint64 * (2 * ks))(*(xs + ys))
+            sproof, splen, scom, sms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+            runs = []
+            for rep in range(4):
+                rc = host.bph_shuffle_prove_verify(C.c_size_t(ks), sarr, C.c_uint64(OS_ENTROPY), C.c_size_t(1 << 15), sproof, C.byref(splen), scom, sms)
+                assert rc == 0, f"bph_shuffle_prove_verify rc={rc}"          # rc == 0: the proof was accepted by the GPU verifier
+                if rep:
+                    runs.append(list(sms))
+            med = [sorted(r[i] for r in runs)[1] for i in range(6)]
+            qs = 4 * (ks - 1) + 1
+            shuffle = {"workload": f"k-shuffle gadget, k = 2^14: q = {qs} constraints, n = {2 * (ks - 1)} multipliers (phase 2), m = {2 * ks}, padded n = 2^15",
+                       "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "circuit_building_ms": med[2]},
+                       "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "circuit_building_ms": med[4]},
+                       "note": "one proof on one GPU, medians of 3; every proof verified (the call fails otherwise); OsRng blinding factors"}
+
+    if pool is not None:
+        pool.close()
+        pool.join()
 
     if rank == 0:
         nvar = 11 + m + 2 * k
         nterms = 13 + m + 2 * (1 << k) + 2 * k
         W = 252 // a.window_bits + 1
         # The kernels of the window-parallel chain that consume algorithmic bytes (96 B per MSM term = 64 B point +
-        # 32 B scalar) and what each reads of them; the dominant kernel = the one with the largest summed duration.
+        # 32 B scalar) and what each reads of them; the dominant kernel = the one with the longest solo duration.
         lpm = 16 if nb >= 1024 else 32
         names = {"verify_back": f"k_verify_back<{a.window_bits},{lpm}>", "verify_front": "k_verify_front<4>",
-                 "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars"}
+                 "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars", "verify_groups": "k_verify_horner_groups",
+                 "verify_verdict": "k_verify_verdict"}
         bytes_per_proof = {"verify_back": (nterms - nvar) * 96, "verify_front": nvar * 64, "verify_windows": nvar * 32,
                            "verify_scalars": (6 + k + 5) * 32 + nterms * 32}
-        timed_names = [n_ for n_ in names if prof.get(n_, (0.0, 0))[1] > 0]
         pmc = None
         if os.path.exists(PMC_FILE):
             with open(PMC_FILE) as f:
                 pmc = json.load(f)
         lib_hash = _lib_hash()
-        roof = None
-        if timed_names:
-            dom = max(timed_names, key=lambda n_: prof[n_][0])
-            # The kernel's launches overlap with those of the other steps in flight, so its "duration" depends on how many: a
-            # 20-step burst holds twenty of them at once (replay below), the steady state of the warm-up and of a long timed
-            # region about five.  The roofline line uses what `rocprofv3 --kernel-trace --stats` of this same command averages
-            # over -- every phase of the run in proportion -- i.e. the one-step-in-21 sample of the warm-up AND the timed region;
-            # the every-launch replay of the timed steps is quoted beside it.
-            pooled_ms = warm_sample.get(dom, (0.0, 0))[0] + prof_sample.get(dom, (0.0, 0))[0]
-            pooled_cnt = warm_sample.get(dom, (0.0, 0))[1] + prof_sample.get(dom, (0.0, 0))[1]
-            rep_ms, rep_cnt = prof[dom]
-            ms, cnt = (pooled_ms, pooled_cnt) if pooled_cnt >= 8 else (rep_ms, rep_cnt)
-            avg_s = ms / cnt / 1e3
-            alg_bytes = nb * bytes_per_proof[dom]
-            achieved = alg_bytes / avg_s / 1e9
-            traffic = (pmc or {}).get("traffic_bytes_per_launch", {}).get(dom)
-            roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": avg_s * 1e3,
-                    "algorithmic_bytes_per_launch": alg_bytes, "launches": cnt,
-                    "timed": (f"HIP-event pairs on the launch stream around this kernel in one step of {prof_every} (rotating over the "
-                              f"contexts) throughout the {warm_s:.1f} s warm-up and the timed region" if pooled_cnt >= 8 else
-                              "every launch of the replay"),
-                    "burst_replay": ({"avg_launch_ms": rep_ms / rep_cnt, "launches": rep_cnt, "ms_per_step": replay_dt / replay_steps * 1e3,
-                                      "what": f"the same {replay_steps} steps again, HIP-event pairs around every launch of every context"}
-                                     if replay_dt and rep_cnt else None),
-                    "under_rocprofv3": ((pmc or {}).get("profiled_run_bench20") if (pmc or {}).get("lib_sha256_16") == lib_hash else None),
-                    "timed_region_sample": ({"avg_launch_ms": prof_sample[dom][0] / prof_sample[dom][1], "launches": prof_sample[dom][1],
-                                             "steps_sampled": f"1 in {prof_every} (rotating over the contexts)"} if prof_sample.get(dom, (0, 0))[1] else None),
-                    "note": "achieved = algorithmic bytes of the dominant kernel / its average launch duration (HIP events on the "
-                            "launch stream).  Twenty steps are in flight, so a launch shares the chip with its neighbours and lasts "
-                            "longer than alone (0.50 ms) -- and longer than under rocprofv3, whose tracing thins the overlap: "
-                            "`under_rocprofv3` holds that run's rocprofv3 and HIP-event averages (they agree with each other).  The "
-                            "path is VALU-integer bound, not HBM bound: 252-bit modular arithmetic spends ~1 650 instructions per 96 "
-                            "algorithmic bytes; see roofline_valu_issue"}
+        pmc_ok = bool(pmc) and nb == 1024 and a.window_bits == 20
+        roof = per_kernel = None
         step_s = dt / a.steps
+        if solo:
+            cand = [n_ for n_ in bytes_per_proof if n_ in solo]
+            dom = max(cand, key=lambda n_: solo[n_][0])
+            solo_ms, solo_cnt = solo[dom]
+            alg_bytes = nb * bytes_per_proof[dom]
+            achieved = alg_bytes / (solo_ms * 1e-3) / 1e9
+            traffic = (pmc or {}).get("traffic_bytes_per_launch", {}).get(dom)
+            res_step = replay["resident_ms_per_step"].get(dom)
+            step_bytes = nb * (nterms * 96 + (6 + k + 5) * 32)
+            roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": solo_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes, "launches": solo_cnt,
+                    "timed": "HIP-event pairs on the launch stream around this kernel, un-pipelined steps on one context right after the timed "
+                             "region (the kernel's SOLO duration: the figure `rocprofv3 --kernel-trace` of a solo run measures, "
+                             "profiles/*_pmc_sq_summary.txt / pmc_constants.json solo_us)",
+                    "in_pipeline": {"resident_ms_per_step": res_step, "achieved": (alg_bytes / (res_step * 1e-3) / 1e9 if res_step else None),
+                                    "frac": (alg_bytes / (res_step * 1e-3) / 1e9 / HBM_PEAK_GBS if res_step else None),
+                                    "what": "union of this kernel's launch intervals over all contexts / steps of the every-launch replay: the share of "
+                                            "a step's wall clock during which the kernel is on the chip (<= ms_per_step of the replay); its launches "
+                                            "overlap each other and the other kernels' there"},
+                    "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS},
+                    "solo_reference_us": ((pmc or {}).get("solo_us", {}).get(dom) if (pmc or {}).get("lib_sha256_16") == lib_hash else None),
+                    "note": "The path is VALU-integer bound, not HBM bound: 252-bit modular arithmetic spends ~1 650 instructions per 96 "
+                            "algorithmic bytes (roofline_valu_issue).  `traffic` (PMC, 2 x FETCH_SIZE + WRITE_SIZE) exceeds the algorithmic bytes "
+                            "because every term gathers 13 random 64-byte rows of the 57 GB fixed-base table -- bytes spent to delete doublings"}
+            if pmc_ok:
+                # per kernel: VALU wave-instructions (rocprofv3 --pmc SQ_INSTS_VALU, solo) / its solo duration measured HERE / the issue
+                # peak of the SIMDs its waves occupy (waves < 1024: one SIMD each)
+                per_kernel = {}
+                for n_, full in names.items():
+                    if n_ in solo and n_ in pmc.get("valu_wave_instr_per_launch", {}):
+                        instr, waves = pmc["valu_wave_instr_per_launch"][n_], (pmc.get("waves_per_launch") or {}).get(n_)
+                        simds = min(N_SIMD, int(waves)) if waves else N_SIMD
+                        per_kernel[full] = {"valu_wave_instr": instr, "solo_ms": solo[n_][0], "waves": waves, "simds_occupied": simds,
+                                            "frac_of_occupied_simds_issue_peak": instr / (solo[n_][0] * 1e-3) / (simds * SIMD_ISSUE_PEAK_MIX),
+                                            "frac_of_chip_issue_peak": instr / (solo[n_][0] * 1e-3) / VALU_ISSUE_PEAK_MIX}
         # integer roofline: algorithmic F_p multiplications x 94 limb MADs each (csrc/fe29.cuh), per step.  Per non-identity proof
         # point 7 table additions + 60 window additions (mixed, 11 mul), one inversion per 4 points (~310), per proof 252
         # doublings (9) + 64 additions (16) in the Horner passes; fixed-base: one mixed addition per (generator, window) + the
@@ -596,15 +760,17 @@ def main():
         fp_var = nb * ((nvar - 3) * (7 + 60) * 11 + ((nvar + 3) // 4) * 310 + 252 * 9 + 64 * 16)
         fp_fixed = nb * ((nterms - nvar) * W * 11 + 15 * 16)
         valu = None
-        if pmc and nb == 1024 and a.window_bits == 20:
+        if pmc_ok:
             instr = pmc["valu_wave_instr_per_step_1024"]
             valu = {"bound": "VALU issue slots (mix-weighted)", "achieved": instr / step_s, "peak": VALU_ISSUE_PEAK_MIX,
                     "unit": "wave-instr/s", "frac": instr / step_s / VALU_ISSUE_PEAK_MIX,
                     "valu_wave_instr_per_step": instr, "measured_on_lib_sha256_16": pmc.get("lib_sha256_16"),
                     "this_lib_sha256_16": lib_hash, "binary_matches": pmc.get("lib_sha256_16") == lib_hash,
-                    "note": "instructions per step: rocprofv3 --pmc SQ_INSTS_VALU of a solo run (" + pmc.get("source", "profiles/") +
+                    "per_kernel_solo": per_kernel,
+                    "note": "THE BINDING ROOFLINE.  instructions per step: rocprofv3 --pmc SQ_INSTS_VALU of a solo run (" + pmc.get("source", "profiles/") +
                             "); peak = 1024 SIMDs x 2.4 GHz / 4.25 cycles per wave64 instruction, the issue rate of THIS instruction "
-                            "mix (74 % v_mad_i64_i32) in the doubling / addition micro-benchmarks"}
+                            "mix (74 % v_mad_i64_i32) in the doubling / addition micro-benchmarks; per_kernel_solo: each kernel alone, against "
+                            "the SIMDs its waves occupy"}
         out = {
             "metric": "range-proof verifications/sec (64-bit, m=1)",
             "value": world * nb * a.steps / dt, "unit": "verifications/s", "n_gpus": world, "steps": a.steps,
@@ -613,24 +779,26 @@ def main():
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs),
-                       "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "untimed_before_the_timed_region": f"max(warmup, steps_in_flight) steps, result check, {warm_s:.1f} s of further untimed "
-                                                          "steps (clocks, event pools), one hand-over step per context"},
+                                                          "steps (clocks), one hand-over step per context"},
             "roofline": roof,
+            "roofline_valu_issue": valu,
             "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "variable-base + fixed-base halves of one step's mega_check MSMs / wall time per step",
                              "achieved": (fp_var + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
                              "frac": (fp_var + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS},
-            "roofline_valu_issue": valu,
-            "kernel_ms_per_launch": {n_: (v[0] / v[1]) for n_, v in prof.items() if v[1]},
-            "kernel_launches_timed": {n_: v[1] for n_, v in prof.items() if v[1]},
+            "kernel_solo_ms": ({n_: v[0] for n_, v in solo.items()} if solo else None),
+            "pipelined_replay": replay,
             "cpu_baseline": cpu,
             "cpu_baseline_1t": cpu1,
-            "single_batch": single,
             "h2d_inclusive": h2d,
+            "one_call": one_call,
+            "single_batch": single,
             "with_device_transcript": fs,
             "from_wire_format": wire,
             "combined_batch_check": comb,
             "r1cs_prove": prove,
+            "shuffle_2e14": shuffle,
             "range_prove": ({"value": nb / wl["prove_seconds"], "unit": "64-bit range proofs/s", "ms_per_batch": wl["prove_seconds"] * 1e3,
                              "note": f"the {nb} proofs of this workload, proved in lock-step by the GPU prover while it was generated "
                                      "(wall clock incl. host circuit building and transcripts)"} if wl.get("prove_seconds") else None),

@@ -66,7 +66,9 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
 #define BPGPU_OPT_VS_LARGE_MIN 7           /* padded n / m from which the verifier's scalar assembly is split over the grid (default 4096) */
 #define BPGPU_OPT_TABLE_NP 8               /* proof points per table lane of the window-parallel chain: 1, 2, 4, 8; 0 = by latency mode */
 #define BPGPU_OPT_IPP_TABLE_MAX_N 9        /* bpgpu_ipp_begin builds per-session generator tables up to this n (default 2^16), literal schedule above */
-#define BPGPU_OPT_COUNT 10
+#define BPGPU_OPT_STREAM_LANES 10          /* lanes (streams + workspaces) a bpgpu_r1cs_verify_stream call spreads its batches over, 1..64 (default 20) */
+#define BPGPU_OPT_STREAM_BATCH 11          /* proofs per batch of a bpgpu_r1cs_verify_stream call (default 1024) */
+#define BPGPU_OPT_COUNT 12
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
 int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);
 /* synchronise and report whether an operand of the `_dev` (device-resident, asynchronous) calls issued since the last read -- or
@@ -84,10 +86,20 @@ int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad);
  * since the last read (at most 64 launches per kind are kept between two reads).  select() restricts the timing to the
  * kinds of a bit mask (bit k = kind k; default all): an event pair is a barrier in the queue on either side of its kernel,
  * so a caller that wants one kernel's duration out of a pipelined run pays for that kernel only. */
-#define BPGPU_PROF_KINDS 16
+#define BPGPU_PROF_KINDS 24
+/* Kinds 16..21 cover the prover (one pair per device phase of a call, i.e. from its first to its last launch): 16 phase commitments
+ * (bpgpu_r1cs_prover_commit), 17 polynomial build, 18 bpgpu_msm_gens (T commitments), 19 IPP session set-up, 20 the IPP round
+ * loop, 21 the L / R table-lookup MSM of one round (the prover's dominant kernel, nested inside 20). */
 int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
 int bpgpu_profile_select(bpgpu_ctx *ctx, uint32_t kind_mask);
 int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t launches[BPGPU_PROF_KINDS]);
+/* The same measurements as intervals: bpgpu_profile_epoch records (and waits for) a reference event on ctx's stream and returns
+ * its handle (owned by ctx, valid until bpgpu_destroy; NULL on failure); bpgpu_profile_intervals returns every timed launch since
+ * the last read -- kind, start and end in milliseconds relative to the epoch of ANY context of the same device -- up to `cap`
+ * entries, instead of bpgpu_profile_read's sums.  The union of the intervals of all contexts is the time the GPU was busy:
+ * sums of overlapping launches exceed the wall clock, their union cannot. */
+void *bpgpu_profile_epoch(bpgpu_ctx *ctx);
+int bpgpu_profile_intervals(bpgpu_ctx *ctx, void *epoch, size_t cap, int32_t *kind, double *start_ms, double *end_ms, size_t *count);
 
 /* device memory plumbing */
 int bpgpu_malloc(bpgpu_ctx *ctx, size_t bytes, void **dptr);
@@ -337,6 +349,22 @@ int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
                                 size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
                                 const void *challenges_dev, void *ok_dev, void *mega_dev,
                                 void *msm_scalars_dev);
+
+/* A STREAM of batches in ONE call on ONE context: the same per-proof verification for any number of proofs of one circuit.  The
+ * library cuts them into batches of BPGPU_OPT_STREAM_BATCH proofs (1024) that take turns on a ring of BPGPU_OPT_STREAM_LANES (20)
+ * internal streams + workspaces, so that the kernel chains of ~20 batches overlap on the GPU -- the pipelined rate (4 M
+ * verifications/s for the 64-bit range gadget) without the caller creating contexts or exporting GPU_MAX_HW_QUEUES (libbpgpu.so
+ * sets it to 24 when it is loaded, unless the process has set it; a process that has initialised HIP before loading the library
+ * keeps the runtime's 4 queues and about a third of the rate).  This is what a Rust host's loop of Verifier::verify
+ * (verifier.rs:393) becomes: collect the proofs of one circuit, one call.
+ *   _dev : operands and ok[] resident in HBM (layouts of bpgpu_r1cs_verify_batch); asynchronous -- the lanes fork from the
+ *          context's stream and are joined back into it: bpgpu_sync, or the next call on this context, waits for all of them.
+ *   host : operands and ok[] in host memory (page-locked from bpgpu_host_alloc for DMA speed): each batch's upload, kernels and
+ *          verdict download run on its lane, so the copies of one batch overlap the kernels of the others; returns when done. */
+int bpgpu_r1cs_verify_stream_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                 const void *points_dev, const void *scalars_dev, const void *challenges_dev, void *ok_dev);
+int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                             const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, int32_t *ok);
 
 /* The same with the Fiat-Shamir transcript replayed ON THE DEVICE for circuits without
  * randomized constraints: instead of challenges the caller passes, per proof, the 32-byte hash-chain state it

@@ -39,12 +39,17 @@ struct bpgpu_ctx {
   int64_t opt[BPGPU_OPT_COUNT] = {};
   std::vector<hipEvent_t> prof_ev[BPGPU_PROF_KINDS];
   std::vector<hipEvent_t> prof_pool;   // recycled events
+  std::vector<hipEvent_t> prof_epochs; // reference events handed out by bpgpu_profile_epoch (alive as long as the context)
   bool prof_skip[BPGPU_PROF_KINDS] = {};
   uint32_t prof_mask = 0xffffffffu;    // bpgpu_profile_select
   // Device buffers of the prover / IPP sessions, recycled between sessions: hipFree waits for the WHOLE device to idle, which
   // serialises two contexts that pipeline batches (one host thread each), and a session is a dozen allocations.
   struct PoolBlk { void *p; size_t cap; bool used; };
   std::vector<PoolBlk> pool;
+  // bpgpu_r1cs_verify_stream: the ring of lanes (child contexts: one stream + workspaces each) this context spreads the batches
+  // of one call over; created on first use, owned by the parent
+  std::vector<bpgpu_ctx *> lanes;
+  hipEvent_t lane_ev = nullptr;   // fork / join marker of a stream call
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
@@ -54,7 +59,7 @@ struct ProfScope {   // records start/stop events on `st` around a launch when p
   // start and stop marks of a kind alternate (scopes of one kind do not nest).  At most PROF_CAP timed launches per kind are
   // kept between two reads: a long run samples its first launches instead of creating thousands of events inside the timed
   // region (2 048 steps: 1 200 hipEventCreate calls on the sampled context cost the run 5 % of its throughput).
-  static constexpr size_t PROF_CAP = 64;
+  static constexpr size_t PROF_CAP = 256;
   static void mark(bpgpu_ctx *c, int kind, hipStream_t st) {
     auto &v = c->prof_ev[kind];
     if (!((c->prof_mask >> kind) & 1u)) return;
@@ -68,6 +73,14 @@ struct ProfScope {   // records start/stop events on `st` around a launch when p
   }
   ProfScope(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_) { if (c->prof) mark(c, kind, st); }
   ~ProfScope() { if (c->prof) mark(c, kind, st); }
+};
+// the same with an explicit end: entry points that wait for their results close the span BEFORE the host-side wait (error paths
+// close it on the way out)
+struct ProfSpan {
+  bpgpu_ctx *c; int kind; hipStream_t st; bool open;
+  ProfSpan(bpgpu_ctx *c_, int kind_, hipStream_t st_) : c(c_), kind(kind_), st(st_), open(c_->prof) { if (open) ProfScope::mark(c, kind, st); }
+  void close() { if (open) { ProfScope::mark(c, kind, st); open = false; } }
+  ~ProfSpan() { close(); }
 };
 static void prof_mark_cb(void *c, int kind, hipStream_t st) { ProfScope::mark((bpgpu_ctx *)c, kind, st); }
 struct bpgpu_gens {
@@ -235,7 +248,19 @@ const char *bpgpu_strerror(int code) {
     default: return "unknown";
   }
 }
+// The pipelined entry points keep ~20 kernels' worth of independent batches in flight, one stream each; the HIP runtime maps
+// streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default: everything beyond serialises).  The runtime reads the variable
+// when it initialises, so it is set here, when the library is loaded, unless the host process has chosen a value itself.
+__attribute__((constructor)) static void bpgpu_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+
+static int ctx_create(int device, bool single_stream, bpgpu_ctx **out);
 int bpgpu_create(int device, bpgpu_ctx **out) {
+  // BPGPU_SINGLE_STREAM=1: one stream per context (deeply pipelined callers overlap ACROSS contexts and
+  // hardware queues are a limited resource: GPU_MAX_HW_QUEUES)
+  const bool single = getenv("BPGPU_SINGLE_STREAM") && atoi(getenv("BPGPU_SINGLE_STREAM")) != 0;
+  return ctx_create(device, single, out);
+}
+static int ctx_create(int device, bool single, bpgpu_ctx **out) {
   if (!out) return BPGPU_E_ARG;
   *out = nullptr;
   int n = 0;
@@ -249,12 +274,10 @@ int bpgpu_create(int device, bpgpu_ctx **out) {
         {BPGPU_OPT_VERIFY_NO_FUSE, "BPGPU_NO_FUSE", 0},               {BPGPU_OPT_VERIFY_WINDOW_PARALLEL, "BPGPU_WINDOW_PARALLEL", 1},
         {BPGPU_OPT_VERIFY_STRAUS_NP, "BPGPU_STRAUS_NP", 4},           {BPGPU_OPT_IPP_LITERAL, "BPGPU_IPP_LITERAL", 0},
         {BPGPU_OPT_VS_LARGE_MIN, "BPGPU_VS_LARGE_MIN", 4096},         {BPGPU_OPT_TABLE_NP, "BPGPU_TABLE_NP", 0},
-        {BPGPU_OPT_IPP_TABLE_MAX_N, "BPGPU_IPP_TABLE_MAX_N", (int64_t)1 << 16}};
+        {BPGPU_OPT_IPP_TABLE_MAX_N, "BPGPU_IPP_TABLE_MAX_N", (int64_t)1 << 16},
+        {BPGPU_OPT_STREAM_LANES, "BPGPU_STREAM_LANES", 20},           {BPGPU_OPT_STREAM_BATCH, "BPGPU_STREAM_BATCH", 1024}};
     for (auto &s : seed) { const char *e = getenv(s.env); ctx->opt[s.opt] = e ? atoll(e) : s.dflt; }
   }
-  // BPGPU_SINGLE_STREAM=1: one stream per context (deeply pipelined callers overlap ACROSS contexts and
-  // hardware queues are a limited resource: GPU_MAX_HW_QUEUES, 4 by default)
-  const bool single = getenv("BPGPU_SINGLE_STREAM") && atoi(getenv("BPGPU_SINGLE_STREAM")) != 0;
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
       (single ? ((ctx->st2 = ctx->st), hipSuccess) : hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking)) != hipSuccess ||
       hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
@@ -268,6 +291,9 @@ int bpgpu_create(int device, bpgpu_ctx **out) {
 }
 void bpgpu_destroy(bpgpu_ctx *ctx) {
   if (!ctx) return;
+  for (auto *l : ctx->lanes) bpgpu_destroy(l);
+  ctx->lanes.clear();
+  if (ctx->lane_ev) hipEventDestroy(ctx->lane_ev);
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->st);
   hipStreamSynchronize(ctx->st2);
@@ -280,6 +306,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   hipEventDestroy(ctx->ev2);
   for (auto &v : ctx->prof_ev) for (auto e : v) hipEventDestroy(e);
   for (auto e : ctx->prof_pool) hipEventDestroy(e);
+  for (auto e : ctx->prof_epochs) hipEventDestroy(e);
   if (ctx->st2 != ctx->st) hipStreamDestroy(ctx->st2);
   hipStreamDestroy(ctx->st);
   delete ctx;
@@ -287,7 +314,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
 const char *bpgpu_last_error(bpgpu_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
 int bpgpu_sync(bpgpu_ctx *ctx) {
   if (!ctx) return BPGPU_E_ARG;
-  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));      // (a stream call joins its lanes into ctx->st before it returns)
   HIPCK(ctx, hipStreamSynchronize(ctx->st2));
   return BPGPU_OK;
 }
@@ -306,6 +333,8 @@ int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value) {
     case BPGPU_OPT_VS_LARGE_MIN: if (value < 1) return BPGPU_E_ARG; break;
     case BPGPU_OPT_TABLE_NP: if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return BPGPU_E_ARG; break;
     case BPGPU_OPT_IPP_TABLE_MAX_N: if (value < 0) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_STREAM_LANES: if (value < 1 || value > 64) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_STREAM_BATCH: if (value < 1 || value > ((int64_t)1 << 20)) return BPGPU_E_ARG; break;
     default: if (value != 0 && value != 1) return BPGPU_E_ARG; break;
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -337,17 +366,59 @@ int bpgpu_profile_read(bpgpu_ctx *ctx, double ms_sum[BPGPU_PROF_KINDS], uint64_t
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   HIPCK(ctx, hipStreamSynchronize(ctx->st2));
-  for (int k = 0; k < BPGPU_PROF_KINDS; k++) {
-    ms_sum[k] = 0;
-    launches[k] = 0;
-    auto &v = ctx->prof_ev[k];
-    for (size_t i = 0; i + 1 < v.size(); i += 2) {
-      float ms = 0;
-      if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) { ms_sum[k] += ms; launches[k]++; }
+  for (int k = 0; k < BPGPU_PROF_KINDS; k++) { ms_sum[k] = 0; launches[k] = 0; }
+  std::vector<bpgpu_ctx *> all{ctx};
+  all.insert(all.end(), ctx->lanes.begin(), ctx->lanes.end());     // the lanes of a stream call report through their parent
+  for (bpgpu_ctx *c : all) {
+    if (c != ctx) HIPCK(ctx, hipStreamSynchronize(c->st));
+    for (int k = 0; k < BPGPU_PROF_KINDS; k++) {
+      auto &v = c->prof_ev[k];
+      for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, v[i], v[i + 1]) == hipSuccess) { ms_sum[k] += ms; launches[k]++; }
+      }
+      for (auto e : v) c->prof_pool.push_back(e);
+      v.clear();
     }
-    for (auto e : v) ctx->prof_pool.push_back(e);
-    v.clear();
   }
+  return BPGPU_OK;
+}
+// Timed intervals instead of sums: every (start, stop) pair recorded since the last read, in milliseconds relative to `epoch`
+// (bpgpu_profile_epoch of ANY context of this device), so that a caller can take the union over kernels, kinds and contexts --
+// the time the GPU was busy -- which sums of overlapping launches cannot give.
+void *bpgpu_profile_epoch(bpgpu_ctx *ctx) {
+  if (!ctx) return nullptr;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  hipEvent_t e = nullptr;
+  if (hipSetDevice(ctx->device) != hipSuccess || hipEventCreate(&e) != hipSuccess) return nullptr;
+  if (hipEventRecord(e, ctx->st) != hipSuccess || hipEventSynchronize(e) != hipSuccess) { hipEventDestroy(e); return nullptr; }
+  try { ctx->prof_epochs.push_back(e); } catch (const std::bad_alloc &) { hipEventDestroy(e); return nullptr; }
+  return (void *)e;                  // owned by the context: valid as a reference until bpgpu_destroy
+}
+int bpgpu_profile_intervals(bpgpu_ctx *ctx, void *epoch, size_t cap, int32_t *kind, double *start_ms, double *end_ms, size_t *count) {
+  if (!ctx || !epoch || !count || (cap && (!kind || !start_ms || !end_ms))) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st2));
+  size_t n = 0;
+  std::vector<bpgpu_ctx *> all{ctx};
+  all.insert(all.end(), ctx->lanes.begin(), ctx->lanes.end());
+  for (bpgpu_ctx *c : all) {
+    if (c != ctx) HIPCK(ctx, hipStreamSynchronize(c->st));
+    for (int k = 0; k < BPGPU_PROF_KINDS; k++) {
+      auto &v = c->prof_ev[k];
+      for (size_t i = 0; i + 1 < v.size(); i += 2) {
+        float a = 0, b = 0;
+        if (n < cap && hipEventElapsedTime(&a, (hipEvent_t)epoch, v[i]) == hipSuccess &&
+            hipEventElapsedTime(&b, (hipEvent_t)epoch, v[i + 1]) == hipSuccess) {
+          kind[n] = k; start_ms[n] = a; end_ms[n] = b; n++;
+        }
+      }
+      for (auto e : v) c->prof_pool.push_back(e);
+      v.clear();
+    }
+  }
+  *count = n;
   return BPGPU_OK;
 }
 int bpgpu_input_flag(bpgpu_ctx *ctx, int *bad) {
@@ -918,10 +989,12 @@ static int msm_gens_impl(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t 
   CK(ws_get(ctx, 5, nb * 64, &dout));
   CK(flag_reset(ctx));
   CK(h2d(ctx, dsc, scalars, tot * 32));
+  ProfSpan span(ctx, 18, ctx->st);
   if (ark) scalars_from_ark(ctx->st, (const Words8 *)dsc, (Words8 *)dsc, tot, ctx->d_flag);
   else scalars_check(ctx->st, (Words8 *)dsc, tot, ctx->d_flag);
   CK(msm_gens_dev(ctx, g, nb, n, (uint32_t *)dsc, (JacRaw *)dres, ctx->st));
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb);
+  span.close();
   CK(launch_ok(ctx));
   int bad = 0;
   CK(flag_read(ctx, &bad));
@@ -1318,6 +1391,74 @@ int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   return BPGPU_OK;
 }
 
+/* A STREAM of verification batches in one call: the proofs are cut into batches of `batch` proofs (default 1024) that take turns
+ * on the context's ring of lanes (child contexts: a stream and a set of workspaces each), so that the six-launch chains of
+ * ~20 batches overlap on the GPU -- what a caller otherwise builds out of twenty contexts.  The lanes fork from ctx->st (inputs
+ * uploaded asynchronously on it are visible) and are joined back into it. */
+static int stream_lanes(bpgpu_ctx *ctx, size_t want) {
+  if (!ctx->lane_ev) HIPCK(ctx, hipEventCreateWithFlags(&ctx->lane_ev, hipEventDisableTiming));
+  while (ctx->lanes.size() < want) {
+    bpgpu_ctx *l = nullptr;
+    int rc = ctx_create(ctx->device, true, &l);
+    if (rc) return rc;
+    try { ctx->lanes.push_back(l); } catch (const std::bad_alloc &) { bpgpu_destroy(l); return BPGPU_E_OOM; }
+  }
+  for (bpgpu_ctx *l : ctx->lanes) {   // the lanes follow their parent's settings
+    for (int i = 0; i < BPGPU_OPT_COUNT; i++) l->opt[i] = ctx->opt[i];
+    l->latency_mode = false;          // (a stream call is the pipelined case by definition)
+    l->prof = ctx->prof; l->prof_mask = ctx->prof_mask;
+  }
+  return BPGPU_OK;
+}
+static int verify_stream_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, uint8_t *ok, bool on_host) {
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t batch = (size_t)ctx->opt[BPGPU_OPT_STREAM_BATCH], nlanes_opt = (size_t)ctx->opt[BPGPU_OPT_STREAM_LANES];
+  const size_t nchunks = (nb + batch - 1) / batch, nl = nchunks < nlanes_opt ? nchunks : nlanes_opt;
+  CK(stream_lanes(ctx, nl));
+  const size_t m = c->m, nvar = 11 + m + 2 * k, nch = 6 + k;
+  HIPCK(ctx, hipEventRecord(ctx->lane_ev, ctx->st));
+  for (size_t l = 0; l < nl; l++) HIPCK(ctx, hipStreamWaitEvent(ctx->lanes[l]->st, ctx->lane_ev, 0));
+  for (size_t ci = 0; ci < nchunks; ci++) {
+    bpgpu_ctx *ln = ctx->lanes[ci % nl];
+    const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
+    const uint8_t *P = points + lo * nvar * 64, *S = scalars + lo * 5 * 32, *Cc = challenges + lo * nch * 32;
+    uint8_t *O = ok + lo * 4;
+    int rc;
+    if (on_host) {       // operands and verdicts in (ideally page-locked) host memory: staged through the lane's own buffers
+      void *dP, *dS, *dC, *dok;
+      if ((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) ||
+          (rc = ws_get(ln, 2, batch * nch * 32, &dC)) || (rc = ws_get(ln, 3, batch * 4, &dok))) { ctx->err = ln->err; return rc; }
+      if ((rc = h2d(ln, dP, P, cnt * nvar * 64)) || (rc = h2d(ln, dS, S, cnt * 5 * 32)) || (rc = h2d(ln, dC, Cc, cnt * nch * 32)) ||
+          (rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, dP, dS, dC, dok, nullptr, nullptr)) ||
+          (rc = d2h(ln, O, dok, cnt * 4))) { ctx->err = ln->err; return rc; }
+    } else if ((rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, O, nullptr, nullptr))) { ctx->err = ln->err; return rc; }
+  }
+  for (size_t l = 0; l < nl; l++) {    // join: ctx->st (and with it bpgpu_sync / the caller's next call) waits for every lane
+    HIPCK(ctx, hipEventRecord(ctx->lanes[l]->ev1, ctx->lanes[l]->st));
+    HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->lanes[l]->ev1, 0));
+  }
+  return BPGPU_OK;
+}
+int bpgpu_r1cs_verify_stream_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                 const void *points_dev, const void *scalars_dev, const void *challenges_dev, void *ok_dev) {
+  if (!ctx || !g || !c || (nb && (!points_dev || !scalars_dev || !challenges_dev || !ok_dev))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_stream_locked(ctx, g, c, nb, n1, k, (const uint8_t *)points_dev, (const uint8_t *)scalars_dev,
+                              (const uint8_t *)challenges_dev, (uint8_t *)ok_dev, false);
+}
+int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                             const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, int32_t *ok) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  CK(verify_stream_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, (uint8_t *)ok, true));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
 
 /* ---------------------------------------------------------------- Verifier::verify with the transcript on the device */
 static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
@@ -1774,6 +1915,7 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
       size_t chunks = fixed_msm_ipp_chunks(s->gens->c, s->n0, nb * 2);
       void *dpart = nullptr;
       if (chunks > 1) CK(ws_get(ctx, 12, nb * 2 * chunks * sizeof(JacRaw), &dpart));
+      ProfScope ps(ctx, 21, st);
       fixed_msm_ipp(st, s->gens->c, s->gens->table, s->n0, s->gens->cap, n, (const uint32_t *)s->msc, s->sums, nb * 2, (JacRaw *)dpart);
     }
     jac_to_boundary(st, s->sums, out_xy, nb * 2);
@@ -1920,6 +2062,7 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
   CK(ws_get(ctx, 18, 4, &dzero));
   CK(h2d(ctx, dstates, states_in, nb * 32));
   Words8 *du = s->uu, *dui = s->uu + nb;
+  ProfSpan span(ctx, 20, ctx->st);
   for (size_t r = 0; r < k; r++) {
     Words8 *lr = (Words8 *)dlr + r * nb * 4;             // 2 points x 2 Words8 per proof
     CK(ipp_round_dev(ctx, s, lr));
@@ -1928,6 +2071,7 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
     batch_inverse(ctx->st, dui, nb, (int *)dzero);       // challenges are non-zero up to 2^-252
     CK(ipp_fold_dev(ctx, s, du, dui));
   }
+  span.close();
   std::vector<uint8_t> tmp(k * nb * 128);
   if (k) CK(d2h(ctx, tmp.data(), dlr, k * nb * 128));
   CK(d2h(ctx, a_out, s->a[s->cur], nb * 32));
@@ -2112,10 +2256,12 @@ int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_ge
     if ((rc = h2d(ctx, dx, x, nb * 32)) || (rc = h2d(ctx, du, u, nb * 32)) || (rc = h2d(ctx, s->w, w, nb * 32))) break;
     if (y_inv) { if ((rc = h2d(ctx, dyi, y_inv, nb * 32))) break; }
     else if (hipMemcpyAsync(dyi, ps->yinv, nb * 32, hipMemcpyDeviceToDevice, ctx->st) != hipSuccess) { rc = BPGPU_E_DEVICE; break; }
+    ProfSpan span(ctx, 19, ctx->st);
     scalars_check(ctx->st, dx, 3 * nb, ctx->d_flag);
     scalars_check(ctx->st, s->w, nb, ctx->d_flag);
     prover_eval(ctx->st, nb, ps->n, n, dx, ps->y, ps->polys, s->a[0], s->b[0]);
     ipp_r1cs_factors(ctx->st, nb, n, n1, du, dyi, s->cG, s->cH);
+    span.close();
     if ((rc = launch_ok(ctx))) break;
     int bad = 0;
     if ((rc = flag_read(ctx, &bad))) break;
@@ -2184,6 +2330,7 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
   for (size_t i = 0; i < nvec && n_new; i++) if ((rc = h2d(ctx, w + i * tot_new, src[i], tot_new * 32))) return fail(rc);
   if ((rc = h2d(ctx, dbl, blindings, nb * 3 * 32))) return fail(rc);
   if (n_new && !explicit_vec && (rc = h2d(ctx, dkeys, vector_keys, nb * 32))) return fail(rc);
+  ProfSpan span(ctx, 16, ctx->st);
   if (n_new) {
     if (wn0 == 0) {          // contiguous planes: convert straight into them
       for (size_t i = 0; i < nvec; i++) scalars_from_ark(ctx->st, w + i * tot_new, *old[i], tot_new, ctx->d_flag);
@@ -2199,6 +2346,7 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
   commit_rows(ctx->st, nb, wn, wn0, wn, s->aL, s->aR, s->aO, s->sL, s->sR, dbl, (Words8 *)drows);
   if ((rc = msm_gens_dev(ctx, g, nb * 3, wn, (const uint32_t *)drows, (JacRaw *)dres, ctx->st))) return fail(rc);
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb * 3);
+  span.close();
   if ((rc = launch_ok(ctx))) return fail(rc);
   int bad = 0;
   if ((rc = flag_read(ctx, &bad))) return fail(rc);
@@ -2233,11 +2381,13 @@ int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu
   CK(h2d(ctx, dz, z, nb * 32));
   scalars_check(ctx->st, s->y, nb, ctx->d_flag);
   scalars_check(ctx->st, dz, nb, ctx->d_flag);
+  ProfSpan span(ctx, 17, ctx->st);
   HIPCK(ctx, hipMemcpyAsync(s->yinv, s->y, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
   batch_inverse(ctx->st, s->yinv, nb, ctx->d_flag);       // y^-1, prover.rs:593 (a zero challenge raises the flag: E_ARG)
   zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);
   prover_polys(ctx->st, circuit_dev(c), nb, s->y, s->yinv, s->aL, s->aR, s->aO, s->sL, s->sR, (const int32_t *)dzp, s->polys, dwV);
   prover_tcoeffs(ctx->st, nb, n, s->polys, dt);
+  span.close();
   CK(launch_ok(ctx));
   int bad = 0;
   CK(flag_read(ctx, &bad));

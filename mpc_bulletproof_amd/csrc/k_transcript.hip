@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64) k_ipp_round_challenge(size_t nb, uint64_t 
 // 512 bits per scalar: the reduction mod n is unbiased to 2^-260 (four words per scalar, as the host RNG draws them, leave a
 // 3 % bump on the low part of the range).  One lane per (prover, vector, block): 2 x 256 x 512 independent permutations for 256
 // provers of 1024 multipliers instead of 525 000 wide reductions and 34 MB of staging on the host.  The CPU oracle restates the
-// same stream (oracle/bpo_r1cs.c: blind_vector), so proofs made this way are replayable under the test RNG.
+// same stream (blind_vector in its transcript file), so proofs made this way are replayable under the test RNG.
 __global__ void __launch_bounds__(64) k_blind_vectors(const Words8 *keys, size_t nb, size_t cnt, Words8 *sL, Words8 *sR, size_t stride,
                                                       size_t off) {
   const size_t blocks = (cnt + 1) / 2;

@@ -7,13 +7,13 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_set_option", "bpgpu_get_option", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
+    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_set_option", "bpgpu_get_option", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_profile_epoch", "bpgpu_profile_intervals", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy", "bpgpu_r1cs_prover_commit", "bpgpu_r1cs_prover_session_polys",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_ark", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
-    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_combined",
+    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_stream", "bpgpu_r1cs_verify_stream_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
     "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev", "bpgpu_r1cs_verify_batch_param", "bpgpu_r1cs_verify_batch_fs2",
     "bpgpu_r1cs_verify_batch_fs2_dev",
@@ -61,11 +61,12 @@ def host_free(p):
 E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
 # bpgpu_set_option (include/bpgpu.h BPGPU_OPT_*)
 OPT = {"msm_wp_max": 1, "msm_pip2_single": 2, "verify_no_fuse": 3, "verify_window_parallel": 4, "verify_straus_np": 5,
-       "ipp_literal": 6, "vs_large_min": 7, "table_np": 8, "ipp_table_max_n": 9}
+       "ipp_literal": 6, "vs_large_min": 7, "table_np": 8, "ipp_table_max_n": 9, "stream_lanes": 10, "stream_batch": 11}
 # bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
 PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
               "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_front_scalars_digits",
-              "combined_sort_accum_reduce", "combined_unused", "combined_final"]
+              "combined_sort_accum_reduce", "combined_unused", "combined_final", "prover_commit", "prover_polys", "msm_gens", "ipp_begin",
+              "ipp_rounds", "ipp_round_msm", "reserved22", "reserved23"]
 PROF_KINDS = len(PROF_NAMES)
 
 
@@ -185,6 +186,20 @@ class BpGpu:
         cnt = (C.c_uint64 * PROF_KINDS)()
         self._ck(_lib.bpgpu_profile_read(self.ctx, ms, cnt))
         return {n: (ms[i], int(cnt[i])) for i, n in enumerate(PROF_NAMES)}
+
+    def profile_epoch(self):
+        """reference event for profile_intervals (of any context of this device); owned by the context"""
+        _lib.bpgpu_profile_epoch.restype = C.c_void_p
+        e = _lib.bpgpu_profile_epoch(self.ctx)
+        if not e:
+            raise BpGpuError(E_DEVICE, "bpgpu_profile_epoch")
+        return C.c_void_p(e)
+
+    def profile_intervals(self, epoch, cap=8192):
+        """-> [(kind name, start ms, end ms)] of every timed launch since the last read, relative to `epoch`"""
+        kind, a, b, n = (C.c_int32 * cap)(), (C.c_double * cap)(), (C.c_double * cap)(), C.c_size_t(0)
+        self._ck(_lib.bpgpu_profile_intervals(self.ctx, epoch, C.c_size_t(cap), kind, a, b, C.byref(n)))
+        return [(PROF_NAMES[kind[i]], a[i], b[i]) for i in range(n.value)]
 
     # ---- scalar field
     def batch_inverse(self, scalars):
@@ -521,6 +536,19 @@ class BpGpu:
     def r1cs_verify_combined_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_rho, d_out):
         self._ck(_lib.bpgpu_r1cs_verify_combined_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                      d_points, d_scalars, d_challenges, d_rho, d_out))
+
+    def r1cs_verify_stream_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_ok):
+        """any number of proofs in one call: batches over the context's ring of lanes (asynchronous; sync() waits for all)"""
+        self._ck(_lib.bpgpu_r1cs_verify_stream_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                   d_points, d_scalars, d_challenges, d_ok))
+
+    def r1cs_verify_stream(self, gens, circuit, nb, n1, k, m, points, scalars, challenges):
+        """the same from host memory (bytes, or c_void_p of page-locked memory for all three operands) -> [ok]"""
+        ok = (C.c_int32 * max(nb, 1))()
+        wrap = lambda b: b if isinstance(b, C.c_void_p) else _buf(b)     # noqa: E731
+        self._ck(_lib.bpgpu_r1cs_verify_stream(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                               wrap(points), wrap(scalars), wrap(challenges), ok))
+        return list(ok)[:nb]
 
     def r1cs_verify_batch_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_ok, d_mega=None,
                               d_full=None):

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <atomic>
 #include <map>
 #include <memory>
@@ -232,9 +233,12 @@ int bph_range_prove_batch(size_t nb, size_t nvals, size_t n_bits, const uint8_t 
 // timed region is the stream of prove_batch calls incl. dropping the provers (Prover::prove consumes self); prebuild = 0: circuit
 // building and commitments are inside the timed region too.  proofs_out: nbatch x nb x proof_len; commitments_out: nbatch x nb x
 // nvals x 64.  ms_out[0] = wall of the timed region, [1] = sum over batches of building, [2] = of prove_batch, [3] = of teardown.
-int bph_range_prove_stream(size_t nbatch, size_t threads, int prebuild, size_t nb, size_t nvals, size_t n_bits, const uint8_t *label,
+// profile = 1: HIP-event timing of the device phases on every worker's context (bpgpu_profile_*): ms_out[4] = GPU-busy time = the
+// union over all contexts of the phase intervals, [5] / [6] = summed duration / launches of the round MSM (the dominant kernel),
+// [7..11] = summed durations of the round loops, phase commitments, polynomial builds, T commitments, IPP set-ups.
+int bph_range_prove_stream(size_t nbatch, size_t threads, int prebuild, int profile, size_t nb, size_t nvals, size_t n_bits, const uint8_t *label,
                            size_t label_len, const uint64_t *values, uint64_t seed0, size_t gens_capacity, uint8_t *proofs_out,
-                           size_t *proof_len, uint8_t *commitments_out, double ms_out[4]) {
+                           size_t *proof_len, uint8_t *commitments_out, double ms_out[12]) {
   GUARD({
     if (!nbatch || !threads || !nb) return -3;
     PedersenGens pc_gens;
@@ -300,6 +304,12 @@ int bph_range_prove_stream(size_t nbatch, size_t threads, int prebuild, size_t n
     std::vector<std::unique_ptr<Device>> devs;
     for (size_t t = 0; t < threads; t++) devs.emplace_back(new Device(0));
     if (prebuild) for (size_t bi = 0; bi < nbatch; bi++) build(bi, *devs[0]);
+    void *epoch = nullptr;
+    if (profile) {
+      epoch = bpgpu_profile_epoch(devs[0]->ctx());
+      if (!epoch) return -10;
+      for (auto &dv : devs) bpgpu_profile_enable(dv->ctx(), 1);
+    }
     std::atomic<size_t> next{0};
     std::vector<std::exception_ptr> errs(threads);
     auto T0 = now();
@@ -320,6 +330,38 @@ int bph_range_prove_stream(size_t nbatch, size_t threads, int prebuild, size_t n
     for (auto &e : errs) if (e) std::rethrow_exception(e);
     ms_out[1] = ms_out[2] = ms_out[3] = 0;
     for (auto &B : batches) { ms_out[1] += B.ms_build; ms_out[2] += B.ms_prove; ms_out[3] += B.ms_drop; }
+    for (int i = 4; i < 12; i++) ms_out[i] = 0;
+    if (profile) {
+      std::vector<std::pair<double, double>> iv;
+      const size_t cap = 1 << 16;
+      std::vector<int32_t> kind(cap);
+      std::vector<double> a(cap), b(cap);
+      for (auto &dv : devs) {
+        size_t cnt = 0;
+        bpgpu_profile_enable(dv->ctx(), 0);
+        if (bpgpu_profile_intervals(dv->ctx(), epoch, cap, kind.data(), a.data(), b.data(), &cnt)) return -10;
+        for (size_t i = 0; i < cnt; i++) {
+          const double dt = b[i] - a[i];
+          switch (kind[i]) {
+            case 21: ms_out[5] += dt; ms_out[6] += 1; break;          // nested inside kind 20: not part of the union
+            case 20: ms_out[7] += dt; iv.emplace_back(a[i], b[i]); break;
+            case 16: ms_out[8] += dt; iv.emplace_back(a[i], b[i]); break;
+            case 17: ms_out[9] += dt; iv.emplace_back(a[i], b[i]); break;
+            case 18: ms_out[10] += dt; iv.emplace_back(a[i], b[i]); break;
+            case 19: ms_out[11] += dt; iv.emplace_back(a[i], b[i]); break;
+            default: iv.emplace_back(a[i], b[i]); break;
+          }
+        }
+      }
+      std::sort(iv.begin(), iv.end());
+      double busy = 0, cs_ = 0, ce = -1;
+      for (auto &x : iv) {
+        if (ce < 0 || x.first > ce) { if (ce >= 0) busy += ce - cs_; cs_ = x.first; ce = x.second; }
+        else if (x.second > ce) ce = x.second;
+      }
+      if (ce >= 0) busy += ce - cs_;
+      ms_out[4] = busy;
+    }
     return 0;
   })
 }

@@ -43,6 +43,9 @@ def test_product_never_references_the_oracle():
                 assert "liboracle" not in txt and "oracle/" not in txt.replace("oracle/ (tests/)", ""), os.path.join(dp, f)
 
 
+CPU_WORKERS = ("_cpu_verify_chunk", "_cpu_prove_chunk", "_cpu_check_proofs")   # bench.py: cpu_baseline legs + the oracle's verdict on GPU-made proofs
+
+
 def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
     """bench.py may touch oracle/ (through tests/oracle_lib.py) only inside its cpu_baseline worker; the workload,
     the timed GPU legs and the secondary measurements must come from the product path."""
@@ -53,10 +56,15 @@ def test_bench_uses_the_oracle_only_for_the_cpu_baseline():
     for node in ast.walk(tree):
         if isinstance(node, ast.FunctionDef):
             body = ast.get_source_segment(src, node)
-            if ("oracle_lib" in body or "pymodel" in body or "liboracle" in body) and node.name != "_cpu_verify_chunk":
+            if ("oracle_lib" in body or "pymodel" in body or "liboracle" in body) and node.name not in CPU_WORKERS:
                 offenders.append(node.name)
     assert offenders == [], offenders
     assert "import oracle_lib" not in src.split("def _cpu_verify_chunk")[0]
+    # the workers run in a fork pool created before the GPU is initialised, and only through pool.map
+    for w in CPU_WORKERS:
+        for m in re.finditer(r"\b%s\b" % w, src):
+            line = src[src.rfind("\n", 0, m.start()) + 1:src.find("\n", m.end())]
+            assert line.startswith("def " + w) or "pool.map(" + w in line, line
 
 
 def test_rust_sys_block_is_complete_and_in_step_with_the_header():

@@ -212,10 +212,10 @@ def test_prove_stream_over_worker_threads(host, prebuild, vkeys):
     proofs = (C.c_uint8 * (nbatch * nb * 8192))()
     plen = C.c_size_t(0)
     com = (C.c_uint8 * (nbatch * nb * nvals * 64))()
-    ms = (C.c_double * 4)()
+    ms = (C.c_double * 12)()
     host.bph_set_seeded_vector_keys(vkeys)
     try:
-        rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_size_t(nb), C.c_size_t(nvals),
+        rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_int(0), C.c_size_t(nb), C.c_size_t(nvals),
                                          C.c_size_t(n_bits), o._buf(label), C.c_size_t(len(label)), arr, C.c_uint64(700), C.c_size_t(cap),
                                          proofs, C.byref(plen), com, ms)
     finally:

@@ -449,6 +449,44 @@ def test_verify_single_dummy_circuit_proof(gpu, opts, lg, tnp):
         gpu.gens_destroy(g)
 
 
+@pytest.mark.parametrize("on_host", [False, True])
+def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
+    """bpgpu_r1cs_verify_stream(_dev): 150 proofs (three tampered) of the 8-bit range gadget in ONE call, cut into batches of 16
+    that take turns on three lanes: the verdicts equal the oracle's proof by proof; a second call on the same context reuses the
+    lanes; a following single-batch call on the parent context sees the same results (the lanes were joined)."""
+    nb, tamper = 150, {2, 77, 149}
+    opts(stream_batch=16, stream_lanes=3)
+    recs, cap = bh.make_range_batch(8, nb, tamper=tamper)
+    s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], recs[0][1], recs[0][0], cap)
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        pts = sc = ch = b""
+        for proof, com in recs:
+            s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap)
+            k, p, q = bh.verify_inputs(proof, com)
+            pts, sc, ch = pts + p, sc + q, ch + s.challenges()
+            s.close()
+        want = [0 if i in tamper else 1 for i in range(nb)]
+        for rep in range(2):
+            if on_host:
+                ok = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch)
+            else:
+                dp, ds, dc, dok = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch), gpu.malloc(4 * nb)
+                gpu.r1cs_verify_stream_dev(g, circ, nb, s0.n1, s0.k, dp, ds, dc, dok)
+                ok = [int.from_bytes(gpu.download(dok, 4 * nb)[4 * i:4 * i + 4], "little") for i in range(nb)]   # (download syncs the parent stream)
+                for d in (dp, ds, dc, dok):
+                    gpu.free(d)
+            assert ok == want, rep
+        ok1, _, _ = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
+        assert list(ok1) == want
+        assert gpu.r1cs_verify_stream(g, circ, 0, s0.n1, s0.k, s0.m, b"", b"", b"") == []
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s0.close()
+
+
 def test_options_setter_rejects_bad_values(gpu):
     import mpc_bulletproof_amd as m
     for name, bad in (("verify_straus_np", 5), ("table_np", 3), ("vs_large_min", 0), ("ipp_literal", 2), ("msm_wp_max", -1)):
@@ -1391,7 +1429,8 @@ def test_verify_batch_other_circuits_all_launch_variants(gpu, opts, kind, param,
 
 def test_profile_events_select_and_cap(gpu):
     """bpgpu_profile_enable / _select / _read (the HIP-event timing bench.py's roofline uses): with a kind mask only the selected
-    launches are timed; at most 64 launches per kind are kept between two reads; verdicts are unaffected."""
+    launches are timed; at most 256 launches per kind are kept between two reads; verdicts are unaffected.  bpgpu_profile_intervals
+    returns the same launches as (kind, start, end) relative to an epoch: ordered, non-negative, and inside the wall-clock window."""
     recs, cap = bh.make_range_batch(8, 70, tamper={3})
     sessions = [o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
     s0 = sessions[0]
@@ -1409,12 +1448,27 @@ def test_profile_events_select_and_cap(gpu):
         every = {n: c for n, (ms, c) in gpu.profile_read().items() if c}
         assert {"verify_front", "verify_scalars", "verify_windows", "verify_groups", "verify_back", "verify_verdict"} <= set(every)
         gpu.profile_select(["verify_back"])
-        for _ in range(70):
+        for _ in range(260):
             ok, _, _ = gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
         assert list(ok) == want
         only = {n: (ms, c) for n, (ms, c) in gpu.profile_read().items() if c}
-        assert set(only) == {"verify_back"} and only["verify_back"][1] == 64 and only["verify_back"][0] > 0
+        assert set(only) == {"verify_back"} and only["verify_back"][1] == 256 and only["verify_back"][0] > 0
         gpu.profile_select(None)
+        import time
+        epoch = gpu.profile_epoch()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            gpu.r1cs_verify_batch(g, circ, 70, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
+        wall_ms = (time.perf_counter() - t0) * 1e3
+        iv = gpu.profile_intervals(epoch)
+        six = ["verify_front", "verify_scalars", "verify_windows", "verify_groups", "verify_back", "verify_verdict"]
+        iv = [x for x in iv if x[0] != "fixed_msm"]                      # (the generator half as its own launch, when it does not ride in `back`)
+        assert len(iv) == 18 and {n for n, _, _ in iv} == set(six)
+        assert all(0 <= a <= b <= wall_ms + 1 for _, a, b in iv)
+        chain = sorted((a, b, n) for n, a, b in iv)[:6]                  # the first batch's six launches, in stream order
+        assert [n for _, _, n in chain] == six
+        assert all(chain[i][1] <= chain[i + 1][0] + 1e-3 for i in range(5))
+        assert gpu.profile_intervals(epoch) == []                       # read-and-clear
     finally:
         gpu.profile_enable(False)
         gpu.gens_destroy(g)
