@@ -169,6 +169,61 @@ def _cpu_baseline(pool, nworkers, wl, nb):
     return allc, one, prove
 
 
+def _one_call_child(cache, window_bits):
+    """A process of its own, as a caller of the library would be: ONE context, ONE call (bpgpu_r1cs_verify_stream_dev /
+    bpgpu_r1cs_verify_stream) over many batches; the library owns the ring of lanes and the hardware-queue setting.  Prints a JSON
+    object.  (Inside the main process the 20 contexts of the timed region hold hardware queues of their own: 40 streams on 24
+    queues make the lanes share queues with them.)"""
+    import pickle
+    import torch  # noqa: F401  (the same import order as a torch-using host; nothing here touches the GPU through torch)
+    import mpc_bulletproof_amd as mb
+    with open(cache, "rb") as f:
+        wl = pickle.load(f)
+    n1, n2, k, m = wl["dims"]
+    pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
+    nb = len(sc) // 160
+    all_ok = (1).to_bytes(4, "little") * nb
+    gpu = mb.BpGpu(int(os.environ.get("LOCAL_RANK", "0")))
+    circ = gpu.circuit_create(*wl["csr"], n1 + n2, m)
+    gens = gpu.gens_create(wl["G"], wl["H"], wl["B"], wl["B"], window_bits)
+    out = {}
+    for tag, reps in (("20k", 20), ("64k", 64), ("256k", 256)):
+        d_p2, d_s2, d_c2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps)
+        d_o2 = gpu.malloc(4 * nb * reps)
+        ts = []
+        for rep_ in range(8):
+            gpu.sync()
+            t0 = time.perf_counter()
+            gpu.r1cs_verify_stream_dev(gens, circ, nb * reps, n1, k, d_p2, d_s2, d_c2, d_o2)
+            gpu.sync()
+            ts.append(time.perf_counter() - t0)
+        assert gpu.download(d_o2, 4 * nb * reps) == all_ok * reps
+        for d in (d_p2, d_s2, d_c2, d_o2):
+            gpu.free(d)
+        ts = sorted(ts[2:])
+        out[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
+                    "best_ms": ts[0] * 1e3}
+    # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane
+    reps = 64
+    h_p, h_s, h_c = mb.lib.host_alloc(len(pts) * reps, pts * reps), mb.lib.host_alloc(len(sc) * reps, sc * reps), mb.lib.host_alloc(len(ch) * reps, ch * reps)
+    ts = []
+    for rep_ in range(6):
+        gpu.sync()
+        t0 = time.perf_counter()
+        ok_h = gpu.r1cs_verify_stream(gens, circ, nb * reps, n1, k, m, h_p, h_s, h_c)
+        ts.append(time.perf_counter() - t0)
+        assert all(ok_h)
+    ts = sorted(ts[2:])
+    out["host_64k"] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
+                       "bytes_uploaded": (len(pts) + len(sc) + len(ch)) * reps}
+    out["hw_queues_exported_by_the_caller"] = os.environ.get("GPU_MAX_HW_QUEUES")     # None: the library's own default is in force
+    out["note"] = ("bpgpu_r1cs_verify_stream(_dev) in a process of its own: one context, one call, no environment variable exported by the caller; the "
+                   "library owns the ring of 20 lanes.  20k = a burst of 20 batches on an idle GPU (the first front launches and the last back launches "
+                   "have the chip to themselves); 64k / 256k approach the steady state; host_64k takes the operands from page-locked host memory "
+                   "and returns the verdicts there (SURVEY 8d's metric as written).  Median of 6 (4) calls")
+    print(json.dumps(out), flush=True)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -253,7 +308,11 @@ def main():
     ap.add_argument("--prover-batches", type=int, default=12, help="batches of 256 provers in the timed prover stream")
     ap.add_argument("--workload-cache", default=None,
                     help="pickle of the generated workload (written if absent); lets a profiled run skip the fork pool")
+    ap.add_argument("--one-call-child", default=None, help=argparse.SUPPRESS)
     a = ap.parse_args()
+    if a.one_call_child:
+        _one_call_child(a.one_call_child, a.window_bits)
+        return
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _spawn_ranks(a.gpus)
@@ -299,11 +358,19 @@ def main():
     n1, n2, k, m = wl["dims"]
     rp, kind, idx, coeff = wl["csr"]
     pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
+    # ---- secondary: the one-call entry point, measured in a fresh process BEFORE this one takes the GPU (one after the other)
+    one_call = None
+    if rank == 0 and world == 1 and not a.no_combined and nb == 1024:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-call-child", cache, "--window-bits", str(a.window_bits)],
+                           capture_output=True, text=True, timeout=600, env={k_: v for k_, v in os.environ.items() if k_ != "GPU_MAX_HW_QUEUES"})
+        if r.returncode != 0:
+            raise RuntimeError("one-call child failed:\n" + r.stderr[-2000:])
+        one_call = json.loads(r.stdout.strip().splitlines()[-1])
 
     # ---- GPU
-    import mpc_bulletproof_amd as mb     # (loads libbpgpu.so: hardware-queue default, before torch's first HIP call)
-    import torch
+    import torch                         # (first, so that libbpgpu.so binds to the HIP runtime torch ships; neither import touches the GPU)
     import torch.distributed as dist
+    import mpc_bulletproof_amd as mb     # loads libbpgpu.so, which sets the hardware-queue default before the first HIP call
     if world > 1:
         if os.environ.get("BPGPU_BENCH_REHEARSAL"):
             # control-flow rehearsal of the multi-rank path on a ONE-GPU box: all ranks share device 0, gloo instead
@@ -429,47 +496,8 @@ def main():
         solo = {n_: (ms / cnt, cnt) for n_, (ms, cnt) in gpu.profile_read().items() if cnt}
         assert gpu.download(d_oks[0], 4 * nb) == all_ok
 
-    one_call = fs = wire = comb = h2d = single = None
+    fs = wire = comb = h2d = single = None
     if not a.no_combined:
-        # ---- secondary: ONE context, ONE call (bpgpu_r1cs_verify_stream_dev): the library cuts the proofs into batches of 1024
-        # and spreads them over its own ring of 20 lanes -- what a Rust host's loop of Verifier::verify becomes
-        one_call = {}
-        for tag, reps in (("20k", 20), ("64k", 64), ("256k", 256)):
-            d_p2, d_s2, d_c2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps)
-            d_o2 = gpu.malloc(4 * nb * reps)
-            ts = []
-            for rep_ in range(6):
-                sync_all()
-                t0 = time.perf_counter()
-                gpu.r1cs_verify_stream_dev(gens, circ, nb * reps, n1, k, d_p2, d_s2, d_c2, d_o2)
-                gpu.sync()
-                ts.append(time.perf_counter() - t0)
-            assert gpu.download(d_o2, 4 * nb * reps) == all_ok * reps
-            for d in (d_p2, d_s2, d_c2, d_o2):
-                gpu.free(d)
-            ts = sorted(ts[1:])
-            one_call[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
-                             "best_ms": ts[0] * 1e3}
-        # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane
-        reps = 64
-        h_p, h_s, h_c = mb.lib.host_alloc(len(pts) * reps, pts * reps), mb.lib.host_alloc(len(sc) * reps, sc * reps), mb.lib.host_alloc(len(ch) * reps, ch * reps)
-        ts = []
-        for rep_ in range(5):
-            sync_all()
-            t0 = time.perf_counter()
-            ok_h = gpu.r1cs_verify_stream(gens, circ, nb * reps, n1, k, m, h_p, h_s, h_c)
-            ts.append(time.perf_counter() - t0)
-            assert all(ok_h)
-        for h_ in (h_p, h_s, h_c):
-            mb.lib.host_free(h_)
-        ts = sorted(ts[1:])
-        one_call["host_64k"] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
-                                "bytes_uploaded": (len(pts) + len(sc) + len(ch)) * reps}
-        one_call["note"] = ("bpgpu_r1cs_verify_stream(_dev): one context, one call, no environment variable exported by the caller; the library owns "
-                            "the ring of 20 lanes.  20k = a burst of 20 batches on an idle GPU (the first front launches and the last back "
-                            "launches have the chip to themselves: ~80 % of the steady state); 64k / 256k approach the steady state; host_64k "
-                            "takes operands from page-locked host memory and returns verdicts there (SURVEY 8d's metric as written).  Median of 5 calls")
-
         # ---- secondary: ONE batch at a time (no pipelining): the latency of a batch's kernel chain
         lat = []
         ctxs[0].set_latency_mode(True)      # the context-level hint for un-pipelined callers (include/bpgpu.h)

@@ -50,6 +50,8 @@ struct bpgpu_ctx {
   // of one call over; created on first use, owned by the parent
   std::vector<bpgpu_ctx *> lanes;
   hipEvent_t lane_ev = nullptr;   // fork / join marker of a stream call
+  void *pinned = nullptr;         // page-locked staging for the verdicts of a host-memory stream call (grow-only)
+  size_t pinned_cap = 0;
   // device-transcript schedule cache (m, k, padded_n) -> steps already resident in ws slot 15
   size_t sched_key[3] = {(size_t)-1, (size_t)-1, (size_t)-1};
   int sched_len = 0;
@@ -294,6 +296,7 @@ void bpgpu_destroy(bpgpu_ctx *ctx) {
   for (auto *l : ctx->lanes) bpgpu_destroy(l);
   ctx->lanes.clear();
   if (ctx->lane_ev) hipEventDestroy(ctx->lane_ev);
+  if (ctx->pinned) hipHostFree(ctx->pinned);
   hipSetDevice(ctx->device);
   hipStreamSynchronize(ctx->st);
   hipStreamSynchronize(ctx->st2);
@@ -1455,8 +1458,18 @@ int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_ci
   if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok))) return BPGPU_E_ARG;
   if (c->nchi) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
-  CK(verify_stream_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, (uint8_t *)ok, true));
+  if (!nb) return BPGPU_OK;
+  // the verdicts come back through page-locked staging: an asynchronous copy into the caller's (pageable) array would make every
+  // batch's download a host-side wait for its lane -- and serialise the lanes
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (ctx->pinned_cap < nb * 4) {
+    if (ctx->pinned) { HIPCK(ctx, hipStreamSynchronize(ctx->st)); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    HIPCK(ctx, hipHostMalloc(&ctx->pinned, nb * 4 + nb, hipHostMallocDefault));
+    ctx->pinned_cap = nb * 4 + nb;
+  }
+  CK(verify_stream_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, (uint8_t *)ctx->pinned, true));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  memcpy(ok, ctx->pinned, nb * 4);
   return BPGPU_OK;
 }
 
