@@ -33,6 +33,81 @@ void scalars_check(hipStream_t st, const Words8 *in, size_t n, int *bad) {
   if (!n) return;
   hipLaunchKernelGGL(k_scalars_check, dim3((n + 255) / 256), dim3(256), 0, st, in, n, bad);
 }
+// ---- constraint rows (CSR, as the reference holds its Vec<LinearCombination>) -> column-major by output variable, on the device.
+// Outputs are ordered wL[0..n) wR[0..n) wO[0..n) wV[0..m) wc; within a column the order of the terms is whatever the atomics
+// give: the flattened weights are exact sums in F_n, so they do not depend on it.
+__device__ __forceinline__ bool csr_out_of(uint32_t kd, uint32_t ix, size_t n_mul, size_t m, size_t &o) {
+  if (kd <= 2) { if (ix >= n_mul) return false; o = (size_t)kd * n_mul + ix; return true; }
+  if (kd == 3) { if (ix >= m) return false; o = 3 * n_mul + ix; return true; }
+  if (kd == 4) { o = 3 * n_mul + m; return true; }
+  return false;
+}
+__global__ void __launch_bounds__(256) k_csr_count(size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx, size_t n_mul,
+                                                   size_t m, uint32_t *cnt, int *bad) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= q) return;
+  for (uint32_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
+    size_t o;
+    if (!csr_out_of(kind[t], idx[t], n_mul, m, o)) { atomicOr(bad, 1); continue; }
+    atomicAdd(&cnt[o + 1], 1u);
+  }
+}
+// exclusive scan in place over cnt[0 .. n] (cnt[0] = 0 on entry): ONE block of 1024 lanes, each owning a contiguous run
+__global__ void __launch_bounds__(1024) k_csr_scan(uint32_t *cnt, size_t n1) {
+  __shared__ uint32_t part[1024];
+  const size_t per = (n1 + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n1 ? lo + per : n1;
+  uint32_t s = 0;
+  for (size_t i = lo; i < hi; i++) s += cnt[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    uint32_t v = threadIdx.x >= (unsigned)off ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
+  for (size_t i = lo; i < hi; i++) { run += cnt[i]; cnt[i] = run; }      // inclusive over cnt[1..]: cnt[o + 1] = end of column o
+}
+template <bool ARK>
+__global__ void __launch_bounds__(256) k_csr_scatter(size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
+                                                     const Words8 *coeff_in, size_t n_mul, size_t m, const uint32_t *col_ptr, uint32_t *fill,
+                                                     uint32_t *rows, Words8 *coeff_out, int *bad) {
+  size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= q) return;
+  for (uint32_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
+    size_t o;
+    if (!csr_out_of(kind[t], idx[t], n_mul, m, o)) continue;
+    const uint32_t pos = col_ptr[o] + atomicAdd(&fill[o], 1u);
+    rows[pos] = (uint32_t)r;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) w[j] = coeff_in[t].w[j];
+    if (!words_lt_mod<FN>(w)) { atomicOr(bad, 1); continue; }
+    Fn x;
+    if (ARK) {       // ark-ff Montgomery limbs (x 2^256 mod n): one multiplication by 2^266 instead of the host's de-Montgomery
+      constexpr int32_t C[NL] = FN_ARK_MONT;
+      Fn k;
+#pragma unroll
+      for (int j = 0; j < NL; j++) k.v[j] = C[j];
+      x = canon(mul(unpack<FN>(w), k));
+    } else x = canon(to_mont(unpack<FN>(w)));
+    pack(w, x);
+#pragma unroll
+    for (int j = 0; j < 8; j++) coeff_out[pos].w[j] = w[j];
+  }
+}
+void circuit_transpose(hipStream_t st, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx, const Words8 *coeff_in,
+                       size_t n_mul, size_t m, bool ark, uint32_t *col_ptr, uint32_t *fill, uint32_t *rows, Words8 *coeff_out, int *bad) {
+  const size_t nout = 3 * n_mul + m + 1;
+  (void)hipMemsetAsync(col_ptr, 0, (nout + 1) * 4, st);
+  (void)hipMemsetAsync(fill, 0, nout * 4, st);
+  if (!q) return;
+  hipLaunchKernelGGL(k_csr_count, dim3((q + 255) / 256), dim3(256), 0, st, q, row_ptr, kind, idx, n_mul, m, col_ptr, bad);
+  hipLaunchKernelGGL(k_csr_scan, dim3(1), dim3(1024), 0, st, col_ptr, nout + 1);
+  if (ark) hipLaunchKernelGGL(k_csr_scatter<true>, dim3((q + 255) / 256), dim3(256), 0, st, q, row_ptr, kind, idx, coeff_in, n_mul, m, col_ptr, fill, rows, coeff_out, bad);
+  else hipLaunchKernelGGL(k_csr_scatter<false>, dim3((q + 255) / 256), dim3(256), 0, st, q, row_ptr, kind, idx, coeff_in, n_mul, m, col_ptr, fill, rows, coeff_out, bad);
+}
 // rows of the commitment MSMs from the witness planes (see kernels.h): one lane per row element
 __global__ void __launch_bounds__(256) k_commit_rows(size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR,
                                                      const Words8 *aO, const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows) {

@@ -182,6 +182,11 @@ struct CircuitDev {
   // qz = (1 + nchi) * q entries, zpow[j * q + r] = chi_j * z^(r+1), and the flattening itself is unchanged.
   size_t nchi, qz;
 };
+// CSR constraint rows (device copies of the ABI arrays; coefficients plain canonical or, ark, ark-ff Montgomery limbs) -> the
+// column-major form above: col_ptr (3n + m + 2), rows / coeff_out (nnz, Montgomery form); fill: 3n + m + 1 scratch counters;
+// *bad |= 1 on an unknown variable kind, an index out of range or a non-canonical coefficient
+void circuit_transpose(hipStream_t st, size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx, const Words8 *coeff_in,
+                       size_t n_mul, size_t m, bool ark, uint32_t *col_ptr, uint32_t *fill, uint32_t *rows, Words8 *coeff_out, int *bad);
 // zpow scratch: nb * q field elements (9 int32 each)
 void flatten(hipStream_t st, const CircuitDev &c, size_t nb, const Words8 *z, size_t z_stride_words,
              Words8 *wL, Words8 *wR, Words8 *wO, Words8 *wV, Words8 *wc, int32_t *zpow_scratch, const Words8 *chi = nullptr);

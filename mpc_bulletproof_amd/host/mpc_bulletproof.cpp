@@ -1166,9 +1166,26 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   std::vector<Scalar> i_b1(nb), o_b1(nb), s_b1(nb), i_b2(nb), o_b2(nb), s_b2(nb);
   // prover.rs:435-445: the blinding RNG is bound to the transcript state and to the witness blindings
   // (build_rng().rekey_with_witness_bytes("v_blinding", ..)); the OS entropy is already in an OsRng's key
+  // (many commitments -- the 2^14-shuffle has 32 768 -- are absorbed as the keccak256 digests of runs of 128 blindings, hashed
+  // on the thread pool: one rekey per blinding was 32 768 dependent permutations, 13 ms)
   parallel_for(nb, [&](size_t p) {
     rngs[p]->rekey(cs[p]->tr.state(), 32);
-    for (const Scalar &vb : cs[p]->v_blinding) { auto b = vb.to_bytes(); rngs[p]->rekey(b.data(), b.size()); }
+    const auto &vb = cs[p]->v_blinding;
+    const size_t RUN = 128, runs = (vb.size() + RUN - 1) / RUN;
+    if (runs <= 1) {
+      std::vector<uint8_t> all(vb.size() * 32);
+      for (size_t i = 0; i < vb.size(); i++) vb[i].to_bytes_le(&all[32 * i]);
+      if (!all.empty()) rngs[p]->rekey(all.data(), all.size());
+    } else {
+      std::vector<uint8_t> dig(runs * 32);
+      parallel_for(runs, [&](size_t r) {
+        const size_t lo = r * RUN, hi = std::min(vb.size(), lo + RUN);
+        std::vector<uint8_t> buf((hi - lo) * 32);
+        for (size_t i = lo; i < hi; i++) vb[i].to_bytes_le(&buf[32 * (i - lo)]);
+        keccak256(buf.data(), buf.size(), &dig[32 * r]);
+      });
+      rngs[p]->rekey(dig.data(), dig.size());
+    }
   }, 16);
   // One phase of commitments, prover.rs:457-494 (lo = 0) / :519-565 (lo = n1): blinding factors, then A_I, A_O, S over
   // [B_blinding, G_lo.., H_lo..] -- the witness planes go to the device once (bpgpu_r1cs_prover_commit keeps them in the
@@ -1288,7 +1305,17 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     u[p] = tr.challenge_scalar("u");                                                      // :639-640
     x[p] = tr.challenge_scalar("x");
     Scalar tb2;
-    for (size_t i = 0; i < m; i++) tb2 += wV[p * m + i] * cs[p]->v_blinding[i];           // :644-648
+    if (m >= 4096) {                                                                      // :644-648 (32 768 terms for the 2^14-shuffle)
+      std::vector<Scalar> part(64);
+      parallel_for(64, [&](size_t c) {
+        Scalar acc;
+        for (size_t i = m * c / 64; i < m * (c + 1) / 64; i++) acc += wV[p * m + i] * cs[p]->v_blinding[i];
+        part[c] = acc;
+      });
+      for (auto &x : part) tb2 += x;
+    } else {
+      for (size_t i = 0; i < m; i++) tb2 += wV[p * m + i] * cs[p]->v_blinding[i];
+    }
     tb[p * 6 + 1] = tb2;
     auto poly6 = [&](const Scalar *c6) {                                                  // util.rs:192-194
       return x[p] * (c6[0] + x[p] * (c6[1] + x[p] * (c6[2] + x[p] * (c6[3] + x[p] * (c6[4] + x[p] * c6[5])))));

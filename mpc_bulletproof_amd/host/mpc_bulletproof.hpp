@@ -236,33 +236,57 @@ struct Variable {                                                  // linear_com
   bool operator<(const Variable &o) const { return kind != o.kind ? kind < o.kind : index < o.index; }
   static Variable one() { return Variable{One, 0}; }
 };
-// terms of a linear combination, ordered by variable: a small sorted vector (the reference's HashMap; a node-based
-// map costs one allocation per term -- 2 x 10^6 of them when 256 provers build 2064 constraints each)
+// terms of a linear combination, ordered by variable (the reference's HashMap).  Up to three terms live INSIDE the object --
+// almost every row of a gadget is `var`, `a + b - 1` or `(x - z) - mul_left`, and one heap allocation per row is 2 x 10^6
+// allocations (and as many frees) when 256 provers build 2064 constraints each --; longer rows (the range gadget's final
+// sum) spill into a sorted vector.
 class TermMap {
  public:
   typedef std::pair<Variable, Scalar> value_type;
-  typedef std::vector<value_type>::iterator iterator;
-  typedef std::vector<value_type>::const_iterator const_iterator;
-  iterator begin() { return v_.begin(); }
-  iterator end() { return v_.end(); }
-  const_iterator begin() const { return v_.begin(); }
-  const_iterator end() const { return v_.end(); }
-  size_t size() const { return v_.size(); }
-  iterator find(const Variable &k) { auto it = lower(k); return it != v_.end() && !(k < it->first) ? it : v_.end(); }
+  typedef value_type *iterator;
+  typedef const value_type *const_iterator;
+  TermMap() {}
+  TermMap(const TermMap &o) : n_(o.n_) { if (o.heap_) heap_.reset(new std::vector<value_type>(*o.heap_)); else std::copy(o.inl_, o.inl_ + o.n_, inl_); }
+  TermMap(TermMap &&o) noexcept : n_(o.n_), heap_(std::move(o.heap_)) { if (!heap_) std::copy(o.inl_, o.inl_ + o.n_, inl_); o.n_ = 0; }
+  TermMap &operator=(const TermMap &o) { if (this != &o) { TermMap t(o); *this = std::move(t); } return *this; }
+  TermMap &operator=(TermMap &&o) noexcept {
+    n_ = o.n_; heap_ = std::move(o.heap_);
+    if (!heap_) std::copy(o.inl_, o.inl_ + o.n_, inl_);
+    o.n_ = 0;
+    return *this;
+  }
+  iterator begin() { return heap_ ? heap_->data() : inl_; }
+  iterator end() { return begin() + n_; }
+  const_iterator begin() const { return heap_ ? heap_->data() : inl_; }
+  const_iterator end() const { return begin() + n_; }
+  size_t size() const { return n_; }
+  iterator find(const Variable &k) { auto it = lower(k); return it != end() && !(k < it->first) ? it : end(); }
   Scalar &operator[](const Variable &k) {
-    auto it = lower(k);
-    if (it == v_.end() || k < it->first) it = v_.insert(it, value_type(k, Scalar()));
-    return it->second;
+    iterator it = lower(k);
+    if (it != end() && !(k < it->first)) return it->second;
+    const size_t pos = (size_t)(it - begin());
+    if (!heap_ && n_ < INLINE) {
+      for (size_t i = n_; i > pos; i--) inl_[i] = inl_[i - 1];
+      inl_[pos] = value_type(k, Scalar());
+      n_++;
+      return inl_[pos].second;
+    }
+    if (!heap_) { heap_.reset(new std::vector<value_type>(inl_, inl_ + n_)); heap_->reserve(2 * INLINE + 2); }
+    heap_->insert(heap_->begin() + (long)pos, value_type(k, Scalar()));
+    n_++;
+    return (*heap_)[pos].second;
   }
  private:
+  static constexpr size_t INLINE = 3;
   iterator lower(const Variable &k) {
-    if (v_.size() > 16)
-      return std::lower_bound(v_.begin(), v_.end(), k, [](const value_type &a, const Variable &b) { return a.first < b; });
-    auto it = v_.begin();
-    while (it != v_.end() && it->first < k) ++it;      // a handful of terms per row: linear beats binary
+    if (n_ > 16) return std::lower_bound(begin(), end(), k, [](const value_type &a, const Variable &b) { return a.first < b; });
+    iterator it = begin(), e = end();
+    while (it != e && it->first < k) ++it;      // a handful of terms per row: linear beats binary
     return it;
   }
-  std::vector<value_type> v_;
+  value_type inl_[INLINE];
+  size_t n_ = 0;
+  std::unique_ptr<std::vector<value_type>> heap_;
 };
 class LinearCombination {                                          // linear_combination.rs:118-121
  public:

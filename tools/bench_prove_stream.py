@@ -40,6 +40,6 @@ for prebuild in (1, 0):
             ms = run(nbatch, threads, prebuild)
             if best is None or ms[0] < best[0]:
                 best = ms
-        wall, build, prove, drop = best
+        wall, build, prove, drop = best[:4]
         print(f"prebuild={prebuild} threads={threads}: {wall / nbatch:7.2f} ms/batch = {nbatch * nb * q / wall / 1e3:7.2f} M constraints/s "
               f"| per batch: build {build / nbatch:6.2f}  prove_batch {prove / nbatch:6.2f}  drop {drop / nbatch:5.2f} ms", flush=True)
