@@ -411,6 +411,21 @@ int bpgpu_r1cs_verify_batch_fs2_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const b
                                     const void *init_states_dev, const uint8_t gadget_label[32], const void *points_dev,
                                     const void *scalars_dev, void *ok_dev, void *mega_dev, void *challenges_out_dev,
                                     void *gadget_challenges_out_dev);
+/* ONE large proof over the GPUs of a node (BASELINE configs[3], the 2^14-shuffle): every rank runs the protocol and
+ * the O(n) scalar work in full, and the multi-scalar multiplications over ITS contiguous share of the terms; the ranks all-gather
+ * their partial points (64 bytes each) and add them with bpgpu_points_sum -- the only exchange on the path.
+ *   bpgpu_set_shard(ctx, rank, world): prover / IPP sessions opened on this context afterwards return PARTIAL sums --
+ *     bpgpu_r1cs_prover_commit: A_I, A_O, S over the rank's generators (the B_blinding term on rank 0);
+ *     bpgpu_ipp_round of a resident-generator session: L, R over the rank's generators (the c Q term on rank 0); the scalar
+ *     vectors are folded on every rank alike; bpgpu_ipp_run_fs refuses such a session (BPGPU_E_ARG: the rounds need the exchange).
+ *     world = 1 (the default) turns it off.
+ *   bpgpu_r1cs_verify_shard: the rank's partial mega_check point of one proof (layouts of bpgpu_r1cs_verify_batch with nb = 1;
+ *     gadget_challenges for a parametric circuit, else NULL).  The proof verifies iff the sum over the ranks is the identity. */
+int bpgpu_set_shard(bpgpu_ctx *ctx, size_t rank, size_t world);
+int bpgpu_r1cs_verify_shard(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t n1, size_t k, const uint8_t *points,
+                            const uint8_t *scalars, const uint8_t *challenges, const uint8_t *gadget_challenges, size_t rank, size_t world,
+                            uint8_t partial_xy[64]);
+
 /* Combined batch check (NOT a reference API -- the reference verifies proof by proof; this is
  * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random
  * weights rho (nb x 32 B, e.g. from a CSPRNG) computes  sum_p rho_p * mega_check_p  as ONE point:

@@ -34,6 +34,7 @@ struct bpgpu_ctx {
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
   bool latency_mode = false;      // bpgpu_set_latency_mode
+  size_t shard_rank = 0, shard_world = 1;   // bpgpu_set_shard: this context's share of ONE large proof split over the GPUs of a node
   // bpgpu_set_option: launch-route selectors of THIS context (tests walk every route through them; a multi-tenant host gives
   // each tenant its own context).  The BPGPU_* environment variables of the same names only seed the defaults, once, in bpgpu_create.
   int64_t opt[BPGPU_OPT_COUNT] = {};
@@ -109,6 +110,8 @@ struct bpgpu_ipp {
   bpgpu_gens *own_gens = nullptr;                                  // tables built for this session only (bpgpu_ipp_begin, one proof)
   const bpgpu_gens *gens = nullptr;                                // resident-generator mode: no G/H buffers,
   Words8 *cG = nullptr, *cH = nullptr, *w = nullptr;               //   coefficient vectors nb x n0 and Q = w * B
+  size_t slo = 0, shi = (size_t)-1;                                // bpgpu_set_shard at session start: the generators whose terms this
+  bool with_q = true;                                              //   rank's L, R carry (the c Q term belongs to rank 0)
 };
 struct bpgpu_circuit {
   size_t q = 0, n = 0, m = 0, nnz = 0, nchi = 0;   // nchi: gadget challenges the coefficients are affine in (kernels.h CircuitDev)
@@ -326,6 +329,17 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on) {
   if (!ctx) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->latency_mode = on != 0;
+  return BPGPU_OK;
+}
+static void shard_bounds(size_t total, size_t rank, size_t world, size_t *lo, size_t *hi) {   // contiguous, sizes differ by at most one
+  const size_t base = total / world, rem = total % world;
+  *lo = rank * base + (rank < rem ? rank : rem);
+  *hi = *lo + base + (rank < rem ? 1 : 0);
+}
+int bpgpu_set_shard(bpgpu_ctx *ctx, size_t rank, size_t world) {
+  if (!ctx || !world || rank >= world) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  ctx->shard_rank = rank; ctx->shard_world = world;
   return BPGPU_OK;
 }
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value) {
@@ -1195,8 +1209,11 @@ int bpgpu_flatten_constraints(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb,
 
 static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
                                    size_t k, const void *points, const void *scalars, const void *challenges,
-                                   void *ok, void *mega, void *full_sc, const void *chi = nullptr) {
+                                   void *ok, void *mega, void *full_sc, const void *chi = nullptr, const size_t *shard = nullptr) {
+  // shard = {rank, world} (nb == 1): this rank's share of ONE proof's mega_check -- the generators and the proof points of its
+  // slice; `mega` receives the partial sum (the ranks all-gather and add them: SURVEY 8e.2), `ok` says whether the PARTIAL is the identity
   if (k >= 32) return BPGPU_E_LEN;
+  if (shard && (nb != 1 || !shard[1] || shard[0] >= shard[1])) return BPGPU_E_ARG;
   if ((c->nchi != 0) != (chi != nullptr)) return BPGPU_E_ARG;   // a parametric circuit needs its gadget challenges, and only it
   size_t np = (size_t)1 << k, n = c->n, m = c->m;
   if (n > np || n1 > n || (np > 1 && n <= np / 2 && n != 0)) return BPGPU_E_LEN;   // padded_n = next_pow2(n)
@@ -1240,6 +1257,12 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     { ProfScope ps(ctx, 0, ctx->st);
       verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
                      (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc, fuse_prep); }
+    if (shard) {   // a small proof: the other ranks' terms are simply zeroed
+      size_t slo, shi, vlo, vhi;
+      shard_bounds(np, shard[0], shard[1], &slo, &shi);
+      shard_bounds(nvar, shard[0], shard[1], &vlo, &vhi);
+      shard_mask(ctx->st, (Words8 *)dfix, np, slo, shi, shard[0] == 0, (Words8 *)dvar, nvar, vlo, vhi);
+    }
     { ProfScope ps(ctx, 7, ctx->st);
       verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
     { ProfScope ps(ctx, 9, ctx->st);
@@ -1259,6 +1282,13 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     ProfScope ps(ctx, 0, ctx->st);
     verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
                    (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc);
+  }
+  size_t vlo = 0, vhi = nvar;
+  if (shard) {     // generator half: the other ranks' scalars are zeroed (a zero digit costs the table-lookup lanes nothing but the
+    size_t slo, shi;   // walk); proof-point half: only this rank's slice of the points is touched at all (below)
+    shard_bounds(np, shard[0], shard[1], &slo, &shi);
+    shard_bounds(nvar, shard[0], shard[1], &vlo, &vhi);
+    shard_mask(ctx->st, (Words8 *)dfix, np, slo, shi, shard[0] == 0, (Words8 *)dvar, nvar, vlo, vhi);
   }
   // proof points: `vnp` points per lane share one doubling chain (lanes per proof = ceil(nvar / vnp)).  Lanes
   // are ROLE-major (lane = role * nb + proof): the 64 lanes of a wave hold the same proof element of 64 proofs,
@@ -1288,7 +1318,10 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
     bool done = false;
     { ProfScope ps(ctx, 3, ctx->st);
-      CK(msm_wp_batch(ctx, 1, nvar, dvar, points, false, (JacRaw *)dvres, &done, (int *)dbadpt, (size_t)1 << 16)); }
+      if (vhi > vlo) CK(msm_wp_batch(ctx, 1, vhi - vlo, (const uint8_t *)dvar + vlo * 32, (const uint8_t *)points + vlo * 64, false, (JacRaw *)dvres, &done,
+                                     (int *)dbadpt, (size_t)1 << 16));
+      else { HIPCK(ctx, hipMemsetAsync(dvres, 0, sizeof(JacRaw), ctx->st)); done = true; }    // (zero limbs = the identity)
+    }
     HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
     if (done) {
       ProfScope ps(ctx, 4, ctx->st);
@@ -1346,6 +1379,38 @@ int bpgpu_r1cs_verify_batch_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
   if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !ok))) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, ok, mega, full_sc);
+}
+/* ONE proof's mega_check split over the GPUs of a node by term range (BASELINE configs[3]: 98 347 terms): this
+ * rank's partial point.  Every rank runs the (cheap, O(n)) scalar assembly in full and the MSM over its share only. */
+int bpgpu_r1cs_verify_shard(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t n1, size_t k, const uint8_t *points,
+                            const uint8_t *scalars, const uint8_t *challenges, const uint8_t *gadget_challenges, size_t rank, size_t world,
+                            uint8_t partial_xy[64]) {
+  if (!ctx || !g || !c || !points || !scalars || !challenges || !partial_xy || !world || rank >= world) return BPGPU_E_ARG;
+  if ((c->nchi != 0) != (gadget_challenges != nullptr)) return BPGPU_E_ARG;
+  if (k >= 32) return BPGPU_E_LEN;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t m = c->m, nvar = 11 + m + 2 * k;
+  void *dP, *dS, *dC, *dok, *dmega, *dchi = nullptr;
+  CK(ws_get(ctx, 0, nvar * 64, &dP));
+  CK(ws_get(ctx, 1, 5 * 32, &dS));
+  CK(ws_get(ctx, 2, (6 + k) * 32, &dC));
+  CK(ws_get(ctx, 3, 4, &dok));
+  CK(ws_get(ctx, 4, 64, &dmega));
+  if (c->nchi) { CK(ws_get(ctx, 21, c->nchi * 32, &dchi)); CK(h2d(ctx, dchi, gadget_challenges, c->nchi * 32)); }
+  CK(flag_reset(ctx));
+  CK(h2d(ctx, dP, points, nvar * 64));
+  CK(h2d(ctx, dS, scalars, 5 * 32));
+  CK(h2d(ctx, dC, challenges, (6 + k) * 32));
+  if (dchi) scalars_check(ctx->st, (const Words8 *)dchi, c->nchi, ctx->d_flag);
+  const size_t shard[2] = {rank, world};
+  CK(verify_batch_dev_locked(ctx, g, c, 1, n1, k, dP, dS, dC, dok, dmega, nullptr, dchi, shard));
+  int bad = 0;
+  CK(flag_read(ctx, &bad));
+  if (bad) return BPGPU_E_ARG;      // (a malformed operand: every rank sees the same inputs and fails alike)
+  CK(d2h(ctx, partial_xy, dmega, 64));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
 }
 int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,
                             size_t k, const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges,
@@ -1859,6 +1924,7 @@ int bpgpu_ipp_begin_gens(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t 
   bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
   if (!s) return BPGPU_E_OOM;
   s->nb = nb; s->n0 = s->n = n; s->gens = g;
+  if (ctx->shard_world > 1) { shard_bounds(n, ctx->shard_rank, ctx->shard_world, &s->slo, &s->shi); s->with_q = ctx->shard_rank == 0; }
   size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
   bool okk = true;
   auto M = [&](void **p, size_t bytes) { if (okk && !pool_alloc(ctx, p, bytes)) okk = false; };
@@ -1905,7 +1971,7 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
   if (s->gens) {   // resident generators: two table-lookup MSMs over the original generators per proof
     sc_dot_batched(st, nb, h, a, n, b + h, n, s->cLR, 2);        // c_L = <a_L, b_R>
     sc_dot_batched(st, nb, h, a + h, n, b, n, s->cLR + 1, 2);    // c_R = <a_R, b_L>
-    ipp_gens_scalars(st, nb, s->n0, n, a, b, s->cG, s->cH, s->cLR, s->w, s->msc);
+    ipp_gens_scalars(st, nb, s->n0, n, a, b, s->cG, s->cH, s->cLR, s->w, s->msc, s->slo, s->shi, s->with_q);
     {
       size_t chunks = fixed_msm_ipp_chunks(s->gens->c, s->n0, nb * 2);
       void *dpart = nullptr;
@@ -2045,6 +2111,7 @@ int bpgpu_ipp_fold(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *u, const uint8_t
 int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uint8_t *L_out, uint8_t *R_out,
                      uint8_t *a_out, uint8_t *b_out, uint8_t *states_out) try {
   if (!ctx || !s || !states_in || !a_out || !b_out) return BPGPU_E_ARG;
+  if (s->shi != (size_t)-1) return BPGPU_E_ARG;    // a sharded session's L, R are partial sums: its rounds need the ranks' exchange
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
   const size_t nb = s->nb;
@@ -2233,6 +2300,7 @@ int bpgpu_r1cs_prover_ipp_begin(bpgpu_ctx *ctx, bpgpu_prover *ps, const bpgpu_ge
   bpgpu_ipp *s = new (std::nothrow) bpgpu_ipp();
   if (!s) return BPGPU_E_OOM;
   s->nb = nb; s->n0 = s->n = n; s->gens = g;
+  if (ctx->shard_world > 1) { shard_bounds(n, ctx->shard_rank, ctx->shard_world, &s->slo, &s->shi); s->with_q = ctx->shard_rank == 0; }
   size_t tot = nb * n, half = nb * (n > 1 ? n / 2 : 1);
   bool okk = true;
   auto M = [&](void **p, size_t bytes) { if (okk && !pool_alloc(ctx, p, bytes)) okk = false; };
@@ -2338,7 +2406,9 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
     if (!explicit_vec) blind_vectors(ctx->st, dkeys, nb, n_new, s->sL, s->sR, wn, wn0);
   }
   scalars_from_ark(ctx->st, dbl, dbl, 3 * nb, ctx->d_flag);
-  commit_rows(ctx->st, nb, wn, wn0, wn, s->aL, s->aR, s->aO, s->sL, s->sR, dbl, (Words8 *)drows);
+  size_t slo = 0, shi = wn;
+  if (ctx->shard_world > 1) shard_bounds(wn, ctx->shard_rank, ctx->shard_world, &slo, &shi);   // this rank's generators: partial commitments
+  commit_rows(ctx->st, nb, wn, wn0, wn, s->aL, s->aR, s->aO, s->sL, s->sR, dbl, (Words8 *)drows, slo, shi, ctx->shard_rank == 0);
   if ((rc = msm_gens_dev(ctx, g, nb * 3, wn, (const uint32_t *)drows, (JacRaw *)dres, ctx->st))) return fail(rc);
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb * 3);
   span.close();

@@ -110,17 +110,18 @@ void circuit_transpose(hipStream_t st, size_t q, const uint32_t *row_ptr, const 
 }
 // rows of the commitment MSMs from the witness planes (see kernels.h): one lane per row element
 __global__ void __launch_bounds__(256) k_commit_rows(size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR,
-                                                     const Words8 *aO, const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows) {
+                                                     const Words8 *aO, const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows,
+                                                     size_t slo, size_t shi, int with_blind) {
   const size_t per = 2 + 2 * n;
   size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= nb * 3 * per) return;
   const size_t e = t % per, w = (t / per) % 3, p = t / (3 * per);
   const Words8 *src = nullptr;
-  if (e == 1) src = blinds + p * 3 + w;
+  if (e == 1) { if (with_blind) src = blinds + p * 3 + w; }
   else if (e >= 2) {
     const size_t i = (e - 2) % n;
     const bool h = e - 2 >= n;
-    if (i >= lo) {
+    if (i >= lo && i >= slo && i < shi) {
       const Words8 *pl = w == 0 ? (h ? aR : aL) : (w == 1 ? (h ? nullptr : aO) : (h ? sR : sL));
       if (pl) src = pl + p * stride + i;
     }
@@ -130,9 +131,30 @@ __global__ void __launch_bounds__(256) k_commit_rows(size_t nb, size_t n, size_t
   rows[t] = v;
 }
 void commit_rows(hipStream_t st, size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR, const Words8 *aO,
-                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows) {
+                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows, size_t slo, size_t shi, bool with_blind) {
   const size_t tot = nb * 3 * (2 + 2 * n);
-  if (tot) hipLaunchKernelGGL(k_commit_rows, dim3((tot + 255) / 256), dim3(256), 0, st, nb, n, lo, stride, aL, aR, aO, sL, sR, blinds, rows);
+  if (tot) hipLaunchKernelGGL(k_commit_rows, dim3((tot + 255) / 256), dim3(256), 0, st, nb, n, lo, stride, aL, aR, aO, sL, sR, blinds, rows,
+                              slo, shi, with_blind ? 1 : 0);
+}
+// one proof's MSM scalars restricted to a rank's share: fixed = [B, B_blinding, G_0..G_{np-1}, H_0..H_{np-1}] keeps the
+// generators [slo, shi) (B, B_blinding on the rank with keep_pedersen), var = nvar proof-point scalars keeps [vlo, vhi)
+__global__ void __launch_bounds__(256) k_shard_mask(Words8 *fixed, size_t np, size_t slo, size_t shi, int keep_pedersen, Words8 *var, size_t nvar,
+                                                    size_t vlo, size_t vhi) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nfix = 2 + 2 * np;
+  Words8 z{};
+  if (t < nfix) {
+    bool keep = t < 2 ? keep_pedersen != 0 : ((t - 2) % np >= slo && (t - 2) % np < shi);
+    if (!keep) fixed[t] = z;
+  } else if (t < nfix + nvar) {
+    const size_t v = t - nfix;
+    if (v < vlo || v >= vhi) var[v] = z;
+  }
+}
+void shard_mask(hipStream_t st, Words8 *fixed, size_t np, size_t slo, size_t shi, bool keep_pedersen, Words8 *var, size_t nvar, size_t vlo,
+                size_t vhi) {
+  const size_t tot = 2 + 2 * np + nvar;
+  hipLaunchKernelGGL(k_shard_mask, dim3((tot + 255) / 256), dim3(256), 0, st, fixed, np, slo, shi, keep_pedersen ? 1 : 0, var, nvar, vlo, vhi);
 }
 void scalars_check_proof(hipStream_t st, const Words8 *in, size_t n, size_t per_unit, int *bad, int32_t *bad_unit) {
   if (!n) return;
@@ -353,15 +375,17 @@ void verification_scalars(hipStream_t st, const Words8 *challenges, size_t k, si
 // (j / h) cur + j % h;  L uses G_hi and H_lo, R uses G_lo and H_hi (k_fixed_msm_ipp applies the same enumeration).
 __global__ void __launch_bounds__(256) k_ipp_gens_scalars(size_t n0, size_t cur, const Words8 *a, const Words8 *b,
                                                           const Words8 *cG, const Words8 *cH, const Words8 *cLR,
-                                                          const Words8 *w, Words8 *msc) {
+                                                          const Words8 *w, Words8 *msc, size_t slo, size_t shi, int with_q) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, p = blockIdx.y;
   if (i >= n0) return;
+  const bool mine = i >= slo && i < shi;       // (a rank of a sharded proof keeps the generators [slo, shi): the others' terms are zero)
   const size_t h = cur / 2, t = i & (cur - 1), tl = t & (h - 1), per = 1 + n0, half = n0 / 2;
   const bool hi = t >= h;
   const size_t j = (i / cur) * h + tl;            // rank of i among the hi (or lo) indices
   const Words8 *ap = a + p * cur, *bp = b + p * cur;
   Words8 *L = msc + (p * 2) * per, *R = L + per;
   Fn cg = load_plain(&cG[p * n0 + i]), ch = load_plain(&cH[p * n0 + i]);
+  if (!mine) cg = ch = fe_zero<FN>();
   if (hi) {
     store_plain(&L[1 + j], mul(load_plain(&ap[tl]), cg));            // <a_L, G_R>
     store_plain(&R[1 + half + j], mul(load_plain(&bp[tl]), ch));     // <b_L, H_R>
@@ -370,15 +394,15 @@ __global__ void __launch_bounds__(256) k_ipp_gens_scalars(size_t n0, size_t cur,
     store_plain(&R[1 + j], mul(load_plain(&ap[h + tl]), cg));        // <a_R, G_L>
   }
   if (i == 0) {
-    Fn ww = load_plain(&w[p]);
+    Fn ww = with_q ? load_plain(&w[p]) : fe_zero<FN>();
     store_plain(&L[0], mul(load_plain(&cLR[2 * p]), ww));       // c_L * Q
     store_plain(&R[0], mul(load_plain(&cLR[2 * p + 1]), ww));   // c_R * Q
   }
 }
 void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,
-                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc) {
+                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc, size_t slo, size_t shi, bool with_q) {
   if (!nb || !n0) return;
-  hipLaunchKernelGGL(k_ipp_gens_scalars, dim3((n0 + 255) / 256, nb), dim3(256), 0, st, n0, cur, a, b, cG, cH, cLR, w, msc);
+  hipLaunchKernelGGL(k_ipp_gens_scalars, dim3((n0 + 255) / 256, nb), dim3(256), 0, st, n0, cur, a, b, cG, cH, cLR, w, msc, slo, shi, with_q ? 1 : 0);
 }
 // G_factors / H_factors of the R1CS proof's inner-product argument (prover.rs:689-697): G_i factor 1 for the
 // phase-1 multipliers and u for the rest, H_i factor y^-i times that

@@ -158,7 +158,8 @@ void sc_dot_batched(hipStream_t st, size_t nb, size_t cnt, const Words8 *x, size
 // IPP over resident generators: L/R MSM scalars over the original generators, and the generator fold as a
 // coefficient update (see k_scalar.hip)
 void ipp_gens_scalars(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *a, const Words8 *b,
-                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc);
+                      const Words8 *cG, const Words8 *cH, const Words8 *cLR, const Words8 *w, Words8 *msc, size_t slo = 0,
+                      size_t shi = (size_t)-1, bool with_q = true);
 void ipp_r1cs_factors(hipStream_t st, size_t nb, size_t np, size_t n1, const Words8 *u, const Words8 *y_inv, Words8 *cG,
                       Words8 *cH);
 void ipp_gens_fold(hipStream_t st, size_t nb, size_t n0, size_t cur, const Words8 *u, const Words8 *u_inv, Words8 *cG,
@@ -260,8 +261,13 @@ void blind_vectors(hipStream_t st, const Words8 *keys, size_t nb, size_t cnt, Wo
 // MSM scalar rows of the three commitments A_I, A_O, S of nb provers over [B, B_blinding, G_0.., H_0..] (prover.rs:465-494 /
 // :532-565): rows[(3 p + w) * (2 + 2 n)] for w = 0, 1, 2 from the witness planes (nb x stride, plain canonical; multipliers
 // [lo, n) are live, the rest of a row is zero) and blinds (nb x 3: i, o, s blinding)
+// [slo, shi): the generator indices of THIS rank's share when one large proof is split over the GPUs of a node (the other
+// entries of a row are zero; with_blind: the B_blinding term belongs to one rank only); default = everything
 void commit_rows(hipStream_t st, size_t nb, size_t n, size_t lo, size_t stride, const Words8 *aL, const Words8 *aR, const Words8 *aO,
-                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows);
+                 const Words8 *sL, const Words8 *sR, const Words8 *blinds, Words8 *rows, size_t slo = 0, size_t shi = (size_t)-1,
+                 bool with_blind = true);
+void shard_mask(hipStream_t st, Words8 *fixed, size_t np, size_t slo, size_t shi, bool keep_pedersen, Words8 *var, size_t nvar, size_t vlo,
+                size_t vhi);
 // one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);
 

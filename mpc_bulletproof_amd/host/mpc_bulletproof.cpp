@@ -159,6 +159,14 @@ OsRng::OsRng(bool vector_keys) : vk_(vector_keys) {
   permute_words(st_);
   used_ = 0;
 }
+OsRng::OsRng(const uint8_t key[32], bool vector_keys) : vk_(vector_keys) {
+  memset(st_, 0, sizeof st_);
+  memcpy(st_, key, 32);
+  st_[4] ^= 0x01;
+  st_[16] ^= 0x8000000000000000ULL;
+  permute_words(st_);
+  used_ = 0;
+}
 void OsRng::refill() {
   ++blocks_;
   for (int i = 0; i < 17; i++) st_[i] = 0;   // forget: every block (17 stores against a 24-round permutation)
@@ -1143,11 +1151,43 @@ R1CSProof Prover::prove(const BulletproofGens &bp_gens, Rng &rng) {
 // Lock-step Prover::prove (prover.rs:412-727) for nb provers of circuits with identical constraint rows
 // (1-phase gadgets, or 2-phase ones whose randomized rows happen to coincide): every device call is
 // batched over the provers; only the transcripts run per prover on the host.
+R1CSProof Prover::prove(const BulletproofGens &bp_gens, RankGroup &group, Rng *rng, Device *device) {
+  std::vector<Prover *> ps{this};
+  std::unique_ptr<Rng> own;
+  if (!rng) {   // rank 0's entropy for everyone: the ranks must draw the same blinding factors
+    OsRng seed_src;
+    uint8_t mine[32];
+    for (int i = 0; i < 4; i++) { uint64_t w = seed_src.next_u64(); memcpy(mine + 8 * i, &w, 8); }
+    std::vector<uint8_t> all(32 * group.size());
+    group.all_gather(mine, 32, all.data());
+    own.reset(new OsRng(all.data(), true));
+    rng = own.get();
+  }
+  std::vector<Rng *> rs{rng};
+  return prove_batch(ps, bp_gens, rs, device, &group)[0];
+}
+// partial points of the ranks -> their sums (count points per rank, in place in `mine`)
+static void combine_partials(Device &d, RankGroup &g, uint8_t *mine, size_t count) {
+  const size_t w = g.size();
+  std::vector<uint8_t> all(w * count * 64), col(w * 64);
+  g.all_gather(mine, count * 64, all.data());
+  for (size_t j = 0; j < count; j++) {
+    for (size_t r = 0; r < w; r++) memcpy(&col[64 * r], &all[(r * count + j) * 64], 64);
+    d.check(bpgpu_points_sum(d.ctx(), col.data(), w, mine + 64 * j), "bpgpu_points_sum");
+  }
+}
 std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
-                                           std::vector<Rng *> &rngs, Device *device) {
+                                           std::vector<Rng *> &rngs, Device *device, RankGroup *group) {
   const size_t nb = provers.size();
   if (!nb || rngs.size() != nb) throw std::invalid_argument("prove_batch: one Rng per prover");
   Device &d = device ? *device : Device::default_device();
+  if (group && group->size() <= 1) group = nullptr;
+  if (group && nb != 1) throw std::invalid_argument("prove_batch: a rank group shards ONE proof");
+  struct ShardGuard {      // the context computes this rank's partial sums for the duration of the call
+    Device &d; bool on;
+    ~ShardGuard() { if (on) bpgpu_set_shard(d.ctx(), 0, 1); }
+  } shard_guard{d, group != nullptr};
+  if (group) d.check(bpgpu_set_shard(d.ctx(), group->rank(), group->size()), "bpgpu_set_shard");
   std::vector<CsCore *> cs(nb);
   for (size_t p = 0; p < nb; p++) cs[p] = provers[p]->c_.get();
   const PedersenGens &pc = cs[0]->pc_gens;
@@ -1222,6 +1262,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
                                       vkeys && cnt ? pkey : nullptr, pbl, o.data());
     if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
     d.check(rc, "bpgpu_r1cs_prover_commit");
+    if (group) combine_partials(d, *group, o.data(), 3);
     for (size_t p = 0; p < nb; p++) {
       StarkPoint *dst[3] = {which_phase == 1 ? &proofs[p].A_I1 : &proofs[p].A_I2, which_phase == 1 ? &proofs[p].A_O1 : &proofs[p].A_O2,
                             which_phase == 1 ? &proofs[p].S1 : &proofs[p].S2};
@@ -1365,7 +1406,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   }
   lap("prove: ipp_begin");
   try {
-    if (!getenv("BPH_HOST_IPP_TRANSCRIPT")) {
+    if (!getenv("BPH_HOST_IPP_TRANSCRIPT") && !group) {
       // the k rounds back to back on the device, hash chain included (bpgpu_ipp_run_fs); the host transcripts are
       // advanced to the same state afterwards
       size_t k = 0;
@@ -1389,6 +1430,12 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     std::vector<uint8_t> L(nb * 64), R(nb * 64), ub(nb * 32), uib(nb * 32);
     while (bpgpu_ipp_len(ipp) > 1) {
       d.check(bpgpu_ipp_round(d.ctx(), ipp, L.data(), R.data()), "bpgpu_ipp_round");
+      if (group) {       // this rank's partial L, R -> the sums over the ranks (nb == 1)
+        uint8_t lr[128];
+        memcpy(lr, L.data(), 64); memcpy(lr + 64, R.data(), 64);
+        combine_partials(d, *group, lr, 2);
+        memcpy(L.data(), lr, 64); memcpy(R.data(), lr + 64, 64);
+      }
       parallel_for(nb, [&](size_t p) {
         StarkPoint Lp, Rp;
         memcpy(Lp.xy.data(), &L[64 * p], 64);
@@ -1499,6 +1546,24 @@ Verifier::BatchInputs Verifier::transcript_replay(const R1CSProof &proof, const 
   return in;
 }
 
+void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens, RankGroup &group, Device *device) {
+  if (group.size() <= 1) { verify(proof, bp_gens); return; }
+  CsCore &c = *c_;
+  BatchInputs in = transcript_replay(proof, bp_gens);          // (every rank replays the transcript: sequential hashing, no shares)
+  Device &d = device ? *device : Device::default_device();
+  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+  bpgpu_circuit *circ = c.upload_circuit(in.n, in.m);
+  uint8_t part[64];
+  int rc = bpgpu_r1cs_verify_shard(d.ctx(), gens, circ, in.n1, in.k, in.points.data(), in.scalars.data(), in.challenges.data(), nullptr,
+                                   group.rank(), group.size(), part);
+  bpgpu_circuit_destroy(d.ctx(), circ);
+  if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+  if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+  d.check(rc, "bpgpu_r1cs_verify_shard");
+  combine_partials(d, group, part, 1);
+  memcpy(c.mega.xy.data(), part, 64);
+  if (!c.mega.is_identity()) throw R1CSException(R1CSError::VerificationError);      // :549-551
+}
 void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
   CsCore &c = *c_;
   Lap lap;

@@ -89,6 +89,9 @@ class Rng {
 class OsRng final : public Rng {
  public:
   explicit OsRng(bool vector_keys = true);   // throws std::runtime_error if the OS gives no entropy
+  // the same generator from 32 caller-supplied bytes: the ranks of a sharded proof must draw IDENTICAL blinding factors, so
+  // rank 0's OS entropy is handed to all of them (Prover::prove with a RankGroup does this)
+  OsRng(const uint8_t key[32], bool vector_keys);
   uint64_t next_u64() override;
   void rekey(const uint8_t *material, size_t len) override;
   bool vector_keys() const override { return vk_; }
@@ -122,6 +125,18 @@ struct StarkPoint {
   bool is_identity() const { for (auto c : xy) if (c) return false; return true; }
   bool operator==(const StarkPoint &o) const { return xy == o.xy; }
   bool operator!=(const StarkPoint &o) const { return !(*this == o); }
+};
+
+// ---- RankGroup: the ranks (one process per GPU) that split ONE large proof -- SURVEY 8e.2 -----------
+// The path's only exchange is an all-gather of a few partial points per call (64 bytes each): RCCL over xGMI on a GPU node
+// (torch.distributed "nccl" behind mpc_bulletproof_amd/sharding.py's callback), gloo in the CPU-rendezvous tests.
+class RankGroup {
+ public:
+  virtual ~RankGroup() {}
+  virtual size_t rank() const = 0;
+  virtual size_t size() const = 0;
+  // every rank contributes `bytes` bytes; `out` receives size() x bytes in rank order, on every rank
+  virtual void all_gather(const uint8_t *mine, size_t bytes, uint8_t *out) = 0;
 };
 
 // ---- Device: owns the bpgpu context --------------------------------------------------------------
@@ -353,7 +368,12 @@ class Prover : public RandomizedConstraintSystem {
   // Device of its own: while one thread waits for its batch's kernels the other builds, packs and hashes the next batch, and
   // the kernels of the two overlap on the GPU (tests/host/capi.cpp bph_range_prove_stream; bench.py r1cs_prove).
   static std::vector<R1CSProof> prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
-                                            std::vector<Rng *> &rngs, Device *device = nullptr);
+                                            std::vector<Rng *> &rngs, Device *device = nullptr, RankGroup *group = nullptr);
+  // ONE large proof split over the ranks of `group` (BASELINE configs[3]): every rank holds the same prover (same
+  // witness, same transcript) and calls this; each computes the multi-scalar multiplications over its share of the generators,
+  // the partial points are all-gathered and added.  Every rank returns the same proof -- byte for byte the single-GPU one.
+  // Without an Rng the blinding factors come from rank 0's OS entropy, handed to all ranks.
+  R1CSProof prove(const BulletproofGens &bp_gens, RankGroup &group, Rng *rng = nullptr, Device *device = nullptr);
   bool constraints_satisfied() const;                              // :405-409
   Transcript &transcript() override;
   size_t num_constraints() const override;
@@ -375,6 +395,8 @@ class Verifier : public RandomizedConstraintSystem {
   ~Verifier();
   Variable commit(const StarkPoint &commitment);                   // :298-306
   void verify(const R1CSProof &proof, const BulletproofGens &bp_gens);   // :393-554; throws R1CSException
+  // the same with the mega_check's 13 + m + 2n + 2 lg n terms split over the ranks of `group` (every rank gets the verdict)
+  void verify(const R1CSProof &proof, const BulletproofGens &bp_gens, RankGroup &group, Device *device = nullptr);
   // The host half of verify(): the transcript replay (verifier.rs:398-455,506; inner_product_proof.rs:259-278) and
   // the operand layout of bpgpu_r1cs_verify_batch -- what a service that batches many proofs of one circuit
   // collects per proof.  Throws like verify() on identity points / bad lengths.

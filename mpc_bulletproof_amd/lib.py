@@ -7,7 +7,7 @@ SO_PATH = os.path.join(_HERE, "libbpgpu.so")
 
 SYMBOLS = [
     "bpgpu_device_count", "bpgpu_create", "bpgpu_destroy", "bpgpu_strerror", "bpgpu_last_error", "bpgpu_sync",
-    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_set_option", "bpgpu_get_option", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_profile_epoch", "bpgpu_profile_intervals", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
+    "bpgpu_stream", "bpgpu_set_latency_mode", "bpgpu_set_shard", "bpgpu_r1cs_verify_shard", "bpgpu_set_option", "bpgpu_get_option", "bpgpu_input_flag", "bpgpu_profile_enable", "bpgpu_profile_select", "bpgpu_profile_read", "bpgpu_profile_epoch", "bpgpu_profile_intervals", "bpgpu_malloc", "bpgpu_free", "bpgpu_upload", "bpgpu_download", "bpgpu_upload_async", "bpgpu_download_async", "bpgpu_host_alloc", "bpgpu_host_free",
     "bpgpu_batch_inverse", "bpgpu_inner_product", "bpgpu_msm", "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_points_sum", "bpgpu_msm_ark", "bpgpu_scalars_from_ark", "bpgpu_scalars_to_ark", "bpgpu_points_from_ark", "bpgpu_points_to_ark", "bpgpu_msm_shared", "bpgpu_points_decompress", "bpgpu_points_compress", "bpgpu_gens_create",
     "bpgpu_gens_destroy", "bpgpu_gens_capacity", "bpgpu_msm_gens", "bpgpu_msm_gens_ark", "bpgpu_fold_witness",
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
@@ -536,6 +536,18 @@ class BpGpu:
     def r1cs_verify_combined_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_rho, d_out):
         self._ck(_lib.bpgpu_r1cs_verify_combined_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                      d_points, d_scalars, d_challenges, d_rho, d_out))
+
+    def set_shard(self, rank, world):
+        """this context's share of ONE large proof split over the GPUs of a node (include/bpgpu.h bpgpu_set_shard)"""
+        self._ck(_lib.bpgpu_set_shard(self.ctx, C.c_size_t(rank), C.c_size_t(world)))
+
+    def r1cs_verify_shard(self, gens, circuit, n1, k, points, scalars, challenges, rank, world, gadget_challenges=None):
+        """rank's partial mega_check point of one proof (64 bytes)"""
+        out = _out(64)
+        self._ck(_lib.bpgpu_r1cs_verify_shard(self.ctx, gens, circuit, C.c_size_t(n1), C.c_size_t(k), _buf(points), _buf(scalars),
+                                              _buf(challenges), _buf(gadget_challenges) if gadget_challenges is not None else None,
+                                              C.c_size_t(rank), C.c_size_t(world), out))
+        return bytes(out)[:64]
 
     def r1cs_verify_stream_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_ok):
         """any number of proofs in one call: batches over the context's ring of lanes (asynchronous; sync() waits for all)"""

@@ -59,6 +59,26 @@ def combine_partial_points(local_point: bytes, points_sum, group=None) -> bytes:
     return points_sum(b"".join(allgather_bytes(local_point, group)))
 
 
+# ---- the all-gather a native RankGroup needs (host mirror: mpc_bulletproof::RankGroup; harness: bph_allgather_fn) -----------------
+import ctypes as _C
+
+ALLGATHER_FN = _C.CFUNCTYPE(None, _C.POINTER(_C.c_uint8), _C.c_size_t, _C.POINTER(_C.c_uint8), _C.c_void_p)
+
+
+def allgather_callback(group=None):
+    """A C callback `void f(const uint8_t *mine, size_t bytes, uint8_t *out, void *user)` over torch.distributed: every rank
+    contributes `bytes` bytes, `out` receives world x bytes in rank order (backend "nccl" = RCCL over xGMI on a GPU node: the byte
+    carrier is a device tensor; "gloo": a CPU tensor).  Keep the returned object alive while native code may call it."""
+    def cb(mine, nbytes, out, user):
+        world = dist.get_world_size(group)
+        t = torch.frombuffer(bytearray(_C.string_at(mine, nbytes)), dtype=torch.uint8).to(_device())
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t, group=group)
+        data = b"".join(o.cpu().numpy().tobytes() for o in outs)
+        _C.memmove(out, data, len(data))
+    return ALLGATHER_FN(cb)
+
+
 def sharded_msm(scalars: bytes, points: bytes, msm_fn, points_sum, group=None) -> bytes:
     """One LARGE multi-scalar multiplication split by term range (the 98 347-term mega_check of
     the 2^14-shuffle): rank r computes the sum over its contiguous slice with `msm_fn(scalars, points) -> 64 B`

@@ -418,6 +418,81 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
   })
 }
 
+// The same proof split over the ranks of a group: every rank (process) calls this with the same inputs and its own
+// rank; `allgather(mine, bytes, out, user)` must gather `bytes` bytes from every rank into out[world x bytes] in rank order
+// (torch.distributed behind a ctypes callback in the tests and in bench.py).  Every rank returns the same proof and verdict.
+typedef void (*bph_allgather_fn)(const uint8_t *mine, size_t bytes, uint8_t *out, void *user);
+namespace {
+struct CallbackGroup final : RankGroup {
+  size_t r, w; bph_allgather_fn fn; void *user;
+  CallbackGroup(size_t r_, size_t w_, bph_allgather_fn f, void *u) : r(r_), w(w_), fn(f), user(u) {}
+  size_t rank() const override { return r; }
+  size_t size() const override { return w; }
+  void all_gather(const uint8_t *mine, size_t bytes, uint8_t *out) override { fn(mine, bytes, out, user); }
+};
+}  // namespace
+int bph_shuffle_prove_verify_sharded(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, size_t rank, size_t world,
+                                     bph_allgather_fn allgather, void *user, uint8_t *proof_out, size_t *proof_len,
+                                     uint8_t *commitments_out, double ms[6]) {
+  GUARD({
+    if (!world || rank >= world || !allgather) return -3;
+    auto T0 = std::chrono::steady_clock::now();
+    int li = 0;
+    auto lap = [&]() {
+      auto t = std::chrono::steady_clock::now();
+      ms[li++] = std::chrono::duration<double, std::milli>(t - T0).count();
+      T0 = t;
+    };
+    CallbackGroup group(rank, world, allgather, user);
+    const char *label = "ShuffleProofTest";
+    PedersenGens pc_gens;
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
+    lap();
+    // the Pedersen blindings of the 2k values and the prover's blinding factors: the same stream on every rank (a replayable
+    // seed, or -- BPH_SEED_OS_ENTROPY -- rank 0's OS entropy handed to all of them)
+    std::unique_ptr<Rng> rng_owner;
+    if (seed == BPH_SEED_OS_ENTROPY) {
+      OsRng src;
+      uint8_t mine[32];
+      for (int i = 0; i < 4; i++) { uint64_t w64 = src.next_u64(); memcpy(mine + 8 * i, &w64, 8); }
+      std::vector<uint8_t> all(32 * world);
+      group.all_gather(mine, 32, all.data());
+      rng_owner.reset(new OsRng(all.data(), getenv("BPH_HOST_VECTORS") == nullptr));
+    } else rng_owner = make_rng(seed);
+    Rng &rng = *rng_owner;
+    std::vector<Scalar> vs, bls;
+    for (size_t i = 0; i < 2 * k; i++) { vs.push_back(Scalar::from(values[i])); bls.push_back(rng.scalar()); }
+    auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
+    lap();
+    R1CSProof proof;
+    {
+      Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+      Prover prover(pc_gens, transcript);
+      std::vector<Variable> vars;
+      for (size_t i = 0; i < 2 * k; i++) vars.push_back(prover.commit_precomputed(vs[i], bls[i], Vs[i]));
+      gadgets::shuffle_gadget(prover, std::vector<Variable>(vars.begin(), vars.begin() + k),
+                              std::vector<Variable>(vars.begin() + k, vars.end()));
+      lap();
+      proof = prover.prove(bp_gens, group, &rng);
+      lap();
+    }
+    auto bytes = proof.to_flat_bytes();
+    memcpy(proof_out, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    for (size_t i = 0; i < 2 * k; i++) memcpy(commitments_out + 64 * i, Vs[i].xy.data(), 64);
+    Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+    Verifier verifier(pc_gens, transcript);
+    std::vector<Variable> vars;
+    for (size_t i = 0; i < 2 * k; i++) vars.push_back(verifier.commit(Vs[i]));
+    gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + k),
+                            std::vector<Variable>(vars.begin() + k, vars.end()));
+    lap();
+    verifier.verify(proof, bp_gens, group);
+    lap();
+    return 0;
+  })
+}
+
 // Operands of bpgpu_r1cs_verify_batch for nb proofs of the n_bits range gadget (m = 1), produced by the host mirror:
 // transcript replay per proof (parallel over proofs), the circuit's CSR rows (buffers sized by the caller:
 // row_ptr 2 n_bits + 2, kind/idx 8 n_bits + 8 entries, coeff 32 x that), dims = n1, n, k, m, q, nnz, and the

@@ -23,7 +23,7 @@ def main():
     gpu = m.BpGpu(0)
     try:
         sc = o.random_scalars(4100, n_terms)
-        pts = ((o.gens("G", 512) + o.gens("H", 512)) * 3)[:64 * n_terms]
+        pts = ((o.gens("G", 512) + o.gens("H", 512)) * ((n_terms + 1023) // 1024))[:64 * n_terms]
         big_host = sh.sharded_msm(sc, pts, gpu.msm, gpu.points_sum)
         d_sc, d_pts, d_out = gpu.to_device(sc), gpu.to_device(pts), gpu.malloc(64)
         big_dev = sh.sharded_msm_dev(gpu, d_sc, d_pts, n_terms, d_out)
@@ -69,9 +69,35 @@ def main():
             Gf, Hf, w = o.scalars([1] * (n_ipp // 2) + [7] * (n_ipp - n_ipp // 2)), o.random_scalars(54, n_ipp), o.random_scalars(55, 1)
             Ls, Rs, aa, bb = sh.sharded_ipp_create(gpu, Tr(n_ipp), n_ipp, w, B, Gf, Hf, Gp, Hp, av, bv)
             ipp[str(n_ipp)] = {"L": b"".join(Ls).hex(), "R": b"".join(Rs).hex(), "a": aa.hex(), "b": bb.hex()}
+        # ONE proof split over the ranks through the host mirror (Prover::prove / Verifier::verify with a RankGroup): the k-shuffle
+        # gadget; at k = 2^14 this is BASELINE configs[3] at full size (n+ = 2^15 generators per side, a 98 347-term mega_check)
+        shuffle = {}
+        if len(sys.argv) > 5:
+            import ctypes as C
+            import random
+            host = C.CDLL(os.path.join(HERE, "host", "libbph_capi.so"))
+            cb = sh.allgather_callback()
+            for lg in [int(x) for x in sys.argv[5].split(",")]:
+                ks = 1 << lg
+                rnd = random.Random(1000 + lg)
+                xs = [rnd.getrandbits(64) for _ in range(ks)]
+                ys = list(xs)
+                rnd.shuffle(ys)
+                cap = max(2, 1 << (2 * (ks - 1) - 1).bit_length()) if ks > 1 else 2
+                arr = (C.c_uint64 * (2 * ks))(*(xs + ys))
+                proof, plen, com, ms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+                rc = host.bph_shuffle_prove_verify_sharded(C.c_size_t(ks), arr, C.c_uint64(4242 + lg), C.c_size_t(cap), C.c_size_t(rank), C.c_size_t(world),
+                                                           cb, None, proof, C.byref(plen), com, ms)
+                bad = list(ys)
+                bad[3] ^= 1                                     # not a permutation any more: the sharded verifier must reject on every rank
+                arr_bad = (C.c_uint64 * (2 * ks))(*(xs + bad))
+                p2, l2, c2, m2 = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+                rc_bad = host.bph_shuffle_prove_verify_sharded(C.c_size_t(ks), arr_bad, C.c_uint64(4242 + lg), C.c_size_t(cap), C.c_size_t(rank),
+                                                               C.c_size_t(world), cb, None, p2, C.byref(l2), c2, m2)
+                shuffle[str(lg)] = {"rc": rc, "rc_bad": rc_bad, "proof": bytes(proof)[:plen.value].hex(), "prove_ms": ms[3], "verify_ms": ms[5]}
         with open(f"{out_prefix}.{rank}", "w") as f:
             json.dump({"big_host": big_host.hex(), "big_dev": big_dev.hex(), "ok": full_ok, "comb": comb.hex(), "tmax": tmax,
-                       "lo": lo, "hi": hi, "ipp": ipp}, f)
+                       "lo": lo, "hi": hi, "ipp": ipp, "shuffle": shuffle}, f)
     finally:
         gpu.close()
         dist.destroy_process_group()

@@ -83,6 +83,41 @@ def test_sharded_msm_and_combined_check_two_ranks_one_gpu(tmp_path):
             assert (got["L"], got["R"], got["a"], got["b"]) == (L.hex(), R.hex(), ao.hex(), bo.hex()), n_ipp
 
 
+def test_one_proof_sharded_over_two_ranks_full_size(tmp_path):
+    """BASELINE configs[3] in its sharded form, at full size, through the host mirror: the k-shuffle proof (k = 2^4 and 2^14:
+    65 533 constraints, 2^15 generators per side, a 98 347-term mega_check) proved and verified by TWO rank processes on one GPU
+    (gloo all-gathers of the partial points; RCCL needs a GPU per rank), every multi-scalar multiplication split by generator /
+    point range.  Both ranks return the single-process proof byte for byte and accept it; a non-permutation is rejected on both.
+    The 98 347-term MSM itself, split by term range with the operands resident (sharded_msm_dev), equals the oracle-free identity."""
+    import ctypes as C
+    import random
+    world = 2
+    prefix = str(tmp_path / "rank")
+    _run_ranks(tmp_path, world, [prefix, "98347", "8", "9", "4,14"], _free_port(), timeout=900)
+    res = [json.load(open(f"{prefix}.{r}")) for r in range(world)]
+    Gp, Gd = o.gens("G", 512, dlogs=True)
+    Hp, Hd = o.gens("H", 512, dlogs=True)
+    sc = o.random_scalars(4100, 98347)
+    dl = ((Gd + Hd) * 97)[:32 * 98347]
+    want = o.point_mul(o.inner_product(sc, dl), o.generator()).hex()         # MSM(s_i, k_i G) = (sum s_i k_i) G
+    assert all(r["big_host"] == want and r["big_dev"] == want for r in res)
+    host = C.CDLL(os.path.join(HERE, "host", "libbph_capi.so"))
+    for lg in (4, 14):
+        ks = 1 << lg
+        rnd = random.Random(1000 + lg)
+        xs = [rnd.getrandbits(64) for _ in range(ks)]
+        ys = list(xs)
+        rnd.shuffle(ys)
+        cap = max(2, 1 << (2 * (ks - 1) - 1).bit_length())
+        arr = (C.c_uint64 * (2 * ks))(*(xs + ys))
+        proof, plen, com, ms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+        assert host.bph_shuffle_prove_verify(C.c_size_t(ks), arr, C.c_uint64(4242 + lg), C.c_size_t(cap), proof, C.byref(plen), com, ms) == 0
+        single = bytes(proof)[:plen.value].hex()
+        for r in res:
+            s = r["shuffle"][str(lg)]
+            assert s["rc"] == 0 and s["rc_bad"] != 0 and s["proof"] == single, (lg, s["rc"], s["rc_bad"])
+
+
 def test_points_sum(gpu_ctx):
     G = o.generator()
     pts = [o.point_mul(o.s2b(k), G) for k in (3, 5, 11)] + [bytes(64), o.point_mul(o.s2b(o.N - 3), G)]
