@@ -721,6 +721,38 @@ def main():
                        "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "circuit_building_ms": med[4]},
                        "note": "one proof on one GPU, medians of 3; every proof verified (the call fails otherwise); OsRng blinding factors"}
 
+    # ======== N > 1: configs[3] in its sharded form -- ONE 2^14-shuffle proof split over the ranks (every multi-scalar multiplication
+    # by generator / point range, partial points all-gathered over RCCL and added: SURVEY 8e.2), proved and verified on all of them
+    shuffle_sharded = None
+    if world > 1 and not a.no_prover and not os.environ.get("BPGPU_BENCH_NO_SHUFFLE"):
+        import ctypes as C
+        from mpc_bulletproof_amd import sharding
+        host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
+        host.bph_set_device(C.c_int(dev))
+        cb = sharding.allgather_callback()
+        ks = 1 << 14
+        rnd = __import__("random").Random(77)
+        xs = [rnd.getrandbits(64) for _ in range(ks)]
+        ys = list(xs)
+        rnd.shuffle(ys)
+        sarr = (C.c_uint64 * (2 * ks))(*(xs + ys))
+        sproof, splen, scom, sms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+        runs = []
+        for rep in range(4):
+            fence()
+            rc = host.bph_shuffle_prove_verify_sharded(C.c_size_t(ks), sarr, C.c_uint64((1 << 64) - 1), C.c_size_t(1 << 15), C.c_size_t(rank), C.c_size_t(world),
+                                                       cb, None, sproof, C.byref(splen), scom, sms)
+            assert rc == 0, f"bph_shuffle_prove_verify_sharded rc={rc} on rank {rank}"
+            if rep:
+                runs.append([sharding.max_over_ranks(x) for x in sms])
+        med = [sorted(r[i] for r in runs)[1] for i in range(6)]
+        qs = 4 * (ks - 1) + 1
+        shuffle_sharded = {"ranks": world, "workload": f"ONE k-shuffle proof, k = 2^14 (q = {qs} constraints, 2^15 generators per side, a 98 347-term mega_check), "
+                                                       "split over the ranks by generator / point range",
+                           "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3]},
+                           "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5]},
+                           "note": "max over ranks, medians of 3; latency-bound: 15 IPP rounds, each with an all-gather of two 64-byte partial points and a host hash"}
+
     if pool is not None:
         pool.close()
         pool.join()
@@ -827,6 +859,7 @@ def main():
             "combined_batch_check": comb,
             "r1cs_prove": prove,
             "shuffle_2e14": shuffle,
+            "shuffle_2e14_sharded": shuffle_sharded,
             "range_prove": ({"value": nb / wl["prove_seconds"], "unit": "64-bit range proofs/s", "ms_per_batch": wl["prove_seconds"] * 1e3,
                              "note": f"the {nb} proofs of this workload, proved in lock-step by the GPU prover while it was generated "
                                      "(wall clock incl. host circuit building and transcripts)"} if wl.get("prove_seconds") else None),

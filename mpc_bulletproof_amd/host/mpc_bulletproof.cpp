@@ -378,7 +378,9 @@ Device::Device(int index) {
   if (rc) throw DeviceException(rc, std::string("bpgpu_create: ") + bpgpu_strerror(rc));
 }
 Device::~Device() { bpgpu_destroy(ctx_); }
-Device &Device::default_device() { static Device d(0); return d; }
+static int g_default_device_index = 0;
+void Device::set_default_index(int index) { g_default_device_index = index; }
+Device &Device::default_device() { static Device d(g_default_device_index); return d; }
 void Device::check(int rc, const char *what) const {
   if (rc) throw DeviceException(rc, std::string(what) + ": " + bpgpu_strerror(rc) + " | " + bpgpu_last_error(ctx_));
 }

@@ -147,7 +147,9 @@ class Device {
   Device(const Device &) = delete;
   Device &operator=(const Device &) = delete;
   bpgpu_ctx *ctx() const { return ctx_; }
-  static Device &default_device();   // lazily created device 0
+  static Device &default_device();   // lazily created; device 0 unless set_default_index was called first
+  // one process per GPU: a rank selects its GPU (its local rank) before the first use of the default device
+  static void set_default_index(int index);
   void check(int rc, const char *what) const;
   // StarkPoint::msm_iter / msm
   StarkPoint msm(const std::vector<Scalar> &scalars, const std::vector<StarkPoint> &points) const;

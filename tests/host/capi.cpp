@@ -78,6 +78,8 @@ extern "C" {
 #pragma GCC visibility push(default)
 
 void bph_set_seeded_vector_keys(int on) { g_seeded_vector_keys = on != 0; }
+// one process per GPU: the rank's device index, before anything else touches the default device
+void bph_set_device(int index) { Device::set_default_index(index); }
 
 int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_len, const uint64_t *values,
                    size_t nvalues, uint64_t seed, size_t gens_capacity, uint8_t *proof_out, size_t *proof_len,

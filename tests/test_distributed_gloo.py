@@ -54,7 +54,13 @@ def _worker(rank, world, port, n_bits, nb, q):
         # one large MSM split by term range; 37 terms -> uneven slices
         sc, pts = o.random_scalars(91, 37), (o.gens("G", 32) + o.gens("H", 32))[:64 * 37]
         big = sh.sharded_msm(sc, pts, o.msm, _points_sum)
-        q.put((rank, lo, hi, full, total_pt, tmax, big))
+        # the all-gather callback a native RankGroup calls (host mirror: Prover::prove / Verifier::verify with a rank group)
+        import ctypes as C
+        cb = sh.allgather_callback()
+        mine = (C.c_uint8 * 96)(*([rank + 1] * 96))
+        out = (C.c_uint8 * (96 * world))()
+        cb(mine, 96, out, None)
+        q.put((rank, lo, hi, full, total_pt, tmax, big, bytes(out)))
     finally:
         dist.destroy_process_group()
 
@@ -93,6 +99,7 @@ def test_sharded_verification_gloo_world2():
     assert res[0][5] == res[1][5] == 2.0
     sc, pts = o.random_scalars(91, 37), (o.gens("G", 32) + o.gens("H", 32))[:64 * 37]
     assert res[0][6] == res[1][6] == o.msm(sc, pts)
+    assert res[0][7] == res[1][7] == bytes([1] * 96 + [2] * 96)
 
 
 def test_shard_bounds_cover_everything():
