@@ -1252,11 +1252,13 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     int32_t *aux = nullptr;
     size_t aux_stride = 0;
     const bool fuse_prep = verify_scalars_aux(circuit_dev(c), d, (int32_t *)dzp, &aux, &aux_stride);
+    const bool fast = fuse_prep && verify_scalars_fast_shape(circuit_dev(c), d);   // wave-sized proofs: the serial part of the assembly in the front launch's lanes
     { ProfScope ps(ctx, 8, ctx->st);
-      verify_wp_front_launch(ctx->st, v, d, (const Words8 *)challenges, aux, aux_stride, fuse_prep); }
+      verify_wp_front_launch(ctx->st, v, d, (const Words8 *)challenges, aux, aux_stride, fuse_prep, fast ? (const Words8 *)scalars : nullptr,
+                             fast ? (Words8 *)dfix : nullptr, fast ? (Words8 *)dvar : nullptr, fast ? (Words8 *)full_sc : nullptr); }
     { ProfScope ps(ctx, 0, ctx->st);
       verify_scalars(ctx->st, circuit_dev(c), d, (const Words8 *)challenges, (const Words8 *)scalars, (Words8 *)dfix,
-                     (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc, fuse_prep); }
+                     (Words8 *)dvar, (Words8 *)full_sc, (int32_t *)dzp, ctx->d_flag, (int32_t *)dbadsc, fuse_prep, fast); }
     if (shard) {   // a small proof: the other ranks' terms are simply zeroed
       size_t slo, shi, vlo, vhi;
       shard_bounds(np, shard[0], shard[1], &slo, &shi);

@@ -472,8 +472,10 @@ static WpLayout wp_layout(const VerifyWp &v) {
 bool verify_wp_layout_fits(const VerifyWp &v) { return wp_layout(v).bytes <= verify_wp_scratch_bytes(v.nb, v.nvar); }
 // tables of the proof points | inversion pass of the scalar assembly (with_prep = false: tables only)
 void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
-                            size_t aux_stride, bool with_prep) {
+                            size_t aux_stride, bool with_prep, const Words8 *fast_proof_scalars, Words8 *fast_fixed_sc, Words8 *fast_var_sc,
+                            Words8 *fast_full_sc) {
   VsPrepArgs prep{d, challenges, aux, aux_stride};
+  prep.proof_scalars = fast_proof_scalars; prep.fixed_sc = fast_fixed_sc; prep.var_sc = fast_var_sc; prep.full_sc = fast_full_sc;
   if (!with_prep) prep.d.nb = 0;
   WpLayout L = wp_layout(v);
   const unsigned pb = (unsigned)((prep.d.nb + 63) / 64);

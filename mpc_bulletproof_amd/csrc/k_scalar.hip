@@ -755,6 +755,105 @@ __global__ void __launch_bounds__(VS_TPB) k_verify_scalars(CircuitDev c, VerifyD
     }
   }
 }
+// The same for WAVE-SIZED proofs (padded n = 64, k = 6) after the lane-per-proof pass has done everything serial (vs_prep.cuh,
+// fast path): this kernel is left with ~25 wave-wide products per proof instead of ~85 -- one per table look-up (y^-i, s_i, z^(r+1)),
+// the flattening, g_i / h_i, delta and w_c, V_j and B.  Values are kept in the domain (plain / Montgomery) that makes every output a
+// plain value without a conversion product (see vs_prep.cuh).
+__global__ void __launch_bounds__(VS_TPB) k_verify_scalars_fast(CircuitDev c, VerifyDims d, const Words8 *challenges,
+                                                                const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc,
+                                                                Words8 *full_sc, int32_t *zpow_all, const int32_t *aux_all, int *bad,
+                                                                int32_t *bad_proof) {
+  __shared__ int32_t sm[VS_AUX * NL];
+  __shared__ int32_t stab[64 * NL], s_part[2 * NL];
+  __builtin_amdgcn_s_setprio(2);
+  const size_t p = blockIdx.x;
+  const int tid = threadIdx.x;
+  const size_t k = 6, n = d.n, np = 64, m = d.m, n1 = d.n1;
+  const Words8 *ch = challenges + p * (6 + k);
+  const Words8 *ps = proof_scalars + p * 5;
+  int32_t *zpow = zpow_all + p * c.qz * NL;
+  for (int t = tid; t < VS_AUX * NL; t += VS_TPB) sm[t] = aux_all[p * VS_AUX * NL + t];
+  if (bad || bad_proof) {   // canonical-encoding check of this proof's 6 + k challenges and 5 scalars
+    bool mine = false;
+    for (size_t t = tid; t < 11 + k; t += VS_TPB) {
+      const Words8 *src = t < 6 + k ? &ch[t] : &ps[t - 6 - k];
+      uint32_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = src->w[j];
+      if (!words_lt_mod<FN>(w)) mine = true;
+    }
+    const bool any = __any(mine);
+    if (tid == 0) {
+      if (any && bad) atomicOr(bad, 1);
+      if (bad_proof) bad_proof[p] = any ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  {   // z^(r+1), plain (verifier.rs:336,358): one table product, then steps of z^64
+    Fn cur = mul(raw_get(sm + (VSF_Z1 + (tid & 7)) * NL), raw_get(sm + (VSF_Z2 + (tid >> 3)) * NL));
+    const Fn z64 = raw_get(sm + VSF_Z64 * NL);
+    for (size_t r = tid; r < c.q; r += VS_TPB) {
+      raw_put(zpow + r * NL, cur);
+      if (r + VS_TPB < c.q) cur = mul(cur, z64);
+    }
+  }
+  const Fn yi = mul(raw_get(sm + (VSF_Y1 + (tid & 7)) * NL), raw_get(sm + (VSF_Y2 + (tid >> 3)) * NL));     // M(y^-i)
+  const Fn si = mul(raw_get(sm + (VSF_S1 + (tid & 7)) * NL), raw_get(sm + (VSF_S2 + (tid >> 3)) * NL));     // P(s_i)
+  raw_put(stab + tid * NL, si);
+  __syncthreads();           // the z-power table (global) and the s table (LDS) are complete
+  const Fn sr = raw_get(stab + (VS_TPB - 1 - tid) * NL);
+  const Fn xm = raw_get(sm + VSF_X * NL), um = raw_get(sm + VSF_U * NL), am = raw_get(sm + VSF_A * NL), bm = raw_get(sm + VSF_B * NL);
+  const size_t nvar = 11 + m + 2 * k, nterms = 13 + m + 2 * np + 2 * k;
+  Words8 *fx = fixed_sc + p * (2 + 2 * np);
+  Words8 *vs = var_sc + p * nvar;
+  Words8 *full = full_sc ? full_sc + p * nterms : nullptr;
+  const size_t off_g = 13 + m, off_h = 13 + m + np, i = tid;
+  Fn one_p = fe_zero<FN>();
+  one_p.v[0] = 1;
+  Fn wLi = fe_zero<FN>(), wRi = fe_zero<FN>(), wOi = fe_zero<FN>();
+  if (i < n) {                                           // plain: Montgomery coefficients x plain z powers
+    wLi = flatten_column(c, i, zpow);
+    wRi = flatten_column(c, n + i, zpow);
+    wOi = flatten_column(c, 2 * n + i, zpow);
+  }
+  const Fn yneg_wR = mul(wRi, yi);                                                       // P, verifier.rs:472-477
+  Fn dpart = mul(yneg_wR, wLi);                                                          // delta_i / R (two plain factors)
+  Fn g = sub(mul(xm, yneg_wR), mul(am, si));                                             // P, verifier.rs:487-491
+  Fn h = sub(mul(yi, sub(add(mul(xm, wLi), wOi), mul(bm, sr))), one_p);                  // P, verifier.rs:493-501
+  if (i >= n1) { g = mul(um, g); h = mul(um, h); }
+  vs_store_p(&fx[2 + i], g);
+  vs_store_p(&fx[2 + np + i], h);
+  if (full) { vs_store_p(&full[off_g + i], g); vs_store_p(&full[off_h + i], h); }
+  Fn wcp = fe_zero<FN>();                                                                // w_c (plain): the `One` column, verifier.rs:352-354
+  {
+    const size_t o = 3 * n + m;
+    int cnt = 0;
+    for (uint32_t t = c.col_ptr[o] + tid; t < c.col_ptr[o + 1]; t += VS_TPB) {
+      uint32_t w[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) w[j] = c.coeff[t].w[j];
+      wcp = add(wcp, mul(unpack<FN>(w), raw_get(zpow + (size_t)c.row[t] * NL)));
+      if ((++cnt & 15) == 0) wcp = fn_reduce(wcp);
+    }
+  }
+  dpart = wave_sum(fn_reduce(dpart));
+  wcp = wave_sum(fn_reduce(wcp));
+  if (tid == 0) { raw_put(s_part, fn_reduce(dpart)); raw_put(s_part + NL, fn_reduce(wcp)); }
+  __syncthreads();
+  // V_j (one lane each) and B (verifier.rs:508-532); everything else was written by the lane-per-proof pass
+  const Fn c1m = raw_get(sm + VSF_C1 * NL);
+  for (size_t v = tid; v < m + 1; v += VS_TPB) {
+    Fn val;
+    if (v < m) val = mul(c1m, flatten_column(c, 3 * n + v, zpow));                       // wV_j r x^2
+    else {
+      const Fn delta = mul(raw_get(s_part), fe_r2<FN>());                                // (delta / R) R^2 / R = delta, plain
+      const Fn wc = neg(raw_get(s_part + NL));
+      val = add(raw_get(sm + VSF_C0 * NL), mul(c1m, add(wc, delta)));
+    }
+    if (v < m) { vs_store_p(&vs[6 + v], val); if (full) vs_store_p(&full[6 + v], val); }
+    else { vs_store_p(&fx[0], val); if (full) vs_store_p(&full[11 + m], val); }
+  }
+}
 // ---- the same assembly for LARGE proofs, split over the grid (one proof of the 2^14-shuffle has padded_n = 2^15,
 // q = 65 533, m = 32 768: a single block per proof would serialise ~10^5 field multiplications per lane).
 // aux per proof (NL ints each): 0 y_inv, 1 allinv, 2.. u_sq[32], 34.. u_inv_sq[32], 66.. delta partials[VSL_PARTS],
@@ -890,6 +989,7 @@ __global__ void __launch_bounds__(VSL_TPB) k_vsl_tail(CircuitDev c, VerifyDims d
   if (full) store_plain(&full[fpos], val);
 }
 
+bool verify_scalars_fast_shape(const CircuitDev &c, const VerifyDims &d) { return vs_fast_shape(d) && c.nchi == 0 && d.m <= 64; }
 static bool vs_large(const CircuitDev &c, const VerifyDims &d) {
   const size_t thr = d.vs_large_min ? d.vs_large_min : 4096;
   return d.padded_n >= thr || d.m >= thr || c.q >= 4 * thr;
@@ -905,13 +1005,22 @@ bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_
 }
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
-                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof, bool prep_done) {
+                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof, bool prep_done, bool prep_fast) {
   if (!d.nb) return;
   int32_t *aux = zpow_scratch + d.nb * (c.qz ? c.qz : 1) * NL;
   if (!vs_large(c, d)) {
-    if (!prep_done) hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, VsPrepArgs{d, challenges, aux, (size_t)VS_AUX});
-    hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
-                       fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad, bad_proof);
+    // wave-sized proofs: the lane-per-proof pass also does the serial part of the assembly (vs_prep.cuh) -- when it runs here, or
+    // when the caller's fused front launch has run it with the output arrays (prep_fast)
+    const bool fast = vs_fast_shape(d) && c.nchi == 0 && d.m <= 64 && (!prep_done || prep_fast);
+    if (!prep_done) {
+      VsPrepArgs pa{d, challenges, aux, (size_t)VS_AUX};
+      if (fast) { pa.proof_scalars = proof_scalars; pa.fixed_sc = fixed_sc; pa.var_sc = var_sc; pa.full_sc = full_sc; }
+      hipLaunchKernelGGL(k_vs_prep, dim3((d.nb + 63) / 64), dim3(64), 0, st, pa);
+    }
+    if (fast) hipLaunchKernelGGL(k_verify_scalars_fast, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
+                                 fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad, bad_proof);
+    else hipLaunchKernelGGL(k_verify_scalars, dim3(d.nb), dim3(VS_TPB), 0, st, c, d, challenges, proof_scalars,
+                            fixed_sc, var_sc, full_sc, zpow_scratch, aux, bad, bad_proof);
     return;
   }
   if (bad_proof) {

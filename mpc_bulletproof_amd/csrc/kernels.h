@@ -72,8 +72,10 @@ bool verify_wp_supported(size_t nb, size_t nvar, int c, size_t n);
 // not become an out-of-bounds write on the device, nor end the host process.
 bool verify_wp_layout_fits(const VerifyWp &v);
 // prep_* describe the inversion pass to fuse (vs_prep.cuh; prep_nb == 0: tables only)
+// fast_* (all set): the inversion pass also does the serial part of a wave-sized proof's scalar assembly (vs_prep.cuh)
 void verify_wp_front_launch(hipStream_t st, const VerifyWp &v, const VerifyDims &d, const Words8 *challenges, int32_t *aux,
-                            size_t aux_stride, bool with_prep);
+                            size_t aux_stride, bool with_prep, const Words8 *fast_proof_scalars = nullptr, Words8 *fast_fixed_sc = nullptr,
+                            Words8 *fast_var_sc = nullptr, Words8 *fast_full_sc = nullptr);
 void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_scalars);
 void verify_wp_groups(hipStream_t st, const VerifyWp &v);
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
@@ -228,7 +230,10 @@ size_t verify_scalars_scratch_ints(const CircuitDev &c, const VerifyDims &d);
 //   prep_done: the inversion pass (vs_prep.cuh) has already run into the aux area of zpow_scratch (verify_scalars_aux)
 void verify_scalars(hipStream_t st, const CircuitDev &c, const VerifyDims &d, const Words8 *challenges,
                     const Words8 *proof_scalars, Words8 *fixed_sc, Words8 *var_sc, Words8 *full_sc,
-                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof = nullptr, bool prep_done = false);
+                    int32_t *zpow_scratch, int *bad, int32_t *bad_proof = nullptr, bool prep_done = false, bool prep_fast = false);
+// wave-sized proofs (padded n = 64): the inversion pass can also do the serial part of the assembly when it is given the proof
+// scalars and the output arrays (vs_prep.cuh); prep_fast tells verify_scalars that the caller's fused launch has done so
+bool verify_scalars_fast_shape(const CircuitDev &c, const VerifyDims &d);
 // where the inversion pass writes (inside zpow_scratch) and its per-proof stride in field elements; false = the large-proof
 // path, which runs its own inversion pass
 bool verify_scalars_aux(const CircuitDev &c, const VerifyDims &d, int32_t *zpow_scratch, int32_t **aux, size_t *aux_stride);
