@@ -437,12 +437,15 @@ void verify_combined2(hipStream_t st, const CombinedArgs &a) {
   int32_t *aux = nullptr;
   size_t aux_stride = 0;
   const bool fuse_prep = verify_scalars_aux(a.circ, a.d, a.zpow_scratch, &aux, &aux_stride);
-  CombFront cf{a.points, dpts, tot, a.bad, VsPrepArgs{a.d, a.challenges, aux, aux_stride}, p.counts, p.nbk + 1,
+  const bool fast = fuse_prep && verify_scalars_fast_shape(a.circ, a.d);   // wave-sized proofs: the serial part of the assembly in the front launch's lanes
+  VsPrepArgs prep{a.d, a.challenges, aux, aux_stride};
+  if (fast) { prep.proof_scalars = a.proof_scalars; prep.fixed_sc = a.fixed_sc; prep.var_sc = a.var_sc; }
+  CombFront cf{a.points, dpts, tot, a.bad, prep, p.counts, p.nbk + 1,
                (unsigned)((tot + 255) / 256), fuse_prep ? (unsigned)((a.d.nb + 255) / 256) : 0u};
   { ProfMark pm(a.prof, a.prof_ctx, 12, st);
     hipLaunchKernelGGL(k_comb_front, dim3(cf.pb + cf.vb + (unsigned)((p.nbk + 1 + 255) / 256)), dim3(256), 0, st, cf);
     // 2 scalars (canonicity of the challenges / proof scalars is checked inside; rho in K1)
-    verify_scalars(st, a.circ, a.d, a.challenges, a.proof_scalars, a.fixed_sc, a.var_sc, nullptr, a.zpow_scratch, a.bad, nullptr, fuse_prep);
+    verify_scalars(st, a.circ, a.d, a.challenges, a.proof_scalars, a.fixed_sc, a.var_sc, nullptr, a.zpow_scratch, a.bad, nullptr, fuse_prep, fast);
     // 3 K1
     CombColsum cs{a.fixed_sc, a.rho, a.d.nb, nfix, dfsum};
     const unsigned db = (unsigned)((tot + 255) / 256);

@@ -614,7 +614,7 @@ std::vector<StarkPoint> BulletproofGens::Share::H(size_t n) const {
 bpgpu_gens *BulletproofGens::device_tables(const PedersenGens &pc, int window_bits) const {
   if (window_bits == 0) {
     if (const char *e = getenv("BPH_WINDOW_BITS")) window_bits = atoi(e);
-    if (window_bits == 0) window_bits = gens_capacity <= 64 ? 16 : (gens_capacity <= 1024 ? 14 : (gens_capacity <= 4096 ? 12 : 8));
+    if (window_bits == 0) window_bits = gens_capacity <= 1024 ? 16 : (gens_capacity <= 4096 ? 12 : 8);
   }
   std::array<uint8_t, 128> key;
   memcpy(key.data(), pc.B.xy.data(), 64);

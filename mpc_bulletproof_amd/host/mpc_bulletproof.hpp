@@ -203,8 +203,9 @@ class BulletproofGens {
   };
   Share share(size_t j) const { return Share{this, j}; }
   // resident fixed-base tables of share 0 for (B, B_blinding) -- built on first use
-  // window_bits 0 = by capacity (BPH_WINDOW_BITS overrides): 16-bit windows up to 64 generators per side (4.5 GB),
-  // 14-bit up to 1024 (20 GB), 12-bit up to 4096 (24 GB), 8-bit beyond (17 GB at 32768)
+  // window_bits 0 = by capacity (BPH_WINDOW_BITS overrides): 16-bit windows up to 1024 generators per side (4.5 GB at 64,
+  // 69 GB at 1024: 16 table additions per term instead of 19 with 14-bit windows -- the prover's IPP rounds are 2 n-term
+  // table-lookup MSMs each), 12-bit up to 4096 (24 GB), 8-bit beyond (17 GB at 32768)
   bpgpu_gens *device_tables(const PedersenGens &pc, int window_bits = 0) const;
  private:
   std::vector<std::vector<StarkPoint>> G_vec_, H_vec_;
