@@ -1981,7 +1981,7 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
       ProfScope ps(ctx, 21, st);
       fixed_msm_ipp(st, s->gens->c, s->gens->table, s->n0, s->gens->cap, n, (const uint32_t *)s->msc, s->sums, nb * 2, (JacRaw *)dpart);
     }
-    jac_to_boundary(st, s->sums, out_xy, nb * 2);
+    if (out_xy) jac_to_boundary(st, s->sums, out_xy, nb * 2);      // (nullptr: the caller's fused round tail converts s->sums itself)
     return launch_ok(ctx);
   }
   const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
@@ -2129,10 +2129,15 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
   ProfSpan span(ctx, 20, ctx->st);
   for (size_t r = 0; r < k; r++) {
     Words8 *lr = (Words8 *)dlr + r * nb * 4;             // 2 points x 2 Words8 per proof
-    CK(ipp_round_dev(ctx, s, lr));
-    ipp_round_challenge(ctx->st, nb, (uint64_t *)dstates, lr, du);
-    HIPCK(ctx, hipMemcpyAsync(dui, du, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
-    batch_inverse(ctx->st, dui, nb, (int *)dzero);       // challenges are non-zero up to 2^-252
+    if (s->gens) {   // resident generators: point conversion, the three transcript steps and u^-1 in ONE launch (k_ipp_round_tail)
+      CK(ipp_round_dev(ctx, s, nullptr));
+      ipp_round_tail(ctx->st, nb, s->sums, (uint64_t *)dstates, lr, du, dui);
+    } else {
+      CK(ipp_round_dev(ctx, s, lr));
+      ipp_round_challenge(ctx->st, nb, (uint64_t *)dstates, lr, du);
+      HIPCK(ctx, hipMemcpyAsync(dui, du, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
+      batch_inverse(ctx->st, dui, nb, (int *)dzero);       // challenges are non-zero up to 2^-252
+    }
     CK(ipp_fold_dev(ctx, s, du, dui));
   }
   span.close();

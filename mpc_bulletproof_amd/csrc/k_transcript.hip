@@ -16,6 +16,8 @@
 //   challenge_bytes: state = keccak256(state || 0x01 || pad_label(l)),  output = state
 // One lane per proof; state and message blocks live in registers (all layouts are compile-time).
 #include "fe29.cuh"
+#include "ec_dev.cuh"
+#include "fn_dev.cuh"
 #include "kernels.h"
 
 using namespace bp;
@@ -330,6 +332,136 @@ void blind_vectors(hipStream_t st, const Words8 *keys, size_t nb, size_t cnt, Wo
   if (!nb || !cnt) return;
   const size_t lanes = nb * 2 * ((cnt + 1) / 2);
   hipLaunchKernelGGL(k_blind_vectors, dim3((lanes + 63) / 64), dim3(64), 0, st, keys, nb, cnt, sL, sR, stride, off);
+}
+// ---- Keccak-f[1600] spread over 25 lanes of a wave: lane i = x + 5 y holds state word i (two states per wave: lanes 0..24 and
+// 32..56).  One lane runs a permutation as ~7 200 dependent instructions (13 us at the rate a lone wave issues them); here a
+// round is 18 ds_bpermute moves (the five column words for theta, the two neighbour columns' parities, the rho-pi source word,
+// the two chi neighbours; 64-bit values = two moves each) and ~50 instructions: ~2 000 per permutation, 3.6x shorter -- for 8.5x
+// the issue slots per state (a wave carries 2 states instead of 64).  That trade is right where a hash chain IS the critical path
+// of a small batch (the prover's per-round challenge: 256 states, an otherwise idle chip) and wrong for the verifier's 1024 x 80
+// permutations per batch, which stay one lane per proof.  i < 25; `base` = first lane of this state's 32-lane half.
+struct CoopK { int i, src_pi, c1, c2, c3, c4, dm, dp, x1, x2; int rho; };
+__device__ __forceinline__ CoopK coop_keccak_setup(int i, int base) {
+  constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};   // by index x + 5 y
+  CoopK k;
+  const int ii = i < 25 ? i : 0, x = ii % 5, y = ii / 5;
+  k.i = ii;
+  k.rho = RHO[ii];
+  // pi: B[y'][(2 x' + 3 y') mod 5] = rot(A[x'][y']), i.e. the word at (X, Y) comes from x' = 3 (Y - 3 X) mod 5 ... in index form:
+  // destination (X, Y) <- source (x', y') with X = y', Y = (2 x' + 3 y') mod 5  =>  y' = X, x' = 3 (Y - 3 X) mod 5
+  const int xs = (3 * (((y - 3 * x) % 5 + 5) % 5)) % 5, ys = x;
+  k.src_pi = base + xs + 5 * ys;
+  k.c1 = base + (ii + 5) % 25; k.c2 = base + (ii + 10) % 25; k.c3 = base + (ii + 15) % 25; k.c4 = base + (ii + 20) % 25;
+  k.dm = base + (x + 4) % 5; k.dp = base + (x + 1) % 5;                      // any lane of the neighbour columns holds that column's parity
+  k.x1 = base + 5 * y + (x + 1) % 5; k.x2 = base + 5 * y + (x + 2) % 5;
+  return k;
+}
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+__device__ __forceinline__ uint64_t coop_keccak_f(uint64_t a, const CoopK &k) {
+  constexpr uint64_t RC[24] = {
+      0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808AULL, 0x8000000080008000ULL, 0x000000000000808BULL,
+      0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL, 0x000000000000008AULL, 0x0000000000000088ULL,
+      0x0000000080008009ULL, 0x000000008000000AULL, 0x000000008000808BULL, 0x800000000000008BULL, 0x8000000000008089ULL,
+      0x8000000000008003ULL, 0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800AULL, 0x800000008000000AULL,
+      0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+#pragma unroll 1
+  for (int r = 0; r < 24; r++) {
+    const uint64_t c = a ^ shfl64(a, k.c1) ^ shfl64(a, k.c2) ^ shfl64(a, k.c3) ^ shfl64(a, k.c4);      // theta: column parity (in every lane of the column)
+    const uint64_t cp = shfl64(c, k.dp);
+    a ^= shfl64(c, k.dm) ^ ((cp << 1) | (cp >> 63));
+    const uint64_t t = k.rho ? ((a << k.rho) | (a >> (64 - k.rho))) : a;                                 // rho (this lane's own offset) ...
+    const uint64_t b = shfl64(t, k.src_pi);                                                              // ... pi
+    a = b ^ (~shfl64(b, k.x1) & shfl64(b, k.x2));                                                        // chi
+    if (k.i == 0) a ^= RC[r];                                                                            // iota
+  }
+  return a;
+}
+// The tail of one IPP prover round for nb provers (inner_product_proof.rs:119-123 / :177-181), one 32-lane half-wave per prover, in ONE
+// launch instead of three (point conversion | hash chain | batch inversion) with two waits between them:
+//   lanes 0, 1: L, R (Jacobian partial sums) -> affine boundary bytes, an inversion each, side by side;
+//   lanes 0..24: transcript.append_point("L"), ("R"), challenge_scalar("u") -- six Keccak permutations, cooperatively (above);
+//   lane 0: u = hash_to_scalar, u^-1.
+// sums: nb x 2 points; lr_xy out: nb x 2 x 64 B; states: 4 x u64 per prover, updated; u_out, uinv_out: nb x 32 B.
+__global__ void __launch_bounds__(64) k_ipp_round_tail(size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out,
+                                                       Words8 *uinv_out) {
+  __shared__ uint64_t sh[2][24];          // per half: [0..3] chain state, [4..11] L x || y, [12..19] R x || y, [20..23] scratch (challenge low)
+  __builtin_amdgcn_s_setprio(3);
+  const int half = threadIdx.x >> 5, l = threadIdx.x & 31, base = half * 32;
+  const size_t p = (size_t)blockIdx.x * 2 + half;
+  const bool live = p < nb;
+  uint64_t *S = sh[half];
+  if (live && l < 2) {                     // L (lane 0) and R (lane 1) to canonical affine bytes
+    Jac q = raw_load(&sums[2 * p + l]);
+    if (!jac_is_inf(q) && is_zero_exact(q.Z)) q = jac_inf();
+    uint32_t w[16];
+    aff_to_boundary(w, jac_to_aff(q));
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      lr_xy[(2 * p + l) * 2].w[j] = w[j];
+      lr_xy[(2 * p + l) * 2 + 1].w[j] = w[8 + j];
+      S[4 + 8 * l + j] = (uint64_t)w[2 * j] | ((uint64_t)w[2 * j + 1] << 32);
+    }
+  }
+  if (live && l < 4) S[l] = states[p * 4 + l];
+  __syncthreads();
+  const CoopK ck = coop_keccak_setup(l, base);
+  // message words of append_message(label, 64-byte point): state (4 words) | then, shifted by the one flag byte: label (4 words),
+  // u64le(64), x || y (8 words) -- 18 words = 137 bytes: two rate blocks of 17 words (keccak256 padding 0x01 .. 0x80)
+  auto strm = [&](int j, const Label &lab, int pt) -> uint64_t {   // stream word j after the flag byte: label[0..3], len, point[0..7]
+    return j < 4 ? lab.w[j] : (j == 4 ? 64ull : S[4 + 8 * pt + (j - 5)]);
+  };
+  uint64_t a = 0;
+  for (int pt = 0; pt < 2; pt++) {
+    const Label lab = pt == 0 ? TR_LABELS[LB_L] : TR_LABELS[LB_R];
+    uint64_t w = 0;
+    if (l < 4) w = S[l];
+    else if (l < 17) w = (strm(l - 4, lab, pt) << 8) | (l == 4 ? 0ull : (strm(l - 5, lab, pt) >> 56));     // flag byte 0x00
+    a = coop_keccak_f(l < 17 ? w : 0ull, ck);                                                                // block 1 (state was zero)
+    uint64_t w2 = 0;
+    if (l == 0) w2 = (strm(12, lab, pt) >> 56) | (0x01ull << 8);          // the 137th byte, then the pad start
+    if (l == 16) w2 = 0x8000000000000000ULL;
+    a = coop_keccak_f(a ^ w2, ck);                                          // block 2
+    __syncthreads();
+    if (l < 4) S[l] = a;                                                    // the chain state after this append
+    __syncthreads();
+  }
+  {   // challenge_bytes("u"): state = keccak256(state || 0x01 || pad_label("u")) -- 65 bytes, one block
+    const Label lab = TR_LABELS[LB_u];
+    uint64_t w = 0;
+    if (l < 4) w = S[l];
+    else if (l < 8) w = (lab.w[l - 4] << 8) | (l == 4 ? 0x01ull : (lab.w[l - 5] >> 56));
+    else if (l == 8) w = (lab.w[3] >> 56) | (0x01ull << 8);                // last label byte, pad start at byte 65
+    if (l == 16) w ^= 0x8000000000000000ULL;
+    a = coop_keccak_f(l < 17 ? w : 0ull, ck);
+    __syncthreads();
+    if (l < 4) { S[l] = a; S[20 + l] = a; }
+    __syncthreads();
+    // hash_to_scalar: high = keccak256(low)
+    uint64_t h = 0;
+    if (l < 4) h = S[20 + l];
+    if (l == 4) h = 0x01;
+    if (l == 16) h = 0x8000000000000000ULL;
+    a = coop_keccak_f(l < 17 ? h : 0ull, ck);
+    __syncthreads();
+    if (l < 4) S[4 + l] = a;                                               // (the point words are no longer needed)
+    __syncthreads();
+  }
+  if (live && l == 0) {
+    Words8 uw;
+    wide_to_scalar(S + 20, S + 4, &uw);
+    u_out[p] = uw;
+    Fn ui = inv(load_plain(&uw));                                          // challenges are non-zero up to 2^-252
+    store_plain(&uinv_out[p], ui);
+#pragma unroll
+    for (int j = 0; j < 4; j++) states[p * 4 + j] = S[j];
+  }
+}
+void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out) {
+  if (!nb) return;
+  hipLaunchKernelGGL(k_ipp_round_tail, dim3((nb + 1) / 2), dim3(64), 0, st, nb, sums, states, lr_xy, u_out, uinv_out);
 }
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr, Words8 *u_out) {
   if (!nb) return;

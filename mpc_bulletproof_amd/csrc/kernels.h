@@ -275,6 +275,9 @@ void shard_mask(hipStream_t st, Words8 *fixed, size_t np, size_t slo, size_t shi
                 size_t vhi);
 // one IPP prover round of the device transcript: append L, R; u = challenge (k_transcript.hip)
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);
+// the whole tail of a round in one launch: L, R (Jacobian sums, nb x 2) -> boundary bytes, the three transcript steps on a
+// wave-cooperative Keccak, u and u^-1
+void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out);
 
 // ---- wire codec of points (k_codec.hip): 32-byte compressed <-> 64-byte affine boundary form ------
 size_t sqrt_table_bytes();
