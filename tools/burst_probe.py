@@ -8,7 +8,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 os.environ.setdefault("BPGPU_SINGLE_STREAM", "1")
 import torch                       # noqa: E402
 import mpc_bulletproof_amd as mb   # noqa: E402

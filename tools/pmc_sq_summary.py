@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 --pmc SQ_* pass (tools/pmc_sq.sh): per kernel wave-instruction counts and the split of wave
+"""Summarise a rocprofv3 --pmc SQ_* pass (tools/profile_all.sh): per kernel wave-instruction counts and the split of wave
 cycles into waiting / issuing.  Usage: pmc_sq_summary.py gpurun_out/pmc_sq/sq_results.db [out.txt]"""
 import collections
 import sqlite3

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FETCH_SIZE / WRITE_SIZE passes (tools/pmc_sq.sh) -> per-kernel averages per launch (KB) as CSV.
+"""FETCH_SIZE / WRITE_SIZE passes (tools/profile_all.sh) -> per-kernel averages per launch (KB) as CSV.
 Usage: pmc_traffic_summary.py gpurun_out profiles/r01"""
 import csv
 import sqlite3

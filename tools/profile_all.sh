@@ -21,3 +21,11 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_W
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c -d $R/gpurun_out/pmc_$c -o p -- python3 $R/bench.py $COMMON --steps 8 --warmup 2 --inflight 1 > $R/gpurun_out/pmc_$c.log 2>&1
 done
+# 6. the prover stream (configs[2]): kernel trace with 3 worker threads and with 1; PMC passes with 1      -> gpurun_out/${TAG}_prove_*
+# 7. the Pippenger pipeline at 2^17 / 2^20 terms: kernel trace + PMC                                       -> gpurun_out/${TAG}_msm_2e*
+TAG=${1:-r03}
+cd $R
+bash tools/prof_prove_stream.sh 3 12 ${TAG}_prove_stream3 > gpurun_out/${TAG}_prove_stream3.txt 2>&1
+bash tools/prof_prove_stream.sh 1 6 ${TAG}_prove_stream1 > gpurun_out/${TAG}_prove_stream1.txt 2>&1
+bash tools/pmc_prove.sh ${TAG} 4 > gpurun_out/${TAG}_prove_pmc.txt 2>&1
+bash tools/prof_msm_all.sh ${TAG} > gpurun_out/${TAG}_msm_profile.txt 2>&1

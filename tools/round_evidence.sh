@@ -15,5 +15,5 @@ if [ "$1" = "A" ]; then
 elif [ "$1" = "B" ]; then
   bash tools/round_logs.sh && bash tools/solo_trace.sh > /dev/null
 else   # C: the rocprofv3 databases alone come close to the 64 MiB that a call may bring back
-  bash tools/profile_all.sh
+  bash tools/profile_all.sh ${2:-r03}
 fi
