@@ -487,6 +487,73 @@ def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
         s0.close()
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_shard_partial_sums_add_up(gpu, world):
+    """bpgpu_set_shard / bpgpu_r1cs_verify_shard (ONE large proof over the GPUs of a node) on one context, rank after
+    rank: the partial commitments of a prover session, the partial L, R of every IPP round and the partial mega_check points of a
+    verification each add up (bpgpu_points_sum) to what the unsharded call returns -- incl. a tampered proof's non-identity point."""
+    import random
+    rnd = random.Random(77 + world)
+    N_ = o.N
+    n, nb, cap = 8, 2, 8
+    ark = lambda vals: b"".join((v * (1 << 256) % N_).to_bytes(32, "little") for v in vals)       # noqa: E731
+    pk = lambda vals: b"".join(o.s2b(v) for v in vals)                                               # noqa: E731
+    g = _gens(gpu, cap, 8)
+    try:
+        # --- prover commitments: explicit blinding vectors so that every rank's session holds the same operands
+        wit = [[rnd.randrange(N_) for _ in range(nb * n)] for _ in range(5)]
+        blinds = [rnd.randrange(N_) for _ in range(3 * nb)]
+        ses, full = gpu.r1cs_prover_commit(g, None, nb, n, ark(wit[0]), ark(wit[1]), ark(wit[2]), ark(blinds), s_L=ark(wit[3]), s_R=ark(wit[4]))
+        gpu.prover_destroy(ses)
+        parts = []
+        for r in range(world):
+            gpu.set_shard(r, world)
+            ses, part = gpu.r1cs_prover_commit(g, None, nb, n, ark(wit[0]), ark(wit[1]), ark(wit[2]), ark(blinds), s_L=ark(wit[3]), s_R=ark(wit[4]))
+            gpu.prover_destroy(ses)
+            parts.append(part)
+        gpu.set_shard(0, 1)
+        for j in range(3 * nb):
+            assert gpu.points_sum(b"".join(p_[64 * j:64 * j + 64] for p_ in parts)) == full[64 * j:64 * j + 64], j
+        # --- IPP rounds over resident generators: partial L, R per round; the scalar state is folded on every rank alike
+        a, b = [rnd.randrange(N_) for _ in range(n)], [rnd.randrange(N_) for _ in range(n)]
+        Gf, Hf, w = [1] * n, [rnd.randrange(1, N_) for _ in range(n)], [rnd.randrange(1, N_)]
+
+        def rounds(rank, world_):
+            gpu.set_shard(rank, world_)
+            s_ = gpu.ipp_begin_gens(g, 1, n, pk(w), pk(Gf), pk(Hf), pk(a), pk(b))
+            gpu.set_shard(0, 1)
+            out, rr = [], random.Random(5)
+            while gpu.ipp_len(s_) > 1:
+                out.append(gpu.ipp_round(s_, 1))
+                u = rr.randrange(1, N_)
+                gpu.ipp_fold(s_, pk([u]), pk([pow(u, -1, N_)]))
+            fin = gpu.ipp_finish(s_, 1)
+            gpu.ipp_destroy(s_)
+            return out, fin
+        ref_rounds, ref_fin = rounds(0, 1)
+        per_rank = [rounds(r, world) for r in range(world)]
+        assert all(fin == ref_fin for _, fin in per_rank)
+        for j, (L, R) in enumerate(ref_rounds):
+            assert gpu.points_sum(b"".join(pr[0][j][0] for pr in per_rank)) == L and gpu.points_sum(b"".join(pr[0][j][1] for pr in per_rank)) == R, j
+        # --- verification: partial mega_check points (valid proof -> identity; tampered -> the oracle's point)
+        recs, cap2 = bh.make_range_batch(8, 2, tamper={1})
+        for proof, com in recs:
+            s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap2)
+            circ = gpu.circuit_create(*s.csr(), s.n1 + s.n2, s.m)
+            k, pts, sc = bh.verify_inputs(proof, com)
+            parts = [gpu.r1cs_verify_shard(g, circ, s.n1, s.k, pts, sc, s.challenges(), r, world) for r in range(world)]
+            assert gpu.points_sum(b"".join(parts)) == s.mega_check()
+            assert (s.mega_check() == bytes(64)) == (s.rc == 0)
+            gpu.circuit_destroy(circ)
+            s.close()
+        import mpc_bulletproof_amd as m
+        with pytest.raises(m.BpGpuError):
+            gpu.set_shard(3, 3)
+    finally:
+        gpu.set_shard(0, 1)
+        gpu.gens_destroy(g)
+
+
 def test_options_setter_rejects_bad_values(gpu):
     import mpc_bulletproof_amd as m
     for name, bad in (("verify_straus_np", 5), ("table_np", 3), ("vs_large_min", 0), ("ipp_literal", 2), ("msm_wp_max", -1)):
