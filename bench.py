@@ -606,6 +606,11 @@ def main():
     # mirror of the reference API over the C ABI.  A stream of batches on `prover_threads` worker threads, one context each.
     prove = shuffle = None
     if world == 1 and not a.no_prover:
+        # the verification legs are done: their contexts (20 streams with hardware queues of their own) go, so that the prover's worker
+        # contexts do not share queues with them; ctxs[0] keeps the circuit and the tables alive until the end
+        for c in ctxs[1:]:
+            c.close()
+        ctxs = ctxs[:1]
         import ctypes as C
         host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
         vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(P_NB) for i in range(P_NVALS)]

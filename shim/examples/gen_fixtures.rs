@@ -77,7 +77,7 @@ fn main() {
         let b: Vec<Scalar> = (0..n as u64).map(|i| det_scalar(300 + i)).collect();
         let g_factors: Vec<Scalar> = vec![Scalar::one(); n];
         let y_inv = det_scalar(555);
-        let h_factors: Vec<Scalar> = mpc_bulletproof::util::exp_iter(y_inv).take(n).collect();   // needs `pub mod util` (it is pub(crate) today: see INTEGRATION.md section 7)
+        let h_factors: Vec<Scalar> = std::iter::successors(Some(Scalar::one()), |p| Some(*p * y_inv)).take(n).collect();   // util::exp_iter (crate-private)
         let c = mpc_bulletproof::inner_product(&a, &b);
         let b_prime: Vec<Scalar> = b.iter().zip(h_factors.iter()).map(|(bi, yi)| *bi * *yi).collect();
         let p = StarkPoint::msm(&[a.clone(), b_prime, vec![c]].concat(), &[g_vec.clone(), h_vec.clone(), vec![q]].concat());

@@ -10,6 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
+OUT = os.path.dirname(tag) or os.path.join(ROOT, "profiles")      # summaries live beside the tag prefix (profiles/rNN or gpurun_out/summ/rNN)
 KERNELS = {"verify_front": "k_verify_front", "verify_scalars": "k_verify_scalars", "verify_windows": "k_verify_windows",
            "verify_groups": "k_verify_horner_groups", "verify_back": "k_verify_back", "verify_verdict": "k_verify_verdict"}
 
@@ -49,10 +50,10 @@ out = {
 # is SHORTER there (fewer neighbours on the chip): bench.py quotes these beside its own event average.
 try:
     import csv
-    run = json.loads(open(os.path.join(ROOT, "profiles", f"{os.path.basename(tag)}_bench20_profiled_run.json")).read())
+    run = json.loads(open(os.path.join(OUT, f"{os.path.basename(tag)}_bench20_profiled_run.json")).read())
     roof = run["roofline"]
     kern = roof["kernel"].split("<")[0]
-    for row in csv.DictReader(open(os.path.join(ROOT, "profiles", f"{os.path.basename(tag)}_bench20_kernel_stats.csv"))):
+    for row in csv.DictReader(open(os.path.join(OUT, f"{os.path.basename(tag)}_bench20_kernel_stats.csv"))):
         if kern in row["Name"]:
             out["profiled_run_bench20"] = {"kernel": roof["kernel"], "rocprofv3_avg_ms": float(row["AverageNs"]) / 1e6, "rocprofv3_calls": int(row["Calls"]),
                                            "hip_events_avg_ms": roof["avg_launch_ms"], "hip_events_launches": roof["launches"],
@@ -65,6 +66,6 @@ try:
     out["prover"] = json.loads(open(f"{src}/{os.path.basename(tag)}_prove_pmc.json").read())
 except OSError as e:
     print("no prover counters:", e, file=sys.stderr)
-path = os.path.join(ROOT, "profiles", "pmc_constants.json")
+path = os.path.join(OUT, "pmc_constants.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out, indent=1))

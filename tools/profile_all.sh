@@ -29,3 +29,8 @@ bash tools/prof_prove_stream.sh 3 12 ${TAG}_prove_stream3 > gpurun_out/${TAG}_pr
 bash tools/prof_prove_stream.sh 1 6 ${TAG}_prove_stream1 > gpurun_out/${TAG}_prove_stream1.txt 2>&1
 bash tools/pmc_prove.sh ${TAG} 4 > gpurun_out/${TAG}_prove_pmc.txt 2>&1
 bash tools/prof_msm_all.sh ${TAG} > gpurun_out/${TAG}_msm_profile.txt 2>&1
+# 8. summaries where the databases are; the databases themselves stay on the box (a gpurun call brings back at most 64 MiB)
+bash tools/profile_collect.sh ${TAG} gpurun_out/summ
+rm -rf gpurun_out/prof_b20 gpurun_out/prof_final gpurun_out/pmc_sq gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/prove_pmc_* \
+       gpurun_out/msm_trace_* gpurun_out/msm_pmc_* gpurun_out/${TAG}_prove_stream*_trace gpurun_out/wl_prof*
+ls gpurun_out/summ
