@@ -605,9 +605,11 @@ def main():
     # range-proving 16 x 64-bit values in one constraint system: n = 1024 multipliers, q = 2064 constraints), through the C++ host
     # mirror of the reference API over the C ABI.  A stream of batches on `prover_threads` worker threads, one context each.
     prove = shuffle = None
+    steps_in_flight = len(ctxs)
     if world == 1 and not a.no_prover:
         # the verification legs are done: their contexts (20 streams with hardware queues of their own) go, so that the prover's worker
         # contexts do not share queues with them; ctxs[0] keeps the circuit and the tables alive until the end
+        steps_in_flight = len(ctxs)
         for c in ctxs[1:]:
             c.close()
         ctxs = ctxs[:1]
@@ -684,13 +686,13 @@ def main():
                                                    "provers' set-up inside the timed region as well"},
                  "single_thread": {"value": P_NB * P_Q / (ms_s[0] / nsolo) * 1e3, "unit": "R1CS constraints/s",
                                    "ms_per_batch": ms_s[0] / nsolo, "note": "one worker thread, batches back to back (with event timing on)"},
-                 "roofline": {"bound": "hbm", "kernel": "k_fixed_msm_ipp<14,128> (+ its block sum): the L / R table-lookup MSMs of one IPP round, 512 MSMs of 1025 terms",
+                 "roofline": {"bound": "hbm", "kernel": "k_fixed_msm_ipp<16,128> (+ its block sum): the L / R table-lookup MSMs of one IPP round, 512 MSMs of 1025 terms",
                               "achieved": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_p or {}).get("traffic_bytes_round_msm"),
                               "avg_launch_ms": solo_msm_ms, "launches": int(ms_s[6]), "algorithmic_bytes_per_launch": per_launch_bytes,
                               "timed": "HIP-event pairs on the launch stream around the kernel, one worker thread (no other batch on the GPU)",
                               "residency_in_the_stream_ms": ms_p[5] / max(ms_p[6], 1),
-                              "note": "VALU-integer bound like every kernel here: 19 mixed additions (~1 650 instructions each) per 96 algorithmic bytes"},
+                              "note": "VALU-integer bound like every kernel here: 16 table additions (~1 650 instructions each) per 96 algorithmic bytes; the binding roofline is roofline_valu_issue beside this one"},
                  "gpu_busy": {"frac": ms_p[4] / ms_p[0], "busy_ms_per_batch": ms_p[4] / NBAT, "wall_ms_per_batch": ms_p[0] / NBAT,
                               "device_phase_ms_per_batch": {"ipp_rounds": ms_p[7] / NBAT, "phase_commitments": ms_p[8] / NBAT, "polynomials": ms_p[9] / NBAT,
                                                             "T_commitments": ms_p[10] / NBAT, "ipp_setup": ms_p[11] / NBAT},
@@ -843,7 +845,7 @@ def main():
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 252-bit prime fields)", "data": "synthetic",
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
                                    f"mega_check MSM per proof, per-proof accept bits) per GPU",
-                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": len(ctxs),
+                       "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": steps_in_flight,
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "untimed_before_the_timed_region": f"max(warmup, steps_in_flight) steps, result check, {warm_s:.1f} s of further untimed "
                                                           "steps (clocks), one hand-over step per context"},

@@ -1121,10 +1121,13 @@ static int circuit_create_impl(bpgpu_ctx *ctx, size_t q_real, size_t nchi, const
   if (!c) return BPGPU_E_OOM;
   c->q = q_real; c->n = n_mul; c->m = m; c->nnz = nnz; c->nchi = nchi;
   // (plain allocations, not the context's pool: a circuit is shared by contexts and may outlive the one that made it)
-  auto fail = [&](int rc) { hipFree(c->col_ptr); hipFree(c->row); hipFree(c->coeff); delete c; return rc; };
-  if (hipMalloc((void **)&c->col_ptr, (nout + 1) * 4) != hipSuccess || hipMalloc((void **)&c->row, (nnz ? nnz : 1) * 4) != hipSuccess ||
-      hipMalloc((void **)&c->coeff, (nnz ? nnz : 1) * 32) != hipSuccess)
-    return fail(BPGPU_E_OOM);
+  // ONE allocation [coeff | col_ptr | row] (a proof of a circuit with randomized constraints pays for this every time: three
+  // hipMalloc + three hipFree were ~1 ms of the 2^14-shuffle's prove and verify)
+  auto fail = [&](int rc) { hipFree(c->coeff); delete c; return rc; };
+  const size_t b_coeff = (nnz ? nnz : 1) * 32, b_col = ((nout + 1) * 4 + 255) / 256 * 256, b_row = (nnz ? nnz : 1) * 4;
+  if (hipMalloc((void **)&c->coeff, b_coeff + b_col + b_row) != hipSuccess) { c->coeff = nullptr; return fail(BPGPU_E_OOM); }
+  c->col_ptr = (uint32_t *)((uint8_t *)c->coeff + b_coeff);
+  c->row = (uint32_t *)((uint8_t *)c->coeff + b_coeff + b_col);
   void *drp, *dkd, *dix, *dcf, *dfill;
   int rc;
   if ((rc = ws_get(ctx, 0, (q + 1) * 4, &drp)) || (rc = ws_get(ctx, 1, (nnz ? nnz : 1) * 4, &dkd)) || (rc = ws_get(ctx, 2, (nnz ? nnz : 1) * 4, &dix)) ||
@@ -1164,9 +1167,7 @@ int bpgpu_circuit_create_param(bpgpu_ctx *ctx, size_t q, size_t nchi, const uint
 void bpgpu_circuit_destroy(bpgpu_ctx *ctx, bpgpu_circuit *c) {
   if (!c) return;
   if (ctx) { std::lock_guard<std::mutex> lk(ctx->mu); hipStreamSynchronize(ctx->st); hipStreamSynchronize(ctx->st2); }
-  hipFree(c->col_ptr);
-  hipFree(c->row);
-  hipFree(c->coeff);
+  hipFree(c->coeff);     // [coeff | col_ptr | row] is one allocation
   delete c;
 }
 static CircuitDev circuit_dev(const bpgpu_circuit *c) {

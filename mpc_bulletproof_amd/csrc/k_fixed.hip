@@ -24,20 +24,26 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
   const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
   const size_t hshift = cap - n;
   Jac acc = jac_inf();
-  // software prefetch of the next table row while the current madd runs.  The scalar words come from
-  // L1/L2 (the W lanes of one generator read the same 32 bytes) and are recoded on the fly: staging all
-  // recoded scalars in LDS needs 36 B per generator -- 81 KB at capacity 1024, past the 64 KB dynamic limit.
-  uint32_t cur[16];
-  int dcur = 0;
-  size_t l = lo + tid;
-  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+  // Staged software prefetch: the table row of pair l + 2 TPB is requested before the addition of pair l starts (a random 64-byte
+  // row of a multi-GB table is a TLB miss + an HBM access: one addition, ~3 us, does not always cover it), and the scalar words
+  // that row's ADDRESS is computed from one iteration earlier still -- the dependent chain scalar load -> recoding -> row load
+  // would otherwise sit exposed in front of every addition (a third of the kernel's wave-cycles were spent waiting with two
+  // waves per SIMD; the verification's Horner launch went from 0.49 to 0.41 ms alone with the same change in fixed_body.cuh).  The scalar words come from L1/L2 (the W lanes of one generator
+  // read the same 32 bytes) and are recoded on the fly: staging all recoded scalars in LDS needs 36 B per generator -- 81 KB at
+  // capacity 1024, past the 64 KB dynamic limit.
+  auto load_sc = [&](size_t ll, uint32_t *s) {
+    if (ll < hi) {
+      const size_t g = ll / W;
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+    }
+  };
+  auto fetch_row = [&](size_t ll, const uint32_t *s, uint32_t *dst, int &dg) {
     dg = 0;
     if (ll < hi) {
       size_t g = ll / W;
       int w = (int)(ll - g * W);
-      uint32_t s[8], r[9];
-#pragma unroll
-      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+      uint32_t r[9];
       recode_add_k<C>(r, s);
       dg = recode_digit<C>(r, w);
       if (dg != 0) {
@@ -48,11 +54,21 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
       }
     }
   };
-  fetch(l, cur, dcur);
+  uint32_t cur[16], n1[16], sA[8], sB[8];
+  int dcur = 0, d1 = 0;
+  size_t l = lo + tid;
+  load_sc(l, sA);
+  load_sc(l + TPB, sB);
+  fetch_row(l, sA, cur, dcur);
+  load_sc(l + 2 * TPB, sA);
+  fetch_row(l + TPB, sB, n1, d1);
+#pragma unroll
+  for (int t = 0; t < 8; t++) sB[t] = sA[t];
   while (l < hi) {
-    uint32_t nxt[16];
-    int dnxt;
-    fetch(l + TPB, nxt, dnxt);
+    uint32_t n2[16];
+    int d2;
+    load_sc(l + 3 * TPB, sA);               // words for the pair three steps ahead
+    fetch_row(l + 2 * TPB, sB, n2, d2);     // row for the pair two steps ahead, from the words requested an iteration ago
     if (dcur != 0) {
       Aff q;
       q.x = unpack<FP>(cur);
@@ -61,8 +77,10 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
       acc = jac_madd(acc, q);
     }
 #pragma unroll
-    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
-    dcur = dnxt;
+    for (int t = 0; t < 16; t++) { cur[t] = n1[t]; n1[t] = n2[t]; }
+#pragma unroll
+    for (int t = 0; t < 8; t++) sB[t] = sA[t];
+    dcur = d1; d1 = d2;
     l += TPB;
   }
   acc = block_sum<TPB>(acc, red);
@@ -118,17 +136,20 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
   const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
   const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
   Jac acc = jac_inf();
-  uint32_t curw[16];
-  int dcur = 0;
-  size_t l = lo + tid;
-  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
+  // staged prefetch as in k_fixed_msm
+  auto load_sc = [&](size_t ll, uint32_t *s) {
+    if (ll < hi) {
+      const size_t t = ll / W;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = sc[t * 8 + k];
+    }
+  };
+  auto fetch_row = [&](size_t ll, const uint32_t *s, uint32_t *dst, int &dg) {
     dg = 0;
     if (ll < hi) {
       size_t t = ll / W;
       int w = (int)(ll - t * W);
-      uint32_t s[8], r[9];
-#pragma unroll
-      for (int k = 0; k < 8; k++) s[k] = sc[t * 8 + k];
+      uint32_t r[9];
       recode_add_k<C>(r, s);
       dg = recode_digit<C>(r, w);
       if (dg != 0) {
@@ -146,11 +167,22 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
       }
     }
   };
-  fetch(l, curw, dcur);
+  // rows two pairs ahead, scalar words three (fixed_body.cuh)
+  uint32_t curw[16], n1[16], sA[8], sB[8];
+  int dcur = 0, d1 = 0;
+  size_t l = lo + tid;
+  load_sc(l, sA);
+  load_sc(l + TPB, sB);
+  fetch_row(l, sA, curw, dcur);
+  load_sc(l + 2 * TPB, sA);
+  fetch_row(l + TPB, sB, n1, d1);
+#pragma unroll
+  for (int k = 0; k < 8; k++) sB[k] = sA[k];
   while (l < hi) {
-    uint32_t nxt[16];
-    int dnxt;
-    fetch(l + TPB, nxt, dnxt);
+    uint32_t n2[16];
+    int d2;
+    load_sc(l + 3 * TPB, sA);
+    fetch_row(l + 2 * TPB, sB, n2, d2);
     if (dcur != 0) {
       Aff q;
       q.x = unpack<FP>(curw);
@@ -159,8 +191,10 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
       acc = jac_madd(acc, q);
     }
 #pragma unroll
-    for (int k = 0; k < 16; k++) curw[k] = nxt[k];
-    dcur = dnxt;
+    for (int k = 0; k < 16; k++) { curw[k] = n1[k]; n1[k] = n2[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sB[k] = sA[k];
+    dcur = d1; d1 = d2;
     l += TPB;
   }
   acc = block_sum<TPB>(acc, red);

@@ -42,22 +42,36 @@ __device__ __forceinline__ bool csr_out_of(uint32_t kd, uint32_t ix, size_t n_mu
   if (kd == 4) { o = 3 * n_mul + m; return true; }
   return false;
 }
+// Terms of the CONSTANT column are counted / placed per wave, not per lane: a gadget like the shuffle puts a constant into every
+// second row, and 32 766 atomics on one counter took 0.37 ms in either kernel.
 __global__ void __launch_bounds__(256) k_csr_count(size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx, size_t n_mul,
                                                    size_t m, uint32_t *cnt, int *bad) {
   size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= q) return;
+  const size_t oc = 3 * n_mul + m;
   for (uint32_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
     size_t o;
-    if (!csr_out_of(kind[t], idx[t], n_mul, m, o)) { atomicOr(bad, 1); continue; }
-    atomicAdd(&cnt[o + 1], 1u);
+    const bool ok = csr_out_of(kind[t], idx[t], n_mul, m, o);
+    const bool is_c = ok && o == oc;
+    const unsigned long long mc = __ballot(is_c);
+    if (!ok) { atomicOr(bad, 1); continue; }
+    if (is_c) {
+      if ((int)__lane_id() == __ffsll((long long)mc) - 1) atomicAdd(&cnt[oc + 1], (uint32_t)__popcll(mc));
+    } else atomicAdd(&cnt[o + 1], 1u);
   }
 }
-// exclusive scan in place over cnt[0 .. n] (cnt[0] = 0 on entry): ONE block of 1024 lanes, each owning a contiguous run
+// exclusive scan in place over cnt[0 .. n] (cnt[0] = 0 on entry): ONE block of 1024 lanes, each owning a contiguous run of a
+// multiple of four entries (16-byte loads, several in flight; cnt is 256-byte aligned)
 __global__ void __launch_bounds__(1024) k_csr_scan(uint32_t *cnt, size_t n1) {
   __shared__ uint32_t part[1024];
-  const size_t per = (n1 + 1023) / 1024, lo = threadIdx.x * per, hi = lo + per < n1 ? lo + per : n1;
+  const size_t per = ((n1 + 1023) / 1024 + 3) / 4 * 4, lo = threadIdx.x * per, hi = lo + per < n1 ? lo + per : n1;
   uint32_t s = 0;
-  for (size_t i = lo; i < hi; i++) s += cnt[i];
+  if (lo < hi) {
+    const size_t full = lo + (hi - lo) / 4 * 4;
+#pragma unroll 4
+    for (size_t i = lo; i < full; i += 4) { const uint4 v = *(const uint4 *)(cnt + i); s += v.x + v.y + v.z + v.w; }
+    for (size_t i = full; i < hi; i++) s += cnt[i];
+  }
   part[threadIdx.x] = s;
   __syncthreads();
   for (int off = 1; off < 1024; off <<= 1) {
@@ -67,7 +81,16 @@ __global__ void __launch_bounds__(1024) k_csr_scan(uint32_t *cnt, size_t n1) {
     __syncthreads();
   }
   uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0;
-  for (size_t i = lo; i < hi; i++) { run += cnt[i]; cnt[i] = run; }      // inclusive over cnt[1..]: cnt[o + 1] = end of column o
+  if (lo < hi) {                                                          // inclusive over cnt[1..]: cnt[o + 1] = end of column o
+    const size_t full = lo + (hi - lo) / 4 * 4;
+#pragma unroll 4
+    for (size_t i = lo; i < full; i += 4) {
+      uint4 v = *(const uint4 *)(cnt + i);
+      v.x += run; v.y += v.x; v.z += v.y; v.w += v.z; run = v.w;
+      *(uint4 *)(cnt + i) = v;
+    }
+    for (size_t i = full; i < hi; i++) { run += cnt[i]; cnt[i] = run; }
+  }
 }
 template <bool ARK>
 __global__ void __launch_bounds__(256) k_csr_scatter(size_t q, const uint32_t *row_ptr, const uint32_t *kind, const uint32_t *idx,
@@ -77,8 +100,18 @@ __global__ void __launch_bounds__(256) k_csr_scatter(size_t q, const uint32_t *r
   if (r >= q) return;
   for (uint32_t t = row_ptr[r]; t < row_ptr[r + 1]; t++) {
     size_t o;
-    if (!csr_out_of(kind[t], idx[t], n_mul, m, o)) continue;
-    const uint32_t pos = col_ptr[o] + atomicAdd(&fill[o], 1u);
+    const bool ok = csr_out_of(kind[t], idx[t], n_mul, m, o);
+    const bool is_c = ok && o == 3 * n_mul + m;
+    const unsigned long long mc = __ballot(is_c);
+    if (!ok) continue;
+    uint32_t pos;
+    if (is_c) {                           // one atomic per wave for the constant column; a lane's slot = its rank among the wave's
+      const int leader = __ffsll((long long)mc) - 1;
+      uint32_t base = 0;
+      if ((int)__lane_id() == leader) base = atomicAdd(&fill[o], (uint32_t)__popcll(mc));
+      base = __shfl(base, leader, 64);
+      pos = col_ptr[o] + base + (uint32_t)__popcll(mc & ((1ull << __lane_id()) - 1));
+    } else pos = col_ptr[o] + atomicAdd(&fill[o], 1u);
     rows[pos] = (uint32_t)r;
     uint32_t w[8];
 #pragma unroll

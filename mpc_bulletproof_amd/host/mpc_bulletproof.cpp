@@ -437,27 +437,53 @@ std::vector<uint8_t> pad_label(const std::string &l) {   // merlin fork pad_labe
   return o;
 }
 }  // namespace
-void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {   // original Keccak padding 0x01
-  const size_t rate = 136;
+namespace {
+// keccak256 as a stream: bytes are XORed into the state where they fall (little-endian host: byte i of the rate is byte i of the
+// state words), so a message assembled from pieces needs no buffer
+struct Keccak256 {
+  static constexpr size_t RATE = 136;
   uint64_t A[25];
-  memset(A, 0, sizeof A);
-  auto absorb = [&](const uint8_t *blk) {
-    for (size_t i = 0; i < rate / 8; i++) {
-      uint64_t w;
-      memcpy(&w, blk + 8 * i, 8);          // little-endian host (x86-64 / the GPU boxes)
-      A[i] ^= w;
+  size_t pos = 0;
+  Keccak256() { memset(A, 0, sizeof A); }
+  void absorb(const uint8_t *in, size_t len) {
+    uint8_t *st = (uint8_t *)A;
+    while (len) {
+      size_t take = std::min(len, RATE - pos);
+      if (take == RATE) {                    // whole block: word by word
+        for (size_t i = 0; i < RATE / 8; i++) { uint64_t w; memcpy(&w, in + 8 * i, 8); A[i] ^= w; }
+      } else {
+        for (size_t i = 0; i < take; i++) st[pos + i] ^= in[i];
+      }
+      pos += take; in += take; len -= take;
+      if (pos == RATE) { permute(A); pos = 0; }
     }
+  }
+  void zeros(size_t len) {                  // absorbing zero bytes only moves the position
+    while (len) {
+      size_t take = std::min(len, RATE - pos);
+      pos += take; len -= take;
+      if (pos == RATE) { permute(A); pos = 0; }
+    }
+  }
+  void finish(uint8_t out[32]) {            // original Keccak padding 0x01 .. 0x80
+    uint8_t *st = (uint8_t *)A;
+    st[pos] ^= 0x01;
+    st[RATE - 1] ^= 0x80;
     permute(A);
-  };
-  size_t off = 0;
-  for (; off + rate <= len; off += rate) absorb(in + off);
-  uint8_t last[rate];
-  memset(last, 0, rate);
-  memcpy(last, in + off, len - off);
-  last[len - off] = 0x01;
-  last[rate - 1] |= 0x80;
-  absorb(last);
-  memcpy(out, A, 32);
+    memcpy(out, A, 32);
+  }
+  void label(const std::string &l) {        // pad_label(l) without materialising it
+    size_t k = (l.size() + 31) / 32 * 32;
+    if (k < 32) k = 32;
+    absorb((const uint8_t *)l.data(), l.size());
+    zeros(k - l.size());
+  }
+};
+}  // namespace
+void keccak256(const uint8_t *in, size_t len, uint8_t out[32]) {   // original Keccak padding 0x01
+  Keccak256 k;
+  k.absorb(in, len);
+  k.finish(out);
 }
 Scalar hash_to_scalar(const uint8_t low[32]) {
   uint8_t buf[64];
@@ -471,13 +497,16 @@ Transcript::Transcript(const std::string &label) {
   keccak256(a.data(), a.size(), state_);
 }
 void Transcript::append_message(const std::string &label, const uint8_t *msg, size_t len) {
-  std::vector<uint8_t> buf(state_, state_ + 32);
-  buf.push_back(0x00);
-  auto l = pad_label(label);
-  buf.insert(buf.end(), l.begin(), l.end());
-  for (int j = 0; j < 8; j++) buf.push_back((uint8_t)((uint64_t)len >> (8 * j)));
-  buf.insert(buf.end(), msg, msg + len);
-  keccak256(buf.data(), buf.size(), state_);
+  Keccak256 k;                              // state || 0x00 || pad_label(label) || u64le(len) || msg
+  const uint8_t tag = 0x00;
+  uint8_t lb[8];
+  for (int j = 0; j < 8; j++) lb[j] = (uint8_t)((uint64_t)len >> (8 * j));
+  k.absorb(state_, 32);
+  k.absorb(&tag, 1);
+  k.label(label);
+  k.absorb(lb, 8);
+  k.absorb(msg, len);
+  k.finish(state_);
 }
 void Transcript::append_u64(const std::string &label, uint64_t x) {
   uint8_t b[8];
@@ -485,11 +514,12 @@ void Transcript::append_u64(const std::string &label, uint64_t x) {
   append_message(label, b, 8);
 }
 void Transcript::challenge_bytes(const std::string &label, uint8_t out[32]) {
-  std::vector<uint8_t> buf(state_, state_ + 32);
-  buf.push_back(0x01);
-  auto l = pad_label(label);
-  buf.insert(buf.end(), l.begin(), l.end());
-  keccak256(buf.data(), buf.size(), state_);
+  Keccak256 k;                              // state || 0x01 || pad_label(label)
+  const uint8_t tag = 0x01;
+  k.absorb(state_, 32);
+  k.absorb(&tag, 1);
+  k.label(label);
+  k.finish(state_);
   memcpy(out, state_, 32);
 }
 static void dom_sep(Transcript &t, const std::string &s) { auto p = pad_label(s); t.append_message("dom-sep", p.data(), p.size()); }
@@ -876,7 +906,14 @@ LinearCombination LinearCombination::operator-() const {
   for (auto &kv : terms) r.terms[kv.first] = -kv.second;
   return r;
 }
-LinearCombination LinearCombination::operator-(const LinearCombination &o) const { return *this + (-o); }
+LinearCombination LinearCombination::operator-(const LinearCombination &o) const {   // (no negated temporary: gadgets subtract a lot)
+  LinearCombination r = *this;
+  for (auto &kv : o.terms) {
+    auto it = r.terms.find(kv.first);
+    if (it == r.terms.end()) r.terms[kv.first] = -kv.second; else it->second = it->second - kv.second;
+  }
+  return r;
+}
 LinearCombination LinearCombination::operator*(const Scalar &s) const {
   LinearCombination r;
   for (auto &kv : terms) r.terms[kv.first] = kv.second * s;
@@ -915,6 +952,31 @@ R1CSProof R1CSProof::from_flat_bytes(const std::vector<uint8_t> &b) {
 }
 
 // ---- shared constraint-system core ---------------------------------------------------------------
+// The constraint rows, append-only, in blocks that never move: a std::vector of 160-byte rows re-allocates (and moves every row
+// it holds) a dozen times while the 2^14-shuffle pushes its 65 533 rows -- a fifth of the gadget's time.
+class RowStore {
+ public:
+  static constexpr size_t BLOCK = 1024;
+  void push_back(LinearCombination &&lc) {
+    if (n_ == blocks_.size() * BLOCK) blocks_.emplace_back(new LinearCombination[BLOCK]);
+    blocks_[n_ / BLOCK][n_ % BLOCK] = std::move(lc);
+    n_++;
+  }
+  size_t size() const { return n_; }
+  const LinearCombination &operator[](size_t i) const { return blocks_[i / BLOCK][i % BLOCK]; }
+  struct const_iterator {
+    const RowStore *s; size_t i;
+    const LinearCombination &operator*() const { return (*s)[i]; }
+    const_iterator &operator++() { ++i; return *this; }
+    bool operator!=(const const_iterator &o) const { return i != o.i; }
+  };
+  const_iterator begin() const { return {this, 0}; }
+  const_iterator end() const { return {this, n_}; }
+ private:
+  std::vector<std::unique_ptr<LinearCombination[]>> blocks_;
+  size_t n_ = 0;
+};
+static const Scalar kOne = Scalar::one(), kMinusOne = -Scalar::one();
 class CsCore {
  public:
   CsCore(bool prover, const PedersenGens &pc, Transcript &t, RandomizedConstraintSystem *self)
@@ -923,24 +985,33 @@ class CsCore {
   PedersenGens pc_gens;
   Transcript &tr;
   RandomizedConstraintSystem *self_;
-  std::vector<LinearCombination> constraints;
+  RowStore constraints;
   // 128-bit running hash of the rows (variables + coefficients, in row order), updated as they are pushed: lock-step provers
   // must share their constraint rows, and comparing 255 x 2064 rows with the first prover's cost every batch as much as
   // building them (BPH_CHECK_ROWS=1 still does it); the hash also keys the cache of uploaded circuits
   uint64_t rows_hash[2] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL};
   size_t rows_nnz = 0;
-  void hash_word(uint64_t x) {
-    rows_hash[0] = (rows_hash[0] ^ x) * 0x9E3779B97F4A7C15ULL; rows_hash[0] ^= rows_hash[0] >> 29;
-    rows_hash[1] = (rows_hash[1] + x) * 0xC2B2AE3D27D4EB4FULL; rows_hash[1] = (rows_hash[1] << 31) | (rows_hash[1] >> 33);
+  // (one dependent multiply-rotate step per TERM; the five words of a term are mixed by independent multiplications -- hashing
+  // word by word was a chain of 26 dependent multiplications per row, a third of the time the 2^14-shuffle's gadget takes)
+  static uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+  void hash_term(uint64_t v, const uint64_t w[4]) {
+    const uint64_t a = (v + 0x9E3779B97F4A7C15ULL) * 0xD6E8FEB86659FD93ULL ^ rotl((w[0] ^ 0x243F6A8885A308D3ULL) * 0xC2B2AE3D27D4EB4FULL, 13) ^
+                       rotl((w[1] + 0x13198A2E03707344ULL) * 0x9FB21C651E98DF25ULL, 26) ^ rotl((w[2] ^ 0xA4093822299F31D0ULL) * 0xFF51AFD7ED558CCDULL, 39) ^
+                       rotl((w[3] + 0x082EFA98EC4E6C89ULL) * 0xC4CEB9FE1A85EC53ULL, 52);
+    const uint64_t b = (v ^ 0x452821E638D01377ULL) * 0x94D049BB133111EBULL + rotl((w[0] + 0xBE5466CF34E90C6CULL) * 0xBF58476D1CE4E5B9ULL, 17) +
+                       rotl((w[1] ^ 0xC0AC29B7C97C50DDULL) * 0xE7037ED1A0B428DBULL, 31) + rotl((w[2] + 0x3F84D5B5B5470917ULL) * 0x8EBC6AF09C88C6E3ULL, 43) +
+                       rotl((w[3] ^ 0x9216D5D98979FB1BULL) * 0x589965CC75374CC3ULL, 55);
+    rows_hash[0] = rotl(rows_hash[0] ^ a, 29) * 0x9E3779B97F4A7C15ULL;
+    rows_hash[1] = rotl(rows_hash[1] + b, 31) * 0xC2B2AE3D27D4EB4FULL;
   }
   void push_row(LinearCombination &&lc) {
-    hash_word(0xA5A5A5A500000000ULL | lc.terms.size());
+    const uint64_t head[4] = {lc.terms.size(), 0, 0, 0};
+    hash_term(0xA5A5A5A500000000ULL, head);
     for (auto &kv : lc.terms) {
       if (kv.first.kind == Variable::Zero) continue;
       uint64_t w[4];
       kv.second.to_ark_le((uint8_t *)w);
-      hash_word(((uint64_t)kv.first.kind << 56) ^ (uint64_t)kv.first.index);
-      hash_word(w[0]); hash_word(w[1]); hash_word(w[2]); hash_word(w[3]);
+      hash_term(((uint64_t)kv.first.kind << 56) ^ (uint64_t)kv.first.index, w);
       rows_nnz++;
     }
     constraints.push_back(std::move(lc));
@@ -957,16 +1028,20 @@ class CsCore {
     Scalar acc;
     if (!is_prover) return acc;
     for (auto &kv : lc.terms) {
-      Scalar val;
+      const Scalar *val = nullptr;
       switch (kv.first.kind) {
-        case Variable::MultiplierLeft: val = a_L.at(kv.first.index); break;
-        case Variable::MultiplierRight: val = a_R.at(kv.first.index); break;
-        case Variable::MultiplierOutput: val = a_O.at(kv.first.index); break;
-        case Variable::Committed: val = v.at(kv.first.index); break;
-        case Variable::One: val = Scalar::one(); break;
-        default: break;
+        case Variable::MultiplierLeft: val = &a_L.at(kv.first.index); break;
+        case Variable::MultiplierRight: val = &a_R.at(kv.first.index); break;
+        case Variable::MultiplierOutput: val = &a_O.at(kv.first.index); break;
+        case Variable::Committed: val = &v.at(kv.first.index); break;
+        case Variable::One: val = &kOne; break;
+        default: continue;
       }
-      acc += kv.second * val;
+      // gadget rows are mostly +-1 * variable and constant terms: those cost an addition, not a multiplication
+      if (val == &kOne) acc += kv.second;
+      else if (kv.second == kOne) acc += *val;
+      else if (kv.second == kMinusOne) acc -= *val;
+      else acc += kv.second * *val;
     }
     return acc;
   }
@@ -978,8 +1053,8 @@ class CsCore {
   }
   std::array<Variable, 3> multiply(LinearCombination left, LinearCombination right) {   // prover.rs:99-125 / verifier.rs:99-120
     auto vars = new_multiplier(eval(left), eval(right));
-    left.add_term(vars[0], -Scalar::one());
-    right.add_term(vars[1], -Scalar::one());
+    left.add_term(vars[0], kMinusOne);
+    right.add_term(vars[1], kMinusOne);
     push_row(std::move(left));
     push_row(std::move(right));
     return vars;
@@ -1039,16 +1114,41 @@ class CsCore {
     }
     coeff.resize(t * 32);
   }
+  // the same arrays, written straight into page-locked staging memory by the thread pool (the 2^14-shuffle builds and uploads
+  // 65 533 rows / 196 600 terms for every proof: its rows carry the gadget's challenge)
   bpgpu_circuit *upload_circuit(size_t n_mul, size_t m) const {
-    std::vector<uint32_t> rp, kind, idx;
-    std::vector<uint8_t> coeff;
-    csr(rp, kind, idx, coeff, true);
+    const size_t q = constraints.size();
+    static thread_local RawBuf buf;
+    static thread_local std::vector<uint32_t> rp;
+    rp.resize(q + 1);
+    size_t nnz = 0;
+    for (size_t r = 0; r < q; r++) {
+      rp[r] = (uint32_t)nnz;
+      for (auto &kv : constraints[r].terms) nnz += kv.first.kind != Variable::Zero;
+    }
+    rp[q] = (uint32_t)nnz;
+    const size_t cap = nnz ? nnz : 1;
+    uint8_t *base = buf.ensure(cap * 40);
+    uint8_t *coeff = base;
+    uint32_t *kind = (uint32_t *)(base + cap * 32), *idx = kind + cap;
+    kind[0] = idx[0] = 0;
+    const size_t CH = 2048, chunks = (q + CH - 1) / CH;
+    const uint32_t *row_ptr = rp.data();      // (a lambda does not capture a thread_local: a pool thread would see its own, empty `rp`)
+    parallel_for(chunks, [&](size_t c) {
+      for (size_t r = c * CH; r < q && r < (c + 1) * CH; r++) {
+        size_t t = row_ptr[r];
+        for (auto &kv : constraints[r].terms) {
+          if (kv.first.kind == Variable::Zero) continue;
+          kind[t] = kv.first.kind;
+          idx[t] = (uint32_t)kv.first.index;
+          kv.second.to_ark_le(coeff + 32 * t);
+          t++;
+        }
+      }
+    }, 4);
     Device &d = Device::default_device();
     bpgpu_circuit *c = nullptr;
-    uint32_t z32 = 0; uint8_t z8 = 0;
-    d.check(bpgpu_circuit_create_ark(d.ctx(), constraints.size(), rp.data(), kind.empty() ? &z32 : kind.data(),
-                                     idx.empty() ? &z32 : idx.data(), coeff.empty() ? &z8 : coeff.data(), n_mul, m, &c),
-            "bpgpu_circuit_create_ark");
+    d.check(bpgpu_circuit_create_ark(d.ctx(), q, row_ptr, kind, idx, coeff, n_mul, m, &c), "bpgpu_circuit_create_ark");
     return c;
   }
 };
@@ -1239,15 +1339,24 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     const size_t cnt = hi - lo, plane = nb * cnt * 32;
     static thread_local RawBuf buf;
     uint8_t *base = buf.ensure((vkeys ? 3 : 5) * plane + nb * 3 * 32 + nb * 32 + 1);
-    uint8_t *paL = base, *paR = base + plane, *paO = base + 2 * plane, *psL = base + 3 * plane, *psR = base + 4 * plane;
+    const uint8_t *paL = base, *paR = base + plane, *paO = base + 2 * plane;
+    uint8_t *psL = base + 3 * plane, *psR = base + 4 * plane;
     uint8_t *pbl = base + (vkeys ? 3 : 5) * plane, *pkey = pbl + nb * 3 * 32;
+    // one prover: its witness vectors already lie in memory as the planes the call takes (a Scalar IS its four Montgomery words)
+    static_assert(sizeof(Scalar) == 32, "Scalar must be its 32 in-memory bytes");
+    const bool direct = nb == 1 && cnt > 0;
+    if (direct) {
+      paL = (const uint8_t *)(cs[0]->a_L.data() + lo); paR = (const uint8_t *)(cs[0]->a_R.data() + lo); paO = (const uint8_t *)(cs[0]->a_O.data() + lo);
+    }
     parallel_for(nb, [&](size_t p) {
       Rng &r = *rngs[p];
       ib[p] = r.scalar(); ob[p] = r.scalar(); sb[p] = r.scalar();                         // :457-459 / :519-521
       ib[p].to_ark_le(pbl + (p * 3) * 32); ob[p].to_ark_le(pbl + (p * 3 + 1) * 32); sb[p].to_ark_le(pbl + (p * 3 + 2) * 32);
-      pack_range_ark(paL + p * cnt * 32, cs[p]->a_L.data() + lo, cnt);
-      pack_range_ark(paR + p * cnt * 32, cs[p]->a_R.data() + lo, cnt);
-      pack_range_ark(paO + p * cnt * 32, cs[p]->a_O.data() + lo, cnt);
+      if (!direct) {
+        pack_range_ark(base + p * cnt * 32, cs[p]->a_L.data() + lo, cnt);
+        pack_range_ark(base + plane + p * cnt * 32, cs[p]->a_R.data() + lo, cnt);
+        pack_range_ark(base + 2 * plane + p * cnt * 32, cs[p]->a_O.data() + lo, cnt);
+      }
       if (!cnt) return;
       if (vkeys) {                                                                        // :461-462 / :526-527, as a key
         for (int i = 0; i < 4; i++) { uint64_t w = r.next_u64(); memcpy(pkey + p * 32 + 8 * i, &w, 8); }   // little-endian host
@@ -1259,6 +1368,7 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
         pack_range_ark(psR + p * cnt * 32, v.data(), cnt);
       }
     });
+    lap("prove:   pack planes");
     std::vector<uint8_t> o(nb * 3 * 64);
     int rc = bpgpu_r1cs_prover_commit(d.ctx(), gens, &ps, nb, cnt, paL, paR, paO, vkeys ? nullptr : psL, vkeys ? nullptr : psR,
                                       vkeys && cnt ? pkey : nullptr, pbl, o.data());
@@ -1279,11 +1389,12 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
     cs[p]->tr.append_point("S1", proofs[p].S1);
     cs[p]->create_randomized_constraints();                                              // :501
   });
+  lap("prove: randomized constraints");
   const size_t n = cs[0]->a_L.size(), n2 = n - n1, padded_n = next_pow2(n);
   for (auto *c : cs) if (c->a_L.size() != n) throw std::invalid_argument("prove_batch: circuits differ after randomization");
   if (bp_gens.gens_capacity < padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :511-513
   if (n2 > 0) commit_phase(n1, n, i_b2, o_b2, s_b2, 2);                                    // else identity, :566-576
-  lap("prove: randomize + phase-2 commit");
+  lap("prove: phase-2 commit");
   std::vector<Scalar> y(nb), z(nb);
   parallel_for(nb, [&](size_t p) {
     cs[p]->tr.append_point("A_I2", proofs[p].A_I2);
