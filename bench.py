@@ -772,7 +772,7 @@ def main():
         # 32 B scalar) and what each reads of them; the dominant kernel = the one with the longest solo duration.
         lpm = 16 if nb >= 1024 else 32
         names = {"verify_back": f"k_verify_back<{a.window_bits},{lpm}>", "verify_front": "k_verify_front<4>",
-                 "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars", "verify_groups": "k_verify_horner_groups",
+                 "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars_fast", "verify_groups": "k_verify_horner_groups",
                  "verify_verdict": "k_verify_verdict"}
         bytes_per_proof = {"verify_back": (nterms - nvar) * 96, "verify_front": nvar * 64, "verify_windows": nvar * 32,
                            "verify_scalars": (6 + k + 5) * 32 + nterms * 32}

@@ -22,65 +22,47 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
   const size_t total = (2 + 2 * n) * W;
   const size_t hshift = cap - n;
   Jac acc = jac_inf();
-  // staged software prefetch (k_fixed.hip): the scalar words are requested a pair ahead of the table row whose address they
-  // give, so that neither the scalar load nor the row load that depends on it is waited for in front of an addition
-  auto load_sc = [&](size_t ll, uint32_t *s) {
-    if (ll < total) {
-      const size_t g = ll / W;
-#pragma unroll
-      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
-    }
-  };
-  auto fetch_row = [&](size_t ll, const uint32_t *s, uint32_t *dst, int &dg) {
+  uint32_t cur[16];
+  int dcur = 0;
+  size_t l = lane;
+  auto fetch = [&](size_t ll, uint32_t *dst, int &dg) {
     dg = 0;
     if (ll < total) {
       size_t g = ll / W;
       int w = (int)(ll - g * W);
-      uint32_t r[9];
+      uint32_t s[8], r[9];
+#pragma unroll
+      for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
       recode_add_k<C>(r, s);
       dg = recode_digit<C>(r, w);
       if (dg != 0) {
         size_t row = (g < 2 + n ? g : g + hshift) * W + w;
         const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+        uint32_t any = 0;
 #pragma unroll
-        for (int t = 0; t < 16; t++) dst[t] = e->w[t];
+        for (int t = 0; t < 16; t++) { dst[t] = e->w[t]; any |= dst[t]; }
+        if (any == 0) dg = 0;   // rows of an identity generator (the ABI accepts one) are the identity: nothing to add
       }
     }
   };
-  // rows TWO pairs ahead (a random 64-byte row of a multi-GB table is a TLB miss + an HBM access: one addition, ~3 us on a SIMD
-  // with a single wave, does not always cover it), scalar words three
-  uint32_t cur[16], n1[16], sA[8], sB[8];
-  int dcur = 0, d1 = 0;
-  size_t l = lane;
-  load_sc(l, sA);
-  load_sc(l + LPM, sB);
-  fetch_row(l, sA, cur, dcur);
-  load_sc(l + 2 * LPM, sA);
-  fetch_row(l + LPM, sB, n1, d1);
-#pragma unroll
-  for (int t = 0; t < 8; t++) sB[t] = sA[t];
+  // (Measured and NOT kept here: rows two pairs ahead + scalar words three, as k_fixed.hip's block kernels do.  A lone batch's
+  // Horner launch went from 0.49 to 0.41 ms, but the kernel grew from 100 to 208 VGPRs -- two waves per SIMD instead of four --
+  // and with twenty batches in flight, where other waves cover a lane's wait anyway, the step rate fell by 7 %.)
+  fetch(l, cur, dcur);
   while (l < total) {
-    uint32_t n2[16];
-    int d2;
-    load_sc(l + 3 * LPM, sA);
-    fetch_row(l + 2 * LPM, sB, n2, d2);
+    uint32_t nxt[16];
+    int dnxt;
+    fetch(l + LPM, nxt, dnxt);
     if (dcur != 0) {
-      uint32_t any = 0;
-#pragma unroll
-      for (int t = 0; t < 16; t++) any |= cur[t];
-      if (any != 0) {   // rows of an identity generator (the ABI accepts one) are the identity: nothing to add
-        Aff q;
-        q.x = unpack<FP>(cur);
-        q.y = unpack<FP>(cur + 8);
-        if (dcur < 0) q.y = neg(q.y);
-        acc = jac_madd_nzq(acc, q);
-      }
+      Aff q;
+      q.x = unpack<FP>(cur);
+      q.y = unpack<FP>(cur + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = jac_madd_nzq(acc, q);   // identity rows were dropped in fetch()
     }
 #pragma unroll
-    for (int t = 0; t < 16; t++) { cur[t] = n1[t]; n1[t] = n2[t]; }
-#pragma unroll
-    for (int t = 0; t < 8; t++) sB[t] = sA[t];
-    dcur = d1; d1 = d2;
+    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
+    dcur = dnxt;
     l += LPM;
   }
 #pragma unroll 1

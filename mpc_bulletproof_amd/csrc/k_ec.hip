@@ -305,54 +305,24 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
   const size_t p = blockIdx.x;
   const int w = threadIdx.x;
   Jac acc = jac_inf();
-  // two-stage software prefetch (as the fixed-base lanes, k_fixed.hip): the scalar of point v + 2 and the table entry of point
-  // v + 1 are in flight while the addition of point v runs
-  auto load_sc = [&](size_t v, uint32_t *s) {
-    if (v < nvar) {
-      const uint32_t *src = scalars + (p * nvar + v) * 8;
-#pragma unroll
-      for (int t = 0; t < 8; t++) s[t] = src[t];
-    }
-  };
-  auto fetch_row = [&](size_t v, const uint32_t *s, int32_t *dst, int &dg) {
-    dg = 0;
-    if (v < nvar) {
-      uint32_t sp[9];
-      recode_add_k<SW>(sp, s);
-      dg = recode_digit<SW>(sp, w);
-      if (dg != 0) {
-        const AffRaw *e = tab + (p * nvar + v) * SE + ((dg < 0 ? -dg : dg) - 1);
-#pragma unroll
-        for (int t = 0; t < 2 * NL; t++) dst[t] = e->v[t];
-      }
-    }
-  };
-  uint32_t s1[8], s2[8];
-  int32_t cur[2 * NL];
-  int dcur = 0;
-  load_sc(0, s1);
-  load_sc(1, s2);
-  fetch_row(0, s1, cur, dcur);
 #pragma unroll 1
   for (size_t v = 0; v < nvar; v++) {
-    int32_t nxt[2 * NL];
-    int dnxt;
-    load_sc(v + 2, s1);
-    fetch_row(v + 1, s2, nxt, dnxt);
-    if (dcur != 0) {
+    uint32_t s[8], sp[9];
+    const uint32_t *src = scalars + (p * nvar + v) * 8;
+#pragma unroll
+    for (int t = 0; t < 8; t++) s[t] = src[t];
+    recode_add_k<SW>(sp, s);
+    const int dg = recode_digit<SW>(sp, w);
+    if (dg != 0) {
+      const AffRaw *e = tab + (p * nvar + v) * SE + ((dg < 0 ? -dg : dg) - 1);
       Aff q;
 #pragma unroll
-      for (int t = 0; t < NL; t++) { q.x.v[t] = cur[t]; q.y.v[t] = cur[NL + t]; }
+      for (int t = 0; t < NL; t++) { q.x.v[t] = e->v[t]; q.y.v[t] = e->v[NL + t]; }
       if (!aff_is_inf(q)) {
-        if (dcur < 0) q.y = neg(q.y);
+        if (dg < 0) q.y = neg(q.y);
         acc = jac_madd_nzq(acc, q);
       }
     }
-#pragma unroll
-    for (int t = 0; t < 2 * NL; t++) cur[t] = nxt[t];
-#pragma unroll
-    for (int t = 0; t < 8; t++) s2[t] = s1[t];
-    dcur = dnxt;
   }
   raw_store(&winsum[p * 64 + w], acc);
 }

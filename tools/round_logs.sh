@@ -15,3 +15,7 @@ WL=$R/gpurun_out/wl_burst
 [ -f $WL.1024 ] || python3 bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > gpurun_out/wl_burst.log 2>&1
 BURST_KS=1,1,1,4,4,20,20,20,64,64,256,256,1024,1024,4096 python3 tools/burst_probe.py $WL.1024 20 > gpurun_out/logs_burst_probe.log 2>&1
 python3 tools/prof_combined.py $WL.1024 20 > gpurun_out/logs_combined_bursts.log 2>&1
+# control flow of the multi-rank bench on this ONE-GPU box (two ranks share device 0 over gloo; not a measurement): the weak-scaling
+# verification legs, the combined check's all-gather and the sharded 2^14-shuffle leg
+BPGPU_BENCH_REHEARSAL=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
+  bench.py --gpus 2 --steps 6 --warmup 2 --window-bits 16 > gpurun_out/logs_rehearsal2.json 2> gpurun_out/logs_rehearsal2.err

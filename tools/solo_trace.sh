@@ -13,6 +13,6 @@ BURST_KS=1,1,1 timeout -k 10 300 rocprofv3 --kernel-trace -d $R/gpurun_out/solo_
 cd $R
 for d in solo_trace solo_trace_lat; do
   db=$(find gpurun_out/$d -name '*.db' | head -1)
-  python3 tools/timeline.py $db 1 > gpurun_out/$d.txt
+  python3 tools/timeline.py $db 1 | tail -12 > gpurun_out/$d.txt      # the last two batches (the warm-up runs without a gap)
 done
 cat gpurun_out/solo_trace_lat.txt
