@@ -12,7 +12,7 @@
 // The hash chain is the build's stand-in for merlin's HashChainTranscript (source absent from the
 // reference tree: transcript bytes are parity-unpinned); it is bit-identical to the host
 // transcripts of mpc_bulletproof_amd/host and of the oracle:
-//   append_message : state = keccak256(state || 0x00 || pad_label(l) || u64le(len) || msg)
+//   append_message : state = keccak256(state || 0x00 || pad_label(l) || u32le(len) || msg)
 //   challenge_bytes: state = keccak256(state || 0x01 || pad_label(l)),  output = state
 // One lane per proof; state and message blocks live in registers (all layouts are compile-time).
 #include "fe29.cuh"
@@ -68,25 +68,27 @@ constexpr Label mk_label(const char *s) {
   return l;
 }
 
-// state = keccak256(state[32] || flag || label[32] || tail[8 * NT]) where the tail starts at byte 65.
-// Everything after byte 32 is shifted by one byte (the flag), handled at compile time.
+// state = keccak256(state[32] || flag || label[32] [|| u32le(tail[0]) || tail[1 .. NT)]): NT = 0 is challenge_bytes (65 bytes),
+// NT > 0 append_message with tail[0] = the message length and NT - 1 message words, which start at byte 69.  The byte shifts
+// (one after the flag, five after the length) are resolved at compile time.  A 64-byte point makes 133 bytes: ONE rate block.
 template <int NT>
 __device__ __forceinline__ void chain_hash(uint64_t state[4], uint8_t flag, const Label &lab, const uint64_t *tail) {
-  constexpr int NS = 4 + NT;                 // stream words after the flag: label (4) + tail
-  constexpr int TOTAL = 33 + 8 * NS;         // message bytes
-  uint64_t strm[NS];
-#pragma unroll
-  for (int i = 0; i < 4; i++) strm[i] = lab.w[i];
-#pragma unroll
-  for (int i = 0; i < NT; i++) strm[4 + i] = tail[i];
-  // message words: w0..3 = state; w[4+i] = strm[i] << 8 | strm[i-1] >> 56 (strm[-1] = flag); last partial word
-  constexpr int NW = 4 + NS + 1;
+  constexpr int NM = NT > 0 ? NT - 1 : 0;                 // message words
+  constexpr int TOTAL = NT > 0 ? 69 + 8 * NM : 65;        // message bytes
+  constexpr int NW = 9 + NM;                               // words that hold them (the last one partially)
   uint64_t w[NW];
 #pragma unroll
   for (int i = 0; i < 4; i++) w[i] = state[i];
+  w[4] = (uint64_t)flag | (lab.w[0] << 8);
 #pragma unroll
-  for (int i = 0; i < NS; i++) w[4 + i] = (strm[i] << 8) | (i == 0 ? (uint64_t)flag : (strm[i - 1] >> 56));
-  w[4 + NS] = strm[NS - 1] >> 56;            // the one spilled byte
+  for (int i = 1; i < 4; i++) w[4 + i] = (lab.w[i - 1] >> 56) | (lab.w[i] << 8);
+  w[8] = lab.w[3] >> 56;
+  if (NT > 0) {
+    w[8] |= (tail[0] & 0xFFFFFFFFull) << 8;
+    if (NM > 0) w[8] |= tail[1] << 40;
+#pragma unroll
+    for (int i = 0; i < NM; i++) w[9 + i] = (tail[1 + i] >> 24) | (i + 1 < NM ? tail[2 + i] << 40 : 0);
+  }
   // pad: 0x01 at byte TOTAL, 0x80 at the last byte of the final block
   uint64_t st[25];
 #pragma unroll
@@ -408,22 +410,20 @@ __global__ void __launch_bounds__(64) k_ipp_round_tail(size_t nb, const JacRaw *
   if (live && l < 4) S[l] = states[p * 4 + l];
   __syncthreads();
   const CoopK ck = coop_keccak_setup(l, base);
-  // message words of append_message(label, 64-byte point): state (4 words) | then, shifted by the one flag byte: label (4 words),
-  // u64le(64), x || y (8 words) -- 18 words = 137 bytes: two rate blocks of 17 words (keccak256 padding 0x01 .. 0x80)
-  auto strm = [&](int j, const Label &lab, int pt) -> uint64_t {   // stream word j after the flag byte: label[0..3], len, point[0..7]
-    return j < 4 ? lab.w[j] : (j == 4 ? 64ull : S[4 + 8 * pt + (j - 5)]);
-  };
+  // message words of append_message(label, 64-byte point): state (4 words) | flag byte, label (32 bytes), u32le(64), x || y --
+  // 133 bytes, ONE rate block of 17 words: the label is shifted by one byte, the point by five (chain_hash's layout)
   uint64_t a = 0;
   for (int pt = 0; pt < 2; pt++) {
     const Label lab = pt == 0 ? TR_LABELS[LB_L] : TR_LABELS[LB_R];
+    const uint64_t *P = S + 4 + 8 * pt;
     uint64_t w = 0;
     if (l < 4) w = S[l];
-    else if (l < 17) w = (strm(l - 4, lab, pt) << 8) | (l == 4 ? 0ull : (strm(l - 5, lab, pt) >> 56));     // flag byte 0x00
-    a = coop_keccak_f(l < 17 ? w : 0ull, ck);                                                                // block 1 (state was zero)
-    uint64_t w2 = 0;
-    if (l == 0) w2 = (strm(12, lab, pt) >> 56) | (0x01ull << 8);          // the 137th byte, then the pad start
-    if (l == 16) w2 = 0x8000000000000000ULL;
-    a = coop_keccak_f(a ^ w2, ck);                                          // block 2
+    else if (l == 4) w = lab.w[0] << 8;                                                       // flag byte 0x00
+    else if (l < 8) w = (lab.w[l - 5] >> 56) | (lab.w[l - 4] << 8);
+    else if (l == 8) w = (lab.w[3] >> 56) | (64ull << 8) | (P[0] << 40);
+    else if (l < 16) w = (P[l - 9] >> 24) | (P[l - 8] << 40);
+    else if (l == 16) w = (P[7] >> 24) | (0x01ull << 40) | 0x8000000000000000ULL;             // bytes 128..132, pad 0x01 .. 0x80
+    a = coop_keccak_f(l < 17 ? w : 0ull, ck);
     __syncthreads();
     if (l < 4) S[l] = a;                                                    // the chain state after this append
     __syncthreads();

@@ -492,19 +492,19 @@ Scalar hash_to_scalar(const uint8_t low[32]) {
   return Scalar::from_le_bytes_mod_order_wide(buf);
 }
 Transcript::Transcript(const std::string &label) {
-  auto a = pad_label("bp-hashchain-v0"), b = pad_label(label);
+  auto a = pad_label("bp-hashchain-v1"), b = pad_label(label);
   a.insert(a.end(), b.begin(), b.end());
   keccak256(a.data(), a.size(), state_);
 }
 void Transcript::append_message(const std::string &label, const uint8_t *msg, size_t len) {
-  Keccak256 k;                              // state || 0x00 || pad_label(label) || u64le(len) || msg
+  Keccak256 k;                              // state || 0x00 || pad_label(label) || u32le(len) || msg
   const uint8_t tag = 0x00;
-  uint8_t lb[8];
-  for (int j = 0; j < 8; j++) lb[j] = (uint8_t)((uint64_t)len >> (8 * j));
+  uint8_t lb[4];
+  for (int j = 0; j < 4; j++) lb[j] = (uint8_t)((uint64_t)len >> (8 * j));
   k.absorb(state_, 32);
   k.absorb(&tag, 1);
   k.label(label);
-  k.absorb(lb, 8);
+  k.absorb(lb, 4);
   k.absorb(msg, len);
   k.finish(state_);
 }

@@ -3,8 +3,8 @@
  *
  * The transcript is a stand-in for merlin's HashChainTranscript (git fork, source absent):
  * PARITY UNPINNED.  Definition (shared with oracle/pymodel.py):
- *   state_0         = keccak256(pad_label("bp-hashchain-v0") || pad_label(label))
- *   append_message  : state = keccak256(state || 0x00 || pad_label(l) || u64le(len) || msg)
+ *   state_0         = keccak256(pad_label("bp-hashchain-v1") || pad_label(label))
+ *   append_message  : state = keccak256(state || 0x00 || pad_label(l) || u32le(len) || msg)
  *   challenge_bytes : state = keccak256(state || 0x01 || pad_label(l)); output = state
  *   pad_label(l)    = l right-padded with zeros to a multiple of 32 bytes (min 32)
  */
@@ -114,7 +114,7 @@ static size_t pad_label(uint8_t *dst, const uint8_t *label, size_t len) {
 }
 void tr_init(transcript *t, const uint8_t *label, size_t len) {
   uint8_t buf[32 + 256];
-  size_t o = pad_label(buf, (const uint8_t *)"bp-hashchain-v0", 15);
+  size_t o = pad_label(buf, (const uint8_t *)"bp-hashchain-v1", 15);
   o += pad_label(buf + o, label, len > 200 ? 200 : len);
   bpo_keccak256(buf, o, t->state);
 }
@@ -125,7 +125,7 @@ void tr_append_message(transcript *t, const char *label, const uint8_t *msg, siz
   memcpy(buf, t->state, 32); o = 32;
   buf[o++] = 0x00;
   o += pad_label(buf + o, (const uint8_t *)label, ll);
-  for (int j = 0; j < 8; j++) buf[o++] = (uint8_t)((uint64_t)len >> (8 * j));
+  for (int j = 0; j < 4; j++) buf[o++] = (uint8_t)((uint64_t)len >> (8 * j));   /* u32le, as merlin frames lengths */
   memcpy(buf + o, msg, len); o += len;
   bpo_keccak256(buf, o, t->state);
   free(buf);

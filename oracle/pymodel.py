@@ -235,19 +235,21 @@ def b2p(b: bytes):
 class Transcript:
     """Stand-in for merlin's `HashChainTranscript` (source absent; parity unpinned).
 
-    state_0            = keccak256(pad_label("bp-hashchain-v0") || pad_label(label))
-    append_message     : state = keccak256(state || 0x00 || pad_label(l) || u64le(len) || msg)
+    state_0            = keccak256(pad_label("bp-hashchain-v1") || pad_label(label))
+    append_message     : state = keccak256(state || 0x00 || pad_label(l) || u32le(len) || msg)
+                         (v1: a 4-byte length as merlin frames it -- a 64-byte point then makes a 133-byte message, ONE rate
+                         block; with v0's 8-byte length it was 137 bytes, two permutations per appended point)
     challenge_bytes(32): state = keccak256(state || 0x01 || pad_label(l)); output = state
 
     Protocol layer (labels, order, encodings) follows src/transcript.rs:63-121.
     """
 
     def __init__(self, label: bytes):
-        self.state = keccak256(pad_label(b"bp-hashchain-v0") + pad_label(label))
+        self.state = keccak256(pad_label(b"bp-hashchain-v1") + pad_label(label))
 
     def append_message(self, label: bytes, msg: bytes):
         self.state = keccak256(self.state + b"\0" + pad_label(label)
-                               + len(msg).to_bytes(8, "little") + msg)
+                               + len(msg).to_bytes(4, "little") + msg)
 
     def append_u64(self, label: bytes, x: int):
         self.append_message(label, x.to_bytes(8, "little"))
