@@ -13,8 +13,10 @@
 #include <functional>
 #include <map>
 #include <memory>
+#include <new>
 #include <stdexcept>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/bpgpu.h"
@@ -263,19 +265,21 @@ class TermMap {
   typedef std::pair<Variable, Scalar> value_type;
   typedef value_type *iterator;
   typedef const value_type *const_iterator;
+  // (the inline slots are raw storage: a fresh TermMap -- gadgets make and move about a dozen per multiplier -- does not zero 144
+  // bytes it is about to overwrite; value_type is trivially copyable and trivially destructible)
   TermMap() {}
-  TermMap(const TermMap &o) : n_(o.n_) { if (o.heap_) heap_.reset(new std::vector<value_type>(*o.heap_)); else std::copy(o.inl_, o.inl_ + o.n_, inl_); }
-  TermMap(TermMap &&o) noexcept : n_(o.n_), heap_(std::move(o.heap_)) { if (!heap_) std::copy(o.inl_, o.inl_ + o.n_, inl_); o.n_ = 0; }
+  TermMap(const TermMap &o) : n_(o.n_) { if (o.heap_) heap_.reset(new std::vector<value_type>(*o.heap_)); else copy_inl(o); }
+  TermMap(TermMap &&o) noexcept : n_(o.n_), heap_(std::move(o.heap_)) { if (!heap_) copy_inl(o); o.n_ = 0; }
   TermMap &operator=(const TermMap &o) { if (this != &o) { TermMap t(o); *this = std::move(t); } return *this; }
   TermMap &operator=(TermMap &&o) noexcept {
     n_ = o.n_; heap_ = std::move(o.heap_);
-    if (!heap_) std::copy(o.inl_, o.inl_ + o.n_, inl_);
+    if (!heap_) copy_inl(o);
     o.n_ = 0;
     return *this;
   }
-  iterator begin() { return heap_ ? heap_->data() : inl_; }
+  iterator begin() { return heap_ ? heap_->data() : inl(); }
   iterator end() { return begin() + n_; }
-  const_iterator begin() const { return heap_ ? heap_->data() : inl_; }
+  const_iterator begin() const { return heap_ ? heap_->data() : inl(); }
   const_iterator end() const { return begin() + n_; }
   size_t size() const { return n_; }
   iterator find(const Variable &k) { auto it = lower(k); return it != end() && !(k < it->first) ? it : end(); }
@@ -284,12 +288,13 @@ class TermMap {
     if (it != end() && !(k < it->first)) return it->second;
     const size_t pos = (size_t)(it - begin());
     if (!heap_ && n_ < INLINE) {
-      for (size_t i = n_; i > pos; i--) inl_[i] = inl_[i - 1];
-      inl_[pos] = value_type(k, Scalar());
+      value_type *a = inl();
+      if (n_ > pos) memmove((void *)(a + pos + 1), (const void *)(a + pos), (n_ - pos) * sizeof(value_type));
+      new (a + pos) value_type(k, Scalar());
       n_++;
-      return inl_[pos].second;
+      return a[pos].second;
     }
-    if (!heap_) { heap_.reset(new std::vector<value_type>(inl_, inl_ + n_)); heap_->reserve(2 * INLINE + 2); }
+    if (!heap_) { heap_.reset(new std::vector<value_type>(inl(), inl() + n_)); heap_->reserve(2 * INLINE + 2); }
     heap_->insert(heap_->begin() + (long)pos, value_type(k, Scalar()));
     n_++;
     return (*heap_)[pos].second;
@@ -302,7 +307,12 @@ class TermMap {
     while (it != e && it->first < k) ++it;      // a handful of terms per row: linear beats binary
     return it;
   }
-  value_type inl_[INLINE];
+  static_assert(std::is_trivially_copyable<Variable>::value && std::is_trivially_copyable<Scalar>::value &&
+                std::is_trivially_destructible<value_type>::value, "inline terms are moved as bytes");
+  value_type *inl() { return reinterpret_cast<value_type *>(raw_); }
+  const value_type *inl() const { return reinterpret_cast<const value_type *>(raw_); }
+  void copy_inl(const TermMap &o) { if (o.n_) memcpy((void *)raw_, (const void *)o.raw_, o.n_ * sizeof(value_type)); }
+  alignas(value_type) unsigned char raw_[INLINE * sizeof(value_type)];
   size_t n_ = 0;
   std::unique_ptr<std::vector<value_type>> heap_;
 };

@@ -487,7 +487,7 @@ def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
         s0.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])     # 8: more ranks than some of the vectors have entries (empty shares)
 def test_shard_partial_sums_add_up(gpu, world):
     """bpgpu_set_shard / bpgpu_r1cs_verify_shard (ONE large proof over the GPUs of a node) on one context, rank after
     rank: the partial commitments of a prover session, the partial L, R of every IPP round and the partial mega_check points of a
