@@ -724,9 +724,14 @@ def main():
             med = [sorted(r[i] for r in runs)[1] for i in range(6)]
             qs = 4 * (ks - 1) + 1
             shuffle = {"workload": f"k-shuffle gadget, k = 2^14: q = {qs} constraints, n = {2 * (ks - 1)} multipliers (phase 2), m = {2 * ks}, padded n = 2^15",
-                       "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "circuit_building_ms": med[2]},
-                       "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "circuit_building_ms": med[4]},
-                       "note": "one proof on one GPU, medians of 3; every proof verified (the call fails otherwise); OsRng blinding factors"}
+                       "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "best_ms": min(r[3] for r in runs),
+                                 "circuit_building_ms": med[2]},
+                       "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "best_ms": min(r[5] for r in runs),
+                                  "circuit_building_ms": med[4]},
+                       "note": "one proof on one GPU, medians (and best) of 3; every proof verified (the call fails otherwise); OsRng blinding "
+                               "factors.  A third of prove and half of verify is the host mirror running the gadget (65 533 constraint rows "
+                               "carrying the challenge): these two figures move with whatever else the box's CPUs are doing; circuit_building = "
+                               "the 32 768 commit calls before prove / verify (a dependent hash chain on the host)"}
 
     # ======== N > 1: configs[3] in its sharded form -- ONE 2^14-shuffle proof split over the ranks (every multi-scalar multiplication
     # by generator / point range, partial points all-gathered over RCCL and added: SURVEY 8e.2), proved and verified on all of them
