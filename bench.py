@@ -203,6 +203,51 @@ def _one_call_child(cache, window_bits):
         ts = sorted(ts[2:])
         out[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
                     "best_ms": ts[0] * 1e3}
+    # ... per-proof accept bits through the SCREENED call: the combined check of every batch first, the per-proof path only for a
+    # batch that fails it.  All proofs valid (the service's usual case), and with ONE tampered proof in the whole call.
+    import random as _random
+    rnd_ = _random.Random(0x5C2EE)
+    ORDER_N = 0x0800000000000010ffffffffffffffffb781126dcae7b2321e66a241adc64d2f
+    rho1 = b"".join(rnd_.randrange(1, ORDER_N).to_bytes(32, "little") for _ in range(nb))
+    screened = {}
+    for tag, reps in (("20k", 20), ("256k", 256)):
+        d_p2, d_s2, d_c2, d_r2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps), gpu.to_device(rho1 * reps)
+        d_o2 = gpu.malloc(4 * nb * reps)
+        ts = []
+        for rep_ in range(8):
+            gpu.sync()
+            t0 = time.perf_counter()
+            nfall = gpu.r1cs_verify_screened_dev(gens, circ, nb * reps, n1, k, d_p2, d_s2, d_c2, d_r2, d_o2)
+            gpu.sync()
+            ts.append(time.perf_counter() - t0)
+            assert nfall == 0
+        assert gpu.download(d_o2, 4 * nb * reps) == all_ok * reps
+        ts = sorted(ts[2:])
+        screened[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3}
+        if tag == "256k":      # one proof of batch 100 with t_x off by one: that batch (only) is verified proof by proof
+            bad_i = 100 * nb + 517
+            sc_bad = bytearray(sc * reps)
+            sc_bad[bad_i * 160] ^= 1
+            gpu.free(d_s2)
+            d_s2 = gpu.to_device(bytes(sc_bad))
+            ts = []
+            for rep_ in range(5):
+                gpu.sync()
+                t0 = time.perf_counter()
+                nfall = gpu.r1cs_verify_screened_dev(gens, circ, nb * reps, n1, k, d_p2, d_s2, d_c2, d_r2, d_o2)
+                gpu.sync()
+                ts.append(time.perf_counter() - t0)
+                assert nfall == 1
+            got = gpu.download(d_o2, 4 * nb * reps)
+            assert got == all_ok * 100 + all_ok[:4 * 517] + bytes(4) + all_ok[4 * 518:] + all_ok * (reps - 101)
+            ts = sorted(ts[1:])
+            screened["256k_one_bad_proof"] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "ms_per_call": ts[len(ts) // 2] * 1e3,
+                                              "fallback_batches": 1}
+        for d in (d_p2, d_s2, d_c2, d_r2, d_o2):
+            gpu.free(d)
+    screened["note"] = ("bpgpu_r1cs_verify_screened_dev: per-proof accept bits; every 1024-proof batch is first checked as ONE combined point "
+                        "(random weights), only a batch that fails is verified proof by proof.  The verdicts are those of the per-proof call")
+    out["screened"] = screened
     # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane
     reps = 64
     h_p, h_s, h_c = mb.lib.host_alloc(len(pts) * reps, pts * reps), mb.lib.host_alloc(len(sc) * reps, sc * reps), mb.lib.host_alloc(len(ch) * reps, ch * reps)

@@ -439,6 +439,22 @@ int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
 int bpgpu_r1cs_verify_combined_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
                                    size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
                                    const void *challenges_dev, const void *rho_dev, void *partial_xy_dev);
+/* SCREENED stream: per-proof accept bits at (nearly) the combined check's price when the proofs are valid -- the usual shape of
+ * a verifier service.  The call cuts the proofs into batches as bpgpu_r1cs_verify_stream does, runs the combined check
+ * sum_p rho_p * mega_check_p of every batch first (rho: nb x 32 B of caller-chosen random non-zero weights, unpredictable to
+ * the provers, as for bpgpu_r1cs_verify_combined), sets ok[p] = 1 for every proof of a batch whose point is the identity and that
+ * holds no malformed input, and runs the per-proof verification only for the other batches, so that ok[] is what
+ * bpgpu_r1cs_verify_stream returns (up to the 2^-250 chance that random weights cancel an invalid proof).  One host-side wait
+ * between the two phases (68 bytes per batch are read back).  fallback_batches (optional): how many batches took the per-proof
+ * path.  No reference API (the reference verifies proof by proof); built from verifier.rs:457-553. */
+int bpgpu_r1cs_verify_screened(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                               const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, const uint8_t *rho, int32_t *ok,
+                               size_t *fallback_batches);
+/* the same with operands, weights and ok[] resident in HBM; ok_dev is complete when bpgpu_sync (or the next call on the context)
+ * returns -- the call itself waits once, between its two phases */
+int bpgpu_r1cs_verify_screened_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                   const void *points_dev, const void *scalars_dev, const void *challenges_dev, const void *rho_dev,
+                                   void *ok_dev, size_t *fallback_batches);
 
 #ifdef __cplusplus
 }

@@ -1474,26 +1474,30 @@ static int verify_stream_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
   const size_t m = c->m, nvar = 11 + m + 2 * k, nch = 6 + k;
   HIPCK(ctx, hipEventRecord(ctx->lane_ev, ctx->st));
   for (size_t l = 0; l < nl; l++) HIPCK(ctx, hipStreamWaitEvent(ctx->lanes[l]->st, ctx->lane_ev, 0));
-  for (size_t ci = 0; ci < nchunks; ci++) {
+  int rc = BPGPU_OK;
+  for (size_t ci = 0; ci < nchunks && rc == BPGPU_OK; ci++) {
     bpgpu_ctx *ln = ctx->lanes[ci % nl];
     const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
     const uint8_t *P = points + lo * nvar * 64, *S = scalars + lo * 5 * 32, *Cc = challenges + lo * nch * 32;
     uint8_t *O = ok + lo * 4;
-    int rc;
     if (on_host) {       // operands and verdicts in (ideally page-locked) host memory: staged through the lane's own buffers
       void *dP, *dS, *dC, *dok;
-      if ((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) ||
-          (rc = ws_get(ln, 2, batch * nch * 32, &dC)) || (rc = ws_get(ln, 3, batch * 4, &dok))) { ctx->err = ln->err; return rc; }
-      if ((rc = h2d(ln, dP, P, cnt * nvar * 64)) || (rc = h2d(ln, dS, S, cnt * 5 * 32)) || (rc = h2d(ln, dC, Cc, cnt * nch * 32)) ||
-          (rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, dP, dS, dC, dok, nullptr, nullptr)) ||
-          (rc = d2h(ln, O, dok, cnt * 4))) { ctx->err = ln->err; return rc; }
-    } else if ((rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, O, nullptr, nullptr))) { ctx->err = ln->err; return rc; }
+      (void)((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) ||
+             (rc = ws_get(ln, 2, batch * nch * 32, &dC)) || (rc = ws_get(ln, 3, batch * 4, &dok)) ||
+             (rc = h2d(ln, dP, P, cnt * nvar * 64)) || (rc = h2d(ln, dS, S, cnt * 5 * 32)) || (rc = h2d(ln, dC, Cc, cnt * nch * 32)) ||
+             (rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, dP, dS, dC, dok, nullptr, nullptr)) ||
+             (rc = d2h(ln, O, dok, cnt * 4)));
+    } else rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, O, nullptr, nullptr);
+    if (rc) ctx->err = ln->err;
   }
-  for (size_t l = 0; l < nl; l++) {    // join: ctx->st (and with it bpgpu_sync / the caller's next call) waits for every lane
-    HIPCK(ctx, hipEventRecord(ctx->lanes[l]->ev1, ctx->lanes[l]->st));
-    HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->lanes[l]->ev1, 0));
+  // join (also on the way out of an error: the batches already submitted keep running, and nothing the caller does next on this
+  // context may overtake them): ctx->st -- and with it bpgpu_sync / the caller's next call -- waits for every lane
+  for (size_t l = 0; l < nl; l++) {
+    if (hipEventRecord(ctx->lanes[l]->ev1, ctx->lanes[l]->st) != hipSuccess || hipStreamWaitEvent(ctx->st, ctx->lanes[l]->ev1, 0) != hipSuccess) {
+      if (rc == BPGPU_OK) { ctx->err = "bpgpu_r1cs_verify_stream: joining the lanes failed"; rc = BPGPU_E_DEVICE; }
+    }
   }
-  return BPGPU_OK;
+  return rc;
 }
 int bpgpu_r1cs_verify_stream_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                  const void *points_dev, const void *scalars_dev, const void *challenges_dev, void *ok_dev) {
@@ -1819,6 +1823,125 @@ int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
   if (bad) return BPGPU_E_ARG;
   CK(d2h(ctx, partial_xy, dout, 64));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  return BPGPU_OK;
+}
+
+/* Screened stream: the combined check of every batch first (one point per batch), the per-proof path only for the batches whose
+ * point is not the identity (or that hold a malformed input).  Phase 1 and phase 2 each fork over the lanes and join; between them
+ * the host reads 68 bytes per batch. */
+static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                  const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, const uint8_t *rho,
+                                  uint8_t *ok, bool on_host, size_t *fallback_batches) try {
+  if (k >= 32) return BPGPU_E_LEN;
+  if (fallback_batches) *fallback_batches = 0;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  const size_t batch = (size_t)ctx->opt[BPGPU_OPT_STREAM_BATCH], nlanes_opt = (size_t)ctx->opt[BPGPU_OPT_STREAM_LANES];
+  const size_t nchunks = (nb + batch - 1) / batch, nl = nchunks < nlanes_opt ? nchunks : nlanes_opt;
+  CK(stream_lanes(ctx, nl));
+  const size_t m = c->m, nvar = 11 + m + 2 * k, nch = 6 + k;
+  void *dpart, *dflag;
+  CK(ws_get(ctx, 26, nchunks * 64, &dpart));
+  CK(ws_get(ctx, 27, nchunks * 4, &dflag));
+  std::vector<uint8_t> hpart(nchunks * 64);
+  std::vector<int> hflag(nchunks);
+  auto fork = [&]() -> int {
+    HIPCK(ctx, hipEventRecord(ctx->lane_ev, ctx->st));
+    for (size_t l = 0; l < nl; l++) HIPCK(ctx, hipStreamWaitEvent(ctx->lanes[l]->st, ctx->lane_ev, 0));
+    return BPGPU_OK;
+  };
+  auto join = [&](int rc) -> int {
+    for (size_t l = 0; l < nl; l++)
+      if (hipEventRecord(ctx->lanes[l]->ev1, ctx->lanes[l]->st) != hipSuccess || hipStreamWaitEvent(ctx->st, ctx->lanes[l]->ev1, 0) != hipSuccess)
+        if (rc == BPGPU_OK) { ctx->err = "bpgpu_r1cs_verify_screened: joining the lanes failed"; rc = BPGPU_E_DEVICE; }
+    return rc;
+  };
+  // stage a batch's operands on its lane (host variant); returns device pointers either way
+  auto operands = [&](bpgpu_ctx *ln, size_t lo, size_t cnt, const void **P, const void **S, const void **Cc, const void **R, void **dok) -> int {
+    if (!on_host) {
+      *P = points + lo * nvar * 64; *S = scalars + lo * 5 * 32; *Cc = challenges + lo * nch * 32; *R = rho + lo * 32; *dok = ok + lo * 4;
+      return BPGPU_OK;
+    }
+    void *dP, *dS, *dC, *dR;
+    int rc;
+    if ((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) || (rc = ws_get(ln, 2, batch * nch * 32, &dC)) ||
+        (rc = ws_get(ln, 3, batch * 32, &dR)) || (rc = ws_get(ln, 4, batch * 4, dok)) ||
+        (rc = h2d(ln, dP, points + lo * nvar * 64, cnt * nvar * 64)) || (rc = h2d(ln, dS, scalars + lo * 5 * 32, cnt * 5 * 32)) ||
+        (rc = h2d(ln, dC, challenges + lo * nch * 32, cnt * nch * 32)) || (rc = h2d(ln, dR, rho + lo * 32, cnt * 32)))
+      return rc;
+    *P = dP; *S = dS; *Cc = dC; *R = dR;
+    return BPGPU_OK;
+  };
+  // ---- phase 1: one combined check per batch
+  CK(fork());
+  int rc = BPGPU_OK;
+  for (size_t ci = 0; ci < nchunks && rc == BPGPU_OK; ci++) {
+    bpgpu_ctx *ln = ctx->lanes[ci % nl];
+    const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
+    const void *P, *S, *Cc, *R;
+    void *dok;
+    (void)((rc = operands(ln, lo, cnt, &P, &S, &Cc, &R, &dok)) ||
+           (rc = verify_combined_locked(ln, g, c, cnt, n1, k, P, S, Cc, R, (uint8_t *)dpart + 64 * ci)));
+    if (rc == BPGPU_OK && hipMemcpyAsync((int *)dflag + ci, ln->d_flag, 4, hipMemcpyDeviceToDevice, ln->st) != hipSuccess) rc = BPGPU_E_DEVICE;
+    if (rc) ctx->err = ln->err;
+  }
+  rc = join(rc);
+  if (rc) return rc;
+  CK(d2h(ctx, hpart.data(), dpart, nchunks * 64));
+  CK(d2h(ctx, hflag.data(), dflag, nchunks * 4));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  // ---- phase 2: all-accept for the batches that passed, the per-proof verification for the others
+  size_t nfall = 0;
+  CK(fork());
+  for (size_t ci = 0; ci < nchunks && rc == BPGPU_OK; ci++) {
+    const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
+    bool pass = hflag[ci] == 0;
+    for (size_t i = 0; i < 64 && pass; i++) pass = hpart[64 * ci + i] == 0;
+    if (pass) {
+      if (on_host) for (size_t i = 0; i < cnt; i++) ((int32_t *)ok)[lo + i] = 1;
+      else if (hipMemsetD32Async((hipDeviceptr_t)(ok + lo * 4), 1, cnt, ctx->st) != hipSuccess) rc = BPGPU_E_DEVICE;
+      continue;
+    }
+    bpgpu_ctx *ln = ctx->lanes[nfall++ % nl];
+    const void *P, *S, *Cc, *R;
+    void *dok;
+    (void)((rc = operands(ln, lo, cnt, &P, &S, &Cc, &R, &dok)) ||
+           (rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, dok, nullptr, nullptr)) ||
+           (on_host && (rc = d2h(ln, ok + lo * 4, dok, cnt * 4))));
+    if (rc) ctx->err = ln->err;
+  }
+  rc = join(rc);
+  if (fallback_batches) *fallback_batches = nfall;
+  return rc;
+} catch (const std::bad_alloc &) {
+  return BPGPU_E_OOM;
+}
+int bpgpu_r1cs_verify_screened_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                   const void *points_dev, const void *scalars_dev, const void *challenges_dev, const void *rho_dev,
+                                   void *ok_dev, size_t *fallback_batches) {
+  if (!ctx || !g || !c || (nb && (!points_dev || !scalars_dev || !challenges_dev || !rho_dev || !ok_dev))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_screened_locked(ctx, g, c, nb, n1, k, (const uint8_t *)points_dev, (const uint8_t *)scalars_dev,
+                                (const uint8_t *)challenges_dev, (const uint8_t *)rho_dev, (uint8_t *)ok_dev, false, fallback_batches);
+}
+int bpgpu_r1cs_verify_screened(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                               const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, const uint8_t *rho, int32_t *ok,
+                               size_t *fallback_batches) {
+  if (!ctx || !g || !c || (nb && (!points || !scalars || !challenges || !rho || !ok))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  if (fallback_batches) *fallback_batches = 0;
+  if (!nb) return BPGPU_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  if (ctx->pinned_cap < nb * 4) {       // verdicts of the fallback batches come back through page-locked staging (bpgpu_r1cs_verify_stream)
+    if (ctx->pinned) { HIPCK(ctx, hipStreamSynchronize(ctx->st)); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; ctx->pinned_cap = 0; }
+    HIPCK(ctx, hipHostMalloc(&ctx->pinned, nb * 4 + nb, hipHostMallocDefault));
+    ctx->pinned_cap = nb * 4 + nb;
+  }
+  CK(verify_screened_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, rho, (uint8_t *)ctx->pinned, true, fallback_batches));
+  HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  memcpy(ok, ctx->pinned, nb * 4);
   return BPGPU_OK;
 }
 

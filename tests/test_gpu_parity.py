@@ -487,6 +487,61 @@ def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
         s0.close()
 
 
+@pytest.mark.parametrize("on_host", [False, True])
+def test_verify_screened_combined_check_first_per_proof_on_failure(gpu, opts, on_host):
+    """bpgpu_r1cs_verify_screened(_dev): 150 proofs of the 8-bit range gadget in batches of 16 over three lanes.  All valid: every
+    batch passes its combined check, no batch takes the per-proof path, every verdict is 1.  With three tampered proofs (in two
+    batches) and one proof whose point bytes are off the curve (a third batch): exactly those three batches fall back to the
+    per-proof path and the verdicts equal the oracle's proof by proof -- what bpgpu_r1cs_verify_stream returns."""
+    import random
+    nb, tamper = 150, {2, 77, 78}
+    opts(stream_batch=16, stream_lanes=3)
+    good, cap = bh.make_range_batch(8, nb)
+    bad, _ = bh.make_range_batch(8, nb, tamper=tamper)
+    s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], good[0][1], good[0][0], cap)
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    rnd = random.Random(4242)
+    rho = b"".join(o.s2b(rnd.randrange(1, o.N)) for _ in range(nb))
+    try:
+        def pack(recs):
+            pts = sc = ch = b""
+            for proof, com in recs:
+                s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap)
+                k, p, q = bh.verify_inputs(proof, com)
+                pts, sc, ch = pts + p, sc + q, ch + s.challenges()
+                s.close()
+            return pts, sc, ch
+
+        def run(pts, sc, ch):
+            if on_host:
+                return gpu.r1cs_verify_screened(g, circ, nb, s0.n1, s0.k, pts, sc, ch, rho)
+            dp, ds, dc, dr, dok = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch), gpu.to_device(rho), gpu.malloc(4 * nb)
+            nf = gpu.r1cs_verify_screened_dev(g, circ, nb, s0.n1, s0.k, dp, ds, dc, dr, dok)
+            ok = [int.from_bytes(gpu.download(dok, 4 * nb)[4 * i:4 * i + 4], "little") for i in range(nb)]
+            for d in (dp, ds, dc, dr, dok):
+                gpu.free(d)
+            return ok, nf
+        pts, sc, ch = pack(good)
+        for rep in range(2):
+            ok, nf = run(pts, sc, ch)
+            assert ok == [1] * nb and nf == 0, rep
+        pts, sc, ch = pack(bad)
+        nvar = 11 + s0.m + 2 * s0.k
+        off = (120 * nvar + 1) * 64                   # proof 120 (batch 7), its second point: y := y + 1 leaves the curve
+        y = (int.from_bytes(pts[off + 32:off + 64], "little") + 1) % (1 << 251)
+        pts = pts[:off + 32] + y.to_bytes(32, "little") + pts[off + 64:]
+        want = [0 if (i in tamper or i == 120) else 1 for i in range(nb)]
+        ok, nf = run(pts, sc, ch)
+        assert ok == want and nf == 3                  # batches 0 (proof 2), 4 (proofs 77, 78), 7 (proof 120)
+        ok_stream = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch)
+        assert ok_stream == want
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s0.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])     # 8: more ranks than some of the vectors have entries (empty shares)
 def test_shard_partial_sums_add_up(gpu, world):
     """bpgpu_set_shard / bpgpu_r1cs_verify_shard (ONE large proof over the GPUs of a node) on one context, rank after
