@@ -1020,9 +1020,9 @@ R1CSProof R1CSProof::from_flat_bytes(const std::vector<uint8_t> &b) {
 // it holds) a dozen times while the 2^14-shuffle pushes its 65 533 rows -- a fifth of the gadget's time.
 class RowStore {
  public:
-  static constexpr size_t BLOCK = 1024;
+  static constexpr size_t BLOCK = 256;     // 40 KB: below malloc's mmap threshold, so the blocks of the next proof come from the freed ones (no page faults)
   void push_back(LinearCombination &&lc) {
-    if (n_ == blocks_.size() * BLOCK) blocks_.emplace_back(new LinearCombination[BLOCK]);
+    if (n_ == blocks_.size() * BLOCK) { std::unique_ptr<LinearCombination[]> b(new LinearCombination[BLOCK]); blocks_.push_back(std::move(b)); }
     blocks_[n_ / BLOCK][n_ % BLOCK] = std::move(lc);
     n_++;
   }
