@@ -153,6 +153,85 @@ BP_HD Jac jac_madd_nzq(const Jac &p, const Aff &q) {
   return jac_select(jac_is_inf(p), qj, r);
 }
 
+// ---- extended Jacobian accumulators (X : Y : ZZ : ZZZ), x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2 ------------------------------
+// A mixed addition into such an accumulator is 8M + 2S (madd-2008-s) against 8M + 3S for the Jacobian one: Z^2 and Z^3 are
+// carried instead of recomputed.  Used where a lane only ADDS table entries to its accumulator (fixed-base walks, window sums,
+// bucket accumulation); the lane converts to Jacobian once (3M + 1S) before its result meets doublings or reductions.
+// Identity <=> all limbs of ZZ are literally zero (ZZZ then is, too).
+struct Xyzz { Fp X, Y, ZZ, ZZZ; };
+BP_HD Xyzz xyzz_inf() {
+  Xyzz r;
+  r.X = fe_one<FP>(); r.Y = fe_one<FP>(); r.ZZ = fe_zero<FP>(); r.ZZZ = fe_zero<FP>();
+  return r;
+}
+BP_HD bool xyzz_is_inf(const Xyzz &p) { return is_zero_limbs(p.ZZ); }
+BP_HD Xyzz xyzz_from_jac(const Jac &p) {
+  Xyzz r;
+  r.X = p.X; r.Y = p.Y; r.ZZ = fpsqr(p.Z); r.ZZZ = fpmul(r.ZZ, p.Z);
+  return r;
+}
+// (X ZZ^2 : Y ZZ^3 : ZZZ) is the same point in Jacobian coordinates (Z = ZZZ: Z^2 = ZZ^3, Z^3 = ZZZ^3 = ZZ^3 ZZZ)
+BP_HD Jac xyzz_to_jac(const Xyzz &p) {
+  Jac r;
+  Fp z2 = fpsqr(p.ZZ);
+  r.X = fpmul(p.X, z2);
+  r.Y = fpmul(p.Y, fpmul(z2, p.ZZ));
+  r.Z = p.ZZZ;
+  return r;
+}
+BP_HD Xyzz xyzz_hide(const Xyzz &a) { Xyzz r; r.X = fp_hide(a.X); r.Y = fp_hide(a.Y); r.ZZ = fp_hide(a.ZZ); r.ZZZ = fp_hide(a.ZZZ); return r; }
+struct XMid { Fp P, R; };
+BP_HD XMid xyzz_madd_mid(const Xyzz &p, const Aff &q) {
+  XMid m;
+  m.P = sub_nr(fpmul(q.x, p.ZZ), p.X);     // a product minus a tight coordinate, left un-normalised (jac_madd_mid)
+  m.R = sub_nr(fpmul(q.y, p.ZZZ), p.Y);
+  return m;
+}
+BP_HD Xyzz xyzz_madd_tail(const Xyzz &p, const XMid &m) {
+  Fp PP = fpsqr(m.P), PPP = fpmul(m.P, PP), Q = fpmul(p.X, PP);
+  Xyzz r;
+  r.X = norm(sub_nr(sub_nr(sub_nr(fpsqr(m.R), PPP), Q), Q));
+  r.Y = sub(fpmul(m.R, sub_nr(Q, r.X)), fpmul(p.Y, PPP));
+  r.ZZ = fpmul(p.ZZ, PP);
+  r.ZZZ = fpmul(p.ZZZ, PPP);
+  return r;
+}
+BP_COLD void xyzz_madd_full(Xyzz *out, const Xyzz *pp, const Aff *qq) {
+  const Xyzz p = *pp;
+  const Aff q = *qq;
+  if (aff_is_inf(q)) { *out = p; return; }
+  Xyzz qe; qe.X = q.x; qe.Y = q.y; qe.ZZ = fe_one<FP>(); qe.ZZZ = fe_one<FP>();
+  if (xyzz_is_inf(p)) { *out = qe; return; }
+  XMid m = xyzz_madd_mid(p, q);
+  if (is_zero_exact(m.P)) {
+    if (is_zero_exact(m.R)) { Jac t; t.X = q.x; t.Y = q.y; t.Z = fe_one<FP>(); *out = xyzz_from_jac(jac_dbl_fast(t)); return; }   // y != 0: odd order
+    *out = xyzz_inf();
+    return;
+  }
+  *out = xyzz_madd_tail(p, m);
+}
+BP_HD Xyzz xyzz_select(bool c, const Xyzz &a, const Xyzz &b) {
+  Xyzz r;
+#pragma unroll
+  for (int j = 0; j < NL; j++) {
+    r.X.v[j] = c ? a.X.v[j] : b.X.v[j]; r.Y.v[j] = c ? a.Y.v[j] : b.Y.v[j];
+    r.ZZ.v[j] = c ? a.ZZ.v[j] : b.ZZ.v[j]; r.ZZZ.v[j] = c ? a.ZZZ.v[j] : b.ZZZ.v[j];
+  }
+  return r;
+}
+// q must not be the identity (callers skip identity table entries); an identity accumulator is resolved by a select
+BP_HD Xyzz xyzz_madd_nzq(const Xyzz &p, const Aff &q) {
+  XMid m = xyzz_madd_mid(p, q);
+  if (fp_maybe_zero(m.P)) { Xyzz pc = xyzz_hide(p), r; Aff qc = aff_hide(q); xyzz_madd_full(&r, &pc, &qc); return xyzz_hide(r); }
+  Xyzz r = xyzz_madd_tail(p, m);
+  Xyzz qe; qe.X = q.x; qe.Y = q.y; qe.ZZ = fe_one<FP>(); qe.ZZZ = fe_one<FP>();
+  return xyzz_select(xyzz_is_inf(p), qe, r);
+}
+BP_HD Xyzz xyzz_madd(const Xyzz &p, const Aff &q) {
+  Xyzz r = xyzz_madd_nzq(p, q);
+  return xyzz_select(aff_is_inf(q), p, r);
+}
+
 // general addition: 12M + 4S
 struct AddMid { Fp U1, S1, H, rr; };
 BP_HD AddMid jac_add_mid(const Jac &p, const Jac &q) {

@@ -21,7 +21,7 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
   const uint32_t *sc = scalars + b * sc_stride;
   const size_t total = (2 + 2 * n) * W;
   const size_t hshift = cap - n;
-  Jac acc = jac_inf();
+  Xyzz acc = xyzz_inf();       // the lane only adds table entries: extended-Jacobian accumulator, 8M + 2S per addition (ec29.cuh)
   uint32_t cur[16];
   int dcur = 0;
   size_t l = lane;
@@ -58,25 +58,26 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
       q.x = unpack<FP>(cur);
       q.y = unpack<FP>(cur + 8);
       if (dcur < 0) q.y = neg(q.y);
-      acc = jac_madd_nzq(acc, q);   // identity rows were dropped in fetch()
+      acc = xyzz_madd_nzq(acc, q);   // identity rows were dropped in fetch()
     }
 #pragma unroll
     for (int t = 0; t < 16; t++) cur[t] = nxt[t];
     dcur = dnxt;
     l += LPM;
   }
+  Jac accj = xyzz_to_jac(acc);
 #pragma unroll 1
   for (int off = LPM / 2; off > 0; off >>= 1) {
     Jac q;
 #pragma unroll
     for (int t = 0; t < NL; t++) {
-      q.X.v[t] = __shfl_xor(acc.X.v[t], off, 64);
-      q.Y.v[t] = __shfl_xor(acc.Y.v[t], off, 64);
-      q.Z.v[t] = __shfl_xor(acc.Z.v[t], off, 64);
+      q.X.v[t] = __shfl_xor(accj.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(accj.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(accj.Z.v[t], off, 64);
     }
-    acc = jac_add(acc, q);
+    accj = jac_add(accj, q);
   }
-  if (lane == 0 && live) raw_store(&out[b], acc);
+  if (lane == 0 && live) raw_store(&out[b], accj);
 }
 struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
 

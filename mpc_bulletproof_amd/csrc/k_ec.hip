@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
                                                        size_t nvar, JacRaw *winsum) {
   const size_t p = blockIdx.x;
   const int w = threadIdx.x;
-  Jac acc = jac_inf();
+  Xyzz acc = xyzz_inf();       // additions only: extended-Jacobian accumulator (ec29.cuh)
 #pragma unroll 1
   for (size_t v = 0; v < nvar; v++) {
     uint32_t s[8], sp[9];
@@ -320,11 +320,11 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
       for (int t = 0; t < NL; t++) { q.x.v[t] = e->v[t]; q.y.v[t] = e->v[NL + t]; }
       if (!aff_is_inf(q)) {
         if (dg < 0) q.y = neg(q.y);
-        acc = jac_madd_nzq(acc, q);
+        acc = xyzz_madd_nzq(acc, q);
       }
     }
   }
-  raw_store(&winsum[p * 64 + w], acc);
+  raw_store(&winsum[p * 64 + w], xyzz_to_jac(acc));
 }
 // Horner over the 64 window sums in two stages.  Stage 1, one lane per (proof, group of 8 windows):
 // T_g = sum_{i<8} 16^i S_{8g+i} (28 doublings, 7 additions), written over S_{8g}.  Stage 2, one lane per proof:

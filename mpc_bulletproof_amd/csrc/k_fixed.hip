@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
   const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
   const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
   const size_t hshift = cap - n;
-  Jac acc = jac_inf();
+  Xyzz acc = xyzz_inf();      // additions only: extended-Jacobian accumulator (8M + 2S per table addition, ec29.cuh)
   // Staged software prefetch: the table row of pair l + 2 TPB is requested before the addition of pair l starts (a random 64-byte
   // row of a multi-GB table is a TLB miss + an HBM access: one addition, ~3 us, does not always cover it), and the scalar words
   // that row's ADDRESS is computed from one iteration earlier still -- the dependent chain scalar load -> recoding -> row load
@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
       q.x = unpack<FP>(cur);
       q.y = unpack<FP>(cur + 8);
       if (dcur < 0) q.y = neg(q.y);
-      acc = jac_madd(acc, q);
+      acc = xyzz_madd(acc, q);
     }
 #pragma unroll
     for (int t = 0; t < 16; t++) { cur[t] = n1[t]; n1[t] = n2[t]; }
@@ -83,8 +83,8 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm(const AffDev *table, size_t n
     dcur = d1; d1 = d2;
     l += TPB;
   }
-  acc = block_sum<TPB>(acc, red);
-  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+  Jac accj = block_sum<TPB>(xyzz_to_jac(acc), red);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], accj);
 }
 template <int C, int LPM>
 __global__ void __launch_bounds__(64) k_fixed_msm_small(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
   const size_t total = per * W;
   const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
   const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
-  Jac acc = jac_inf();
+  Xyzz acc = xyzz_inf();
   // staged prefetch as in k_fixed_msm
   auto load_sc = [&](size_t ll, uint32_t *s) {
     if (ll < hi) {
@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
       q.x = unpack<FP>(curw);
       q.y = unpack<FP>(curw + 8);
       if (dcur < 0) q.y = neg(q.y);
-      acc = jac_madd(acc, q);
+      acc = xyzz_madd(acc, q);
     }
 #pragma unroll
     for (int k = 0; k < 16; k++) { curw[k] = n1[k]; n1[k] = n2[k]; }
@@ -197,8 +197,8 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
     dcur = d1; d1 = d2;
     l += TPB;
   }
-  acc = block_sum<TPB>(acc, red);
-  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], acc);
+  Jac accj = block_sum<TPB>(xyzz_to_jac(acc), red);
+  if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], accj);
 }
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
   size_t total = (1 + n0) * (252 / c + 1);

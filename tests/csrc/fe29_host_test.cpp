@@ -69,6 +69,8 @@ int h29_fp(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) { return bi
 int h29_fn(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) { return binop<FN>(op, a, b, out); }
 
 // op 0: madd(a, b)  1: add(jac a, jac b') with b' rescaled by a random-ish Z  2: dbl(a)
+// op 3: the same sum through the extended-Jacobian accumulator: ((identity + a) + b) by xyzz_madd, back through xyzz_to_jac
+// op 4: (a rescaled to a non-trivial ZZ / ZZZ) + b by xyzz_madd_nzq (b must not be the identity)
 int h29_point(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
   Aff p, q;
   if (!load_pt(p, a) || !load_pt(q, b)) return -1;
@@ -82,6 +84,15 @@ int h29_point(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     if (!jac_is_inf(qj)) { qj.X = mul(qj.X, z2); qj.Y = mul(qj.Y, z3); qj.Z = mul(qj.Z, z); }
     if (!jac_is_inf(pj)) { Fp w = add(z, z2), w2 = sqr(w), w3 = mul(w2, w); pj.X = mul(pj.X, w2); pj.Y = mul(pj.Y, w3); pj.Z = mul(pj.Z, w); }
     r = jac_add(pj, qj);
+  } else if (op == 3) {
+    Xyzz acc = xyzz_madd(xyzz_madd(xyzz_inf(), p), q);
+    r = xyzz_to_jac(acc);
+  } else if (op == 4) {
+    if (aff_is_inf(q)) return -3;
+    Jac t = pj;
+    Fp z = to_mont(unpack<FP>((const uint32_t[8]){0x54321, 11, 5, 0, 0, 0, 0, 0}));
+    if (!jac_is_inf(t)) { Fp z2 = sqr(z), z3 = mul(z2, z); t.X = mul(t.X, z2); t.Y = mul(t.Y, z3); t.Z = mul(t.Z, z); }
+    r = xyzz_to_jac(xyzz_madd_nzq(xyzz_from_jac(t), q));
   } else r = jac_dbl(pj);
   store_pt(out, r);
   return 0;
