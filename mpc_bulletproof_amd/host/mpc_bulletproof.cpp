@@ -1709,12 +1709,17 @@ Verifier::BatchInputs Verifier::transcript_replay(const R1CSProof &proof, const 
       ch.push_back(tr.challenge_scalar("u"));
     }
     ch[5] = tr.challenge_scalar("r");                                                   // :506
-    std::vector<StarkPoint> pts{proof.A_I1, proof.A_O1, proof.S1, proof.A_I2, proof.A_O2, proof.S2};
-    pts.insert(pts.end(), c.V.begin(), c.V.end());
-    for (auto *q : {&proof.T_1, &proof.T_3, &proof.T_4, &proof.T_5, &proof.T_6}) pts.push_back(*q);
-    pts.insert(pts.end(), proof.ipp_proof.L_vec.begin(), proof.ipp_proof.L_vec.end());
-    pts.insert(pts.end(), proof.ipp_proof.R_vec.begin(), proof.ipp_proof.R_vec.end());
-    in.points = pack_points(pts);
+    // the points in bpgpu_r1cs_verify_batch's order, written once (a StarkPoint IS its 64 boundary bytes: the 32 768 commitments
+    // of a 2^14-shuffle are one 2 MB copy, not two vectors of points and a packing pass)
+    static_assert(sizeof(StarkPoint) == 64, "StarkPoint must be its 64 boundary bytes");
+    in.points.resize((11 + c.V.size() + 2 * k) * 64);
+    uint8_t *dst = in.points.data();
+    auto put = [&](const StarkPoint *q, size_t count) { if (count) memcpy(dst, q, 64 * count); dst += 64 * count; };
+    for (auto *q : {&proof.A_I1, &proof.A_O1, &proof.S1, &proof.A_I2, &proof.A_O2, &proof.S2}) put(q, 1);
+    put(c.V.data(), c.V.size());
+    for (auto *q : {&proof.T_1, &proof.T_3, &proof.T_4, &proof.T_5, &proof.T_6}) put(q, 1);
+    put(proof.ipp_proof.L_vec.data(), k);
+    put(proof.ipp_proof.R_vec.data(), k);
     in.scalars = pack_scalars({proof.t_x, proof.t_x_blinding, proof.e_blinding, proof.ipp_proof.a, proof.ipp_proof.b});
     in.challenges = pack_scalars(ch);
   } catch (const ProofException &) {
