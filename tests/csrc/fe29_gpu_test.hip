@@ -55,6 +55,8 @@ template <class F> __global__ void k_rawmul(int sq, const int32_t *a, const int3
   for (int j = 0; j < 8; j++) out[8 * i + j] = t[j];
 }
 // op 0: madd(a, b)  1: add(jac a, jac b) with both operands rescaled to non-trivial Z  2: dbl(a)   (as h29_point)
+// op 3: ((identity + a) + b) through the extended-Jacobian accumulator (xyzz_madd), 4: (a with a non-trivial ZZ / ZZZ) + b by
+// xyzz_madd_nzq -- the additions of the fixed-base walks and window sums, incl. their out-of-line exact cases
 __global__ void k_point(int op, const uint32_t *a, const uint32_t *b, uint32_t *out, int *rc, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -72,6 +74,15 @@ __global__ void k_point(int op, const uint32_t *a, const uint32_t *b, uint32_t *
     if (!jac_is_inf(qj)) { qj.X = mul(qj.X, z2); qj.Y = mul(qj.Y, z3); qj.Z = mul(qj.Z, z); }
     if (!jac_is_inf(pj)) { Fp w = add(z, z2), w2 = sqr(w), w3 = mul(w2, w); pj.X = mul(pj.X, w2); pj.Y = mul(pj.Y, w3); pj.Z = mul(pj.Z, w); }
     r = jac_add(pj, qj);
+  } else if (op == 3) {
+    r = xyzz_to_jac(xyzz_madd(xyzz_madd(xyzz_inf(), p), q));
+  } else if (op == 4) {
+    if (aff_is_inf(q)) { rc[i] = -3; return; }
+    Jac t = pj;
+    const uint32_t zw[8] = {0x54321, 11, 5, 0, 0, 0, 0, 0};
+    Fp z = to_mont(unpack<FP>(zw));
+    if (!jac_is_inf(t)) { Fp z2 = sqr(z), z3 = mul(z2, z); t.X = mul(t.X, z2); t.Y = mul(t.Y, z3); t.Z = mul(t.Z, z); }
+    r = xyzz_to_jac(xyzz_madd_nzq(xyzz_from_jac(t), q));
   } else r = jac_dbl(pj);
   uint32_t wo[16];
   aff_to_boundary(wo, jac_to_aff(r));

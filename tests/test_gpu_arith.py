@@ -120,12 +120,15 @@ def test_point_ops_including_exceptional_cases_on_device(g):
     a = (C.c_uint8 * (64 * n)).from_buffer_copy(b"".join(pm.p2b(x) for x, _ in pairs))
     b = (C.c_uint8 * (64 * n)).from_buffer_copy(b"".join(pm.p2b(y) for _, y in pairs))
     out, rc = (C.c_uint8 * (64 * n))(), (C.c_int * n)()
-    for op in (0, 1, 2):
+    for op in (0, 1, 2, 3, 4):       # 3, 4: the extended-Jacobian accumulator's mixed addition (fixed-base walks, window sums)
         assert g.g29_point(op, a, b, C.c_size_t(n), out, rc) == 0, "no HIP device"
-        assert not any(rc)
         ob = bytes(out)
         for i, (x, y) in enumerate(pairs):
-            want = pm.pt_add(x, y) if op < 2 else pm.pt_add(x, x)
+            if op == 4 and y is pm.INF:
+                assert rc[i] == -3       # xyzz_madd_nzq is for non-identity addends only
+                continue
+            assert rc[i] == 0
+            want = pm.pt_add(x, x) if op == 2 else pm.pt_add(x, y)
             assert pm.b2p(ob[64 * i:64 * i + 64]) == want, (op, x, y)
     # off-curve input is rejected
     bad = bytearray(pm.p2b(pm.G))
