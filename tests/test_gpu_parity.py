@@ -1260,6 +1260,53 @@ def test_verify_with_device_transcript(gpu):
             gpu.circuit_destroy(circ)
 
 
+def test_whole_verify_differential_fuzz(gpu):
+    """Random byte flips ANYWHERE in the proof or the commitment (points knocked off the curve, non-canonical coordinates and
+    scalars, identity points, flipped transcript material): the GPU's whole Verifier::verify (device transcript + verification,
+    one batch) returns the oracle's verdict for every proof.  tools/fuzz_verify.py is the long form of this test."""
+    import random
+    sys_path_oracle()
+    import pymodel as pm
+    rnd = random.Random(9001)
+    for n_bits, nb in ((8, 96), (64, 40)):
+        cap = 1 << max(0, (n_bits - 1).bit_length())
+        recs = []
+        for i in range(nb):
+            rc, proof, com = o.r1cs_prove(o.K_RANGE, n_bits, b"RangeProofTest", [rnd.getrandbits(n_bits)], rnd.getrandbits(40), cap)
+            assert rc == 0
+            proof, com = bytearray(proof), bytearray(com)
+            mode = rnd.randrange(8)
+            if mode >= 2:
+                for _ in range(rnd.choice((1, 1, 2, 3))):
+                    if mode == 7:
+                        com[rnd.randrange(len(com))] ^= 1 << rnd.randrange(8)
+                    elif mode == 6:
+                        slot = rnd.randrange(11)
+                        proof[8 + 64 * slot:8 + 64 * slot + 64] = bytes(64)
+                    elif mode == 5:
+                        proof[8 + 32 * rnd.randrange((len(proof) - 8) // 32) + 31] |= 0xF0
+                    else:
+                        proof[8 + rnd.randrange(len(proof) - 8)] ^= 1 << rnd.randrange(8)
+            recs.append((bytes(proof), bytes(com)))
+        good = o.r1cs_prove(o.K_RANGE, n_bits, b"RangeProofTest", [1], 7, cap)
+        s0 = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], good[2], good[1], cap)
+        circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+        g = _gens(gpu, cap, 8)
+        try:
+            pts = sc = b""
+            for proof, com in recs:
+                k, p, q = bh.verify_inputs(proof, com)
+                pts, sc = pts + p, sc + q
+            ok, _, _ = gpu.r1cs_verify_batch_fs(g, circ, nb, s0.n1, s0.k, s0.m, pm.Transcript(b"RangeProofTest").state * nb, pts, sc, want_mega=False)
+            want = [1 if o.r1cs_verify(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap) == 0 else 0 for proof, com in recs]
+            assert ok == want
+            assert 0 < sum(want) < nb          # the sample holds accepted and rejected proofs
+        finally:
+            gpu.gens_destroy(g)
+            gpu.circuit_destroy(circ)
+            s0.close()
+
+
 def test_two_phase_circuits_batched_with_device_transcript(gpu):
     """SURVEY 8f N1 for circuits with RANDOMIZED constraints (verifier.rs:366-385): four k-shuffle proofs with different
     inputs -- hence four different gadget challenges z -- verified in ONE batch against ONE parametric circuit (coefficient
