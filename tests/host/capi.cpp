@@ -102,6 +102,13 @@ int bph_r1cs_prove(int kind, size_t param, const uint8_t *label, size_t label_le
       if (nvalues != 1) return -3;
       commit(values[0]);
       gadgets::range_proof(prover, LinearCombination(vars[0]), &values[0], param);
+    } else if (kind == K_RANGE_MULTI) {   // several values range-proved in ONE constraint system: param = n_bits | nvals << 16
+      const size_t nbits = param & 0xffff, nv = param >> 16;
+      if (nvalues != nv) return -3;
+      for (size_t i = 0; i < nv; i++) {
+        commit(values[i]);
+        gadgets::range_proof(prover, LinearCombination(vars[i]), &values[i], nbits);
+      }
     } else if (kind == K_SHUFFLE) {
       if (nvalues != 2 * param) return -3;
       for (size_t i = 0; i < 2 * param; i++) commit(values[i]);

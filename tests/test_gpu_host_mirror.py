@@ -24,7 +24,7 @@ def _prove(host, kind, param, label, values, seed, cap):
     vals = (C.c_uint64 * max(len(values), 1))(*values)
     proof = (C.c_uint8 * 8192)()
     plen, m = C.c_size_t(0), C.c_size_t(0)
-    com = (C.c_uint8 * (64 * max(1, 2 * param, 5)))()
+    com = (C.c_uint8 * (64 * max(1, 2 * param if kind == o.K_SHUFFLE else param >> 16, 5)))()
     rc = host.bph_r1cs_prove(kind, C.c_size_t(param), o._buf(label), C.c_size_t(len(label)), vals, C.c_size_t(len(values)),
                              C.c_uint64(seed), C.c_size_t(cap), proof, C.byref(plen), com, C.byref(m))
     return rc, bytes(proof)[:plen.value], bytes(com)[:64 * m.value]
@@ -82,6 +82,39 @@ def test_prover_bytes_identical_to_oracle(host, golden_r1cs):
     for rec in golden_r1cs["example"]:
         rc, proof, com = _prove(host, o.K_EXAMPLE, 0, H(rec["label"]), rec["values"], rec["seed"], 16)
         assert rc == 0 and proof == H(rec["proof"])
+
+
+def test_prover_bytes_identical_to_oracle_on_random_circuits(host):
+    """The same byte equality away from the golden sizes: range gadgets of random widths (incl. widths that are not powers of two:
+    padded n), several values in one constraint system, k-shuffles of random k, dummy circuits, random values, seeds and labels,
+    in both blinding modes; the GPU verifier accepts each proof and rejects it after a one-bit flip, as the oracle does."""
+    import random
+    rnd = random.Random(20261004)
+    cases = [(o.K_RANGE, nb_, [rnd.getrandbits(nb_)]) for nb_ in (1, 3, 7, 13, 24, 33, 47, 64)]
+    cases += [(o.K_RANGE_MULTI, nb_ | (nv << 16), [rnd.getrandbits(nb_) for _ in range(nv)]) for nb_, nv in ((8, 3), (16, 5), (5, 2), (64, 2))]
+    for k in (2, 3, 5, 12):
+        xs = [rnd.getrandbits(64) for _ in range(k)]
+        ys = list(xs)
+        rnd.shuffle(ys)
+        cases.append((o.K_SHUFFLE, k, xs + ys))
+    cases += [(o.K_DUMMY, n, []) for n in (3, 20)]
+    for vkeys in (0, 1):
+        host.bph_set_seeded_vector_keys(vkeys)
+        try:
+            for kind, param, values in cases:
+                label = bytes(rnd.getrandbits(8) | 1 for _ in range(rnd.randrange(1, 30)))
+                seed, cap = rnd.getrandbits(48), 128
+                rc_o, proof_o, com_o = o.r1cs_prove(kind, param, label, values, seed, cap, vector_keys=bool(vkeys))
+                rc, proof, com = _prove(host, kind, param, label, values, seed, cap)
+                assert rc == rc_o == 0 and proof == proof_o and com == com_o, (kind, param, vkeys)
+                vals_v = values if kind == o.K_DUMMY else []
+                assert _verify(host, kind, param, label, vals_v, com, proof, cap)[0] == 0
+                bad = bytearray(proof)
+                bad[8 + 11 * 64 + rnd.randrange(96)] ^= 1 << rnd.randrange(7)         # t_x / t_x_blinding / e_blinding
+                rc_bad = _verify(host, kind, param, label, vals_v, com, bytes(bad), cap)[0]
+                assert rc_bad != 0 and (o.r1cs_verify(kind, param, label, vals_v, com, bytes(bad), cap) != 0)
+        finally:
+            host.bph_set_seeded_vector_keys(0)
 
 
 def test_verifier_matches_oracle(host, golden_r1cs):
