@@ -224,7 +224,7 @@ def _one_call_child(cache, window_bits):
         assert gpu.download(d_o2, 4 * nb * reps) == all_ok * reps
         ts = sorted(ts[2:])
         screened[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3}
-        if tag == "256k":      # one proof of batch 100 with t_x off by one: that batch (only) is verified proof by proof
+        if tag == "256k":      # one proof with t_x off by one: its screening batch (only) is verified proof by proof
             bad_i = 100 * nb + 517
             sc_bad = bytearray(sc * reps)
             sc_bad[bad_i * 160] ^= 1
@@ -245,7 +245,7 @@ def _one_call_child(cache, window_bits):
                                               "fallback_batches": 1}
         for d in (d_p2, d_s2, d_c2, d_r2, d_o2):
             gpu.free(d)
-    screened["note"] = ("bpgpu_r1cs_verify_screened_dev: per-proof accept bits; every 1024-proof batch is first checked as ONE combined point "
+    screened["note"] = ("bpgpu_r1cs_verify_screened_dev: per-proof accept bits; every batch of 2560 proofs is first checked as ONE combined point "
                         "(random weights), only a batch that fails is verified proof by proof.  The verdicts are those of the per-proof call")
     out["screened"] = screened
     # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane

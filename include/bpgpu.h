@@ -68,7 +68,8 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
 #define BPGPU_OPT_IPP_TABLE_MAX_N 9        /* bpgpu_ipp_begin builds per-session generator tables up to this n (default 2^16), literal schedule above */
 #define BPGPU_OPT_STREAM_LANES 10          /* lanes (streams + workspaces) a bpgpu_r1cs_verify_stream call spreads its batches over, 1..64 (default 20) */
 #define BPGPU_OPT_STREAM_BATCH 11          /* proofs per batch of a bpgpu_r1cs_verify_stream call (default 1024) */
-#define BPGPU_OPT_COUNT 12
+#define BPGPU_OPT_SCREEN_BATCH 12          /* proofs per combined check of a bpgpu_r1cs_verify_screened call (default 2560; capped so that one check's proof points stay within the one-instance bucket pipeline) */
+#define BPGPU_OPT_COUNT 13
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
 int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);
 /* synchronise and report whether an operand of the `_dev` (device-resident, asynchronous) calls issued since the last read -- or
@@ -440,7 +441,8 @@ int bpgpu_r1cs_verify_combined_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
                                    size_t n1, size_t k, const void *points_dev, const void *scalars_dev,
                                    const void *challenges_dev, const void *rho_dev, void *partial_xy_dev);
 /* SCREENED stream: per-proof accept bits at (nearly) the combined check's price when the proofs are valid -- the usual shape of
- * a verifier service.  The call cuts the proofs into batches as bpgpu_r1cs_verify_stream does, runs the combined check
+ * a verifier service.  The call cuts the proofs into batches of BPGPU_OPT_SCREEN_BATCH proofs (2560: the combined check has a long
+ * kernel chain and little work per proof, so its batches are larger than the per-proof path's), runs the combined check
  * sum_p rho_p * mega_check_p of every batch first (rho: nb x 32 B of caller-chosen random non-zero weights, unpredictable to
  * the provers, as for bpgpu_r1cs_verify_combined), sets ok[p] = 1 for every proof of a batch whose point is the identity and that
  * holds no malformed input, and runs the per-proof verification only for the other batches, so that ok[] is what

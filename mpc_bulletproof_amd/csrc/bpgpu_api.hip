@@ -280,7 +280,8 @@ static int ctx_create(int device, bool single, bpgpu_ctx **out) {
         {BPGPU_OPT_VERIFY_STRAUS_NP, "BPGPU_STRAUS_NP", 4},           {BPGPU_OPT_IPP_LITERAL, "BPGPU_IPP_LITERAL", 0},
         {BPGPU_OPT_VS_LARGE_MIN, "BPGPU_VS_LARGE_MIN", 4096},         {BPGPU_OPT_TABLE_NP, "BPGPU_TABLE_NP", 0},
         {BPGPU_OPT_IPP_TABLE_MAX_N, "BPGPU_IPP_TABLE_MAX_N", (int64_t)1 << 16},
-        {BPGPU_OPT_STREAM_LANES, "BPGPU_STREAM_LANES", 20},           {BPGPU_OPT_STREAM_BATCH, "BPGPU_STREAM_BATCH", 1024}};
+        {BPGPU_OPT_STREAM_LANES, "BPGPU_STREAM_LANES", 20},           {BPGPU_OPT_STREAM_BATCH, "BPGPU_STREAM_BATCH", 1024},
+        {BPGPU_OPT_SCREEN_BATCH, "BPGPU_SCREEN_BATCH", 2560}};
     for (auto &s : seed) { const char *e = getenv(s.env); ctx->opt[s.opt] = e ? atoll(e) : s.dflt; }
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
@@ -352,6 +353,7 @@ int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value) {
     case BPGPU_OPT_IPP_TABLE_MAX_N: if (value < 0) return BPGPU_E_ARG; break;
     case BPGPU_OPT_STREAM_LANES: if (value < 1 || value > 64) return BPGPU_E_ARG; break;
     case BPGPU_OPT_STREAM_BATCH: if (value < 1 || value > ((int64_t)1 << 20)) return BPGPU_E_ARG; break;
+    case BPGPU_OPT_SCREEN_BATCH: if (value < 1 || value > ((int64_t)1 << 20)) return BPGPU_E_ARG; break;
     default: if (value != 0 && value != 1) return BPGPU_E_ARG; break;
   }
   std::lock_guard<std::mutex> lk(ctx->mu);
@@ -1836,10 +1838,16 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   if (fallback_batches) *fallback_batches = 0;
   if (!nb) return BPGPU_OK;
   HIPCK(ctx, hipSetDevice(ctx->device));
-  const size_t batch = (size_t)ctx->opt[BPGPU_OPT_STREAM_BATCH], nlanes_opt = (size_t)ctx->opt[BPGPU_OPT_STREAM_LANES];
+  // proofs per combined check: the check is a chain of nine mostly latency-bound launches with little work per proof, so its
+  // batches are larger than the per-proof path's (2560 x 24 points still fit the one-instance bucket pipeline of k_pip2.hip:
+  // 11.2 M/s against 8.1 M/s at 1024); a batch that fails is re-verified proof by proof as a whole
+  const size_t m = c->m, nvar = 11 + m + 2 * k, nch = 6 + k;
+  size_t batch = (size_t)ctx->opt[BPGPU_OPT_SCREEN_BATCH];
+  const size_t fit = ((size_t)1 << 16) / nvar / 64 * 64;          // proof points of one check <= 2^16
+  if (fit >= 256 && batch > fit) batch = fit;
+  const size_t nlanes_opt = (size_t)ctx->opt[BPGPU_OPT_STREAM_LANES];
   const size_t nchunks = (nb + batch - 1) / batch, nl = nchunks < nlanes_opt ? nchunks : nlanes_opt;
   CK(stream_lanes(ctx, nl));
-  const size_t m = c->m, nvar = 11 + m + 2 * k, nch = 6 + k;
   void *dpart, *dflag;
   CK(ws_get(ctx, 26, nchunks * 64, &dpart));
   CK(ws_get(ctx, 27, nchunks * 4, &dflag));

@@ -495,7 +495,7 @@ def test_verify_screened_combined_check_first_per_proof_on_failure(gpu, opts, on
     per-proof path and the verdicts equal the oracle's proof by proof -- what bpgpu_r1cs_verify_stream returns."""
     import random
     nb, tamper = 150, {2, 77, 78}
-    opts(stream_batch=16, stream_lanes=3)
+    opts(stream_batch=16, screen_batch=16, stream_lanes=3)
     good, cap = bh.make_range_batch(8, nb)
     bad, _ = bh.make_range_batch(8, nb, tamper=tamper)
     s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], good[0][1], good[0][0], cap)
