@@ -795,20 +795,28 @@ def main():
         sarr = (C.c_uint64 * (2 * ks))(*(xs + ys))
         sproof, splen, scom, sms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
         runs = []
+        err = None
         for rep in range(4):
             fence()
             rc = host.bph_shuffle_prove_verify_sharded(C.c_size_t(ks), sarr, C.c_uint64((1 << 64) - 1), C.c_size_t(1 << 15), C.c_size_t(rank), C.c_size_t(world),
                                                        cb, None, sproof, C.byref(splen), scom, sms)
-            assert rc == 0, f"bph_shuffle_prove_verify_sharded rc={rc} on rank {rank}"
+            # a failure of this secondary leg (every rank sees the same return code: they compute the same proof) must not cost the
+            # run its headline line: it is reported in place of the figures
+            if sharding.max_over_ranks(float(rc != 0)) != 0:
+                err = f"bph_shuffle_prove_verify_sharded returned {rc} on rank {rank} (repetition {rep})"
+                break
             if rep:
                 runs.append([sharding.max_over_ranks(x) for x in sms])
-        med = [sorted(r[i] for r in runs)[1] for i in range(6)]
         qs = 4 * (ks - 1) + 1
-        shuffle_sharded = {"ranks": world, "workload": f"ONE k-shuffle proof, k = 2^14 (q = {qs} constraints, 2^15 generators per side, a 98 347-term mega_check), "
-                                                       "split over the ranks by generator / point range",
-                           "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3]},
-                           "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5]},
-                           "note": "max over ranks, medians of 3; latency-bound: 15 IPP rounds, each with an all-gather of two 64-byte partial points and a host hash"}
+        if err:
+            shuffle_sharded = {"ranks": world, "error": err}
+        else:
+            med = [sorted(r[i] for r in runs)[1] for i in range(6)]
+            shuffle_sharded = {"ranks": world, "workload": f"ONE k-shuffle proof, k = 2^14 (q = {qs} constraints, 2^15 generators per side, a 98 347-term mega_check), "
+                                                           "split over the ranks by generator / point range",
+                               "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3]},
+                               "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5]},
+                               "note": "max over ranks, medians of 3; latency-bound: 15 IPP rounds, each with an all-gather of two 64-byte partial points and a host hash"}
 
     if pool is not None:
         pool.close()
