@@ -408,9 +408,11 @@ def main():
     if rank == 0 and world == 1 and not a.no_combined and nb == 1024:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--one-call-child", cache, "--window-bits", str(a.window_bits)],
                            capture_output=True, text=True, timeout=600, env={k_: v for k_, v in os.environ.items() if k_ != "GPU_MAX_HW_QUEUES"})
-        if r.returncode != 0:
-            raise RuntimeError("one-call child failed:\n" + r.stderr[-2000:])
-        one_call = json.loads(r.stdout.strip().splitlines()[-1])
+        if r.returncode != 0:      # a secondary leg: reported in its place (and on stderr), the headline line survives
+            print("bench.py: the one-call child failed:\n" + r.stderr[-2000:], file=sys.stderr)
+            one_call = {"error": "the one-call child process failed: " + r.stderr.strip().splitlines()[-1][:300] if r.stderr.strip() else "no output"}
+        else:
+            one_call = json.loads(r.stdout.strip().splitlines()[-1])
 
     # ---- GPU
     import torch                         # (first, so that libbpgpu.so binds to the HIP runtime torch ships; neither import touches the GPU)
@@ -658,125 +660,134 @@ def main():
         for c in ctxs[1:]:
             c.close()
         ctxs = ctxs[:1]
-        import ctypes as C
-        host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
-        vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(P_NB) for i in range(P_NVALS)]
-        arr = (C.c_uint64 * len(vals))(*vals)
-        lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
-        OS_ENTROPY = (1 << 64) - 1
+        # (the secondary legs below must not cost a run its headline line: a failure -- incl. a failed correctness assertion on the
+        # prover's output -- is reported in the leg's place, loudly on stderr as well)
+        try:
+            import ctypes as C
+            host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
+            vals = [((0x9E3779B97F4A7C15 * (i + 1 + 31 * p)) & ((1 << 64) - 1)) for p in range(P_NB) for i in range(P_NVALS)]
+            arr = (C.c_uint64 * len(vals))(*vals)
+            lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
+            OS_ENTROPY = (1 << 64) - 1
 
-        def stream(nbatch, threads, prebuild, profile):
-            pout, plen_ = (C.c_uint8 * (nbatch * P_NB * 4096))(), C.c_size_t(0)
-            pcom, ms_ = (C.c_uint8 * (nbatch * P_NB * P_NVALS * 64))(), (C.c_double * 12)()
-            rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_int(profile), C.c_size_t(P_NB),
-                                             C.c_size_t(P_NVALS), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr, C.c_uint64(OS_ENTROPY),
-                                             C.c_size_t(P_N), pout, C.byref(plen_), pcom, ms_)
-            assert rc == 0, f"bph_range_prove_stream rc={rc}"
-            return list(ms_), pout, plen_.value, pcom
+            def stream(nbatch, threads, prebuild, profile):
+                pout, plen_ = (C.c_uint8 * (nbatch * P_NB * 4096))(), C.c_size_t(0)
+                pcom, ms_ = (C.c_uint8 * (nbatch * P_NB * P_NVALS * 64))(), (C.c_double * 12)()
+                rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(prebuild), C.c_int(profile), C.c_size_t(P_NB),
+                                                 C.c_size_t(P_NVALS), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr, C.c_uint64(OS_ENTROPY),
+                                                 C.c_size_t(P_N), pout, C.byref(plen_), pcom, ms_)
+                assert rc == 0, f"bph_range_prove_stream rc={rc}"
+                return list(ms_), pout, plen_.value, pcom
 
-        T, NBAT = max(1, a.prover_threads), max(1, a.prover_batches)
-        stream(2, 1, 1, 0)            # generator tables (20 GB, c = 14), workspaces, pools, the cached circuit
-        stream(2 * T, T, 1, 0)        # every worker's context warm
-        best = None
-        for rep in range(3):
-            r = stream(NBAT, T, 1, 0)
-            if best is None or r[0][0] < best[0][0]:
-                best = r
-        ms_b, pout, plen_v, pcom = best
-        # a sample of the proofs made inside the timed region must verify: GPU verifier here, the CPU oracle in the fork pool
-        param = N_BITS | (P_NVALS << 16)
-        sample = [(bi, p) for bi in sorted({0, NBAT // 2, NBAT - 1}) for p in (0, 101, P_NB - 1)]
-        pb, cb = bytes(pout), bytes(pcom)
-        chk = []
-        for bi, p in sample:
-            i = bi * P_NB + p
-            proof_i, com_i = pb[i * plen_v:(i + 1) * plen_v], cb[i * P_NVALS * 64:(i + 1) * P_NVALS * 64]
-            mega = (C.c_uint8 * 64)()
-            vv = (C.c_uint64 * 1)()
-            rc = host.bph_r1cs_verify(4, C.c_size_t(param), lab, C.c_size_t(len(LABEL)), vv, C.c_size_t(0),
-                                      (C.c_uint8 * len(com_i)).from_buffer_copy(com_i), C.c_size_t(P_NVALS),
-                                      (C.c_uint8 * len(proof_i)).from_buffer_copy(proof_i), C.c_size_t(len(proof_i)), C.c_size_t(P_N), mega)
-            assert rc == 0, f"a proof of the timed prover stream does not verify (batch {bi}, prover {p}): rc={rc}"
-            chk.append((4, param, LABEL, com_i, proof_i, P_N))
-        oracle_checked = 0
-        if pool is not None:
-            verdicts = pool.map(_cpu_check_proofs, [chk[:2], chk[-2:]])
-            assert all(v == 0 for vs in verdicts for v in vs), "the CPU oracle rejects a proof of the timed prover stream"
-            oracle_checked = 4
-        assert len({pb[i * plen_v:(i + 1) * plen_v] for i in range(NBAT * P_NB)}) == NBAT * P_NB      # every proof is a different one
-        # the same stream with HIP-event timing of the device phases (separate region): GPU-busy share, the dominant kernel's residency;
-        # one worker alone: the dominant kernel's SOLO duration; circuit building inside the timed region
-        ms_p = stream(NBAT, T, 1, 1)[0]
-        nsolo = max(2, NBAT // 4)
-        ms_s = stream(nsolo, 1, 1, 1)[0]
-        ms_full = min((stream(NBAT, T, 0, 0)[0] for _ in range(2)), key=lambda r: r[0])
-        wall = ms_b[0]
-        per_launch_bytes = 2 * P_NB * (1 + P_N) * 96          # 512 L / R MSMs of 1 + n terms, 96 B per term
-        solo_msm_ms = ms_s[5] / max(ms_s[6], 1)
-        pmc_p = None
-        if os.path.exists(PMC_FILE):
-            with open(PMC_FILE) as f:
-                pmc_p = json.load(f).get("prover")
-        prove = {"value": NBAT * P_NB * P_Q / wall * 1e3, "unit": "R1CS constraints/s", "proofs_per_s": NBAT * P_NB / wall * 1e3,
-                 "ms_per_batch": wall / NBAT,
-                 "workload": f"{NBAT} batches x {P_NB} provers x ({P_NVALS} x 64-bit range gadgets in one constraint system: n = {P_N}, q = {P_Q}, m = {P_NVALS}), "
-                             f"{T} worker threads with a context each",
-                 "timed": "Prover::prove_batch for every batch incl. dropping the provers (Prover::prove consumes self): the reference's own bench "
-                          "times proof generation only, with the constraint system built beforehand (benches/r1cs.rs:36-55, 95-108).  Blinding factors "
-                          "from the default RNG (OsRng; the blinding vectors s_L, s_R are expanded on the device from one key per prover).  Best of 3 streams",
-                 "proofs_checked": {"gpu_verifier": len(sample), "cpu_oracle": oracle_checked, "distinct_proofs": NBAT * P_NB},
-                 "host_ms_per_batch": {"prove_batch": ms_b[2] / NBAT, "drop": ms_b[3] / NBAT, "circuit_building_untimed": ms_b[1] / NBAT},
-                 "incl_circuit_building": {"value": NBAT * P_NB * P_Q / ms_full[0] * 1e3, "unit": "R1CS constraints/s", "ms_per_batch": ms_full[0] / NBAT,
-                                           "note": "the same stream with gadget building (256 x 2064 constraint rows), the 4096 Pedersen commitments and the "
-                                                   "provers' set-up inside the timed region as well"},
-                 "single_thread": {"value": P_NB * P_Q / (ms_s[0] / nsolo) * 1e3, "unit": "R1CS constraints/s",
-                                   "ms_per_batch": ms_s[0] / nsolo, "note": "one worker thread, batches back to back (with event timing on)"},
-                 "roofline": {"bound": "hbm", "kernel": "k_fixed_msm_ipp<16,128> (+ its block sum): the L / R table-lookup MSMs of one IPP round, 512 MSMs of 1025 terms",
-                              "achieved": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_p or {}).get("traffic_bytes_round_msm"),
-                              "avg_launch_ms": solo_msm_ms, "launches": int(ms_s[6]), "algorithmic_bytes_per_launch": per_launch_bytes,
-                              "timed": "HIP-event pairs on the launch stream around the kernel, one worker thread (no other batch on the GPU)",
-                              "residency_in_the_stream_ms": ms_p[5] / max(ms_p[6], 1),
-                              "note": "VALU-integer bound like every kernel here: 16 table additions (~1 650 instructions each) per 96 algorithmic bytes; the binding roofline is roofline_valu_issue beside this one"},
-                 "gpu_busy": {"frac": ms_p[4] / ms_p[0], "busy_ms_per_batch": ms_p[4] / NBAT, "wall_ms_per_batch": ms_p[0] / NBAT,
-                              "device_phase_ms_per_batch": {"ipp_rounds": ms_p[7] / NBAT, "phase_commitments": ms_p[8] / NBAT, "polynomials": ms_p[9] / NBAT,
-                                                            "T_commitments": ms_p[10] / NBAT, "ipp_setup": ms_p[11] / NBAT},
-                              "what": "union over the worker contexts of the device-phase intervals (HIP events, first to last launch of every call) / wall "
-                                      "clock of the stream, measured in a separate stream with event timing on"},
-                 "roofline_valu_issue": ({"bound": "VALU issue slots (mix-weighted)", "achieved": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3),
-                                          "peak": VALU_ISSUE_PEAK_MIX, "unit": "wave-instr/s",
-                                          "frac": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3) / VALU_ISSUE_PEAK_MIX,
-                                          "valu_wave_instr_per_batch": pmc_p["valu_wave_instr_per_batch"], "source": pmc_p.get("source")} if pmc_p else None),
-                 "cpu_baseline": cpu_prove}
+            T, NBAT = max(1, a.prover_threads), max(1, a.prover_batches)
+            stream(2, 1, 1, 0)            # generator tables (20 GB, c = 14), workspaces, pools, the cached circuit
+            stream(2 * T, T, 1, 0)        # every worker's context warm
+            best = None
+            for rep in range(3):
+                r = stream(NBAT, T, 1, 0)
+                if best is None or r[0][0] < best[0][0]:
+                    best = r
+            ms_b, pout, plen_v, pcom = best
+            # a sample of the proofs made inside the timed region must verify: GPU verifier here, the CPU oracle in the fork pool
+            param = N_BITS | (P_NVALS << 16)
+            sample = [(bi, p) for bi in sorted({0, NBAT // 2, NBAT - 1}) for p in (0, 101, P_NB - 1)]
+            pb, cb = bytes(pout), bytes(pcom)
+            chk = []
+            for bi, p in sample:
+                i = bi * P_NB + p
+                proof_i, com_i = pb[i * plen_v:(i + 1) * plen_v], cb[i * P_NVALS * 64:(i + 1) * P_NVALS * 64]
+                mega = (C.c_uint8 * 64)()
+                vv = (C.c_uint64 * 1)()
+                rc = host.bph_r1cs_verify(4, C.c_size_t(param), lab, C.c_size_t(len(LABEL)), vv, C.c_size_t(0),
+                                          (C.c_uint8 * len(com_i)).from_buffer_copy(com_i), C.c_size_t(P_NVALS),
+                                          (C.c_uint8 * len(proof_i)).from_buffer_copy(proof_i), C.c_size_t(len(proof_i)), C.c_size_t(P_N), mega)
+                assert rc == 0, f"a proof of the timed prover stream does not verify (batch {bi}, prover {p}): rc={rc}"
+                chk.append((4, param, LABEL, com_i, proof_i, P_N))
+            oracle_checked = 0
+            if pool is not None:
+                verdicts = pool.map(_cpu_check_proofs, [chk[:2], chk[-2:]])
+                assert all(v == 0 for vs in verdicts for v in vs), "the CPU oracle rejects a proof of the timed prover stream"
+                oracle_checked = 4
+            assert len({pb[i * plen_v:(i + 1) * plen_v] for i in range(NBAT * P_NB)}) == NBAT * P_NB      # every proof is a different one
+            # the same stream with HIP-event timing of the device phases (separate region): GPU-busy share, the dominant kernel's residency;
+            # one worker alone: the dominant kernel's SOLO duration; circuit building inside the timed region
+            ms_p = stream(NBAT, T, 1, 1)[0]
+            nsolo = max(2, NBAT // 4)
+            ms_s = stream(nsolo, 1, 1, 1)[0]
+            ms_full = min((stream(NBAT, T, 0, 0)[0] for _ in range(2)), key=lambda r: r[0])
+            wall = ms_b[0]
+            per_launch_bytes = 2 * P_NB * (1 + P_N) * 96          # 512 L / R MSMs of 1 + n terms, 96 B per term
+            solo_msm_ms = ms_s[5] / max(ms_s[6], 1)
+            pmc_p = None
+            if os.path.exists(PMC_FILE):
+                with open(PMC_FILE) as f:
+                    pmc_p = json.load(f).get("prover")
+            prove = {"value": NBAT * P_NB * P_Q / wall * 1e3, "unit": "R1CS constraints/s", "proofs_per_s": NBAT * P_NB / wall * 1e3,
+                     "ms_per_batch": wall / NBAT,
+                     "workload": f"{NBAT} batches x {P_NB} provers x ({P_NVALS} x 64-bit range gadgets in one constraint system: n = {P_N}, q = {P_Q}, m = {P_NVALS}), "
+                                 f"{T} worker threads with a context each",
+                     "timed": "Prover::prove_batch for every batch incl. dropping the provers (Prover::prove consumes self): the reference's own bench "
+                              "times proof generation only, with the constraint system built beforehand (benches/r1cs.rs:36-55, 95-108).  Blinding factors "
+                              "from the default RNG (OsRng; the blinding vectors s_L, s_R are expanded on the device from one key per prover).  Best of 3 streams",
+                     "proofs_checked": {"gpu_verifier": len(sample), "cpu_oracle": oracle_checked, "distinct_proofs": NBAT * P_NB},
+                     "host_ms_per_batch": {"prove_batch": ms_b[2] / NBAT, "drop": ms_b[3] / NBAT, "circuit_building_untimed": ms_b[1] / NBAT},
+                     "incl_circuit_building": {"value": NBAT * P_NB * P_Q / ms_full[0] * 1e3, "unit": "R1CS constraints/s", "ms_per_batch": ms_full[0] / NBAT,
+                                               "note": "the same stream with gadget building (256 x 2064 constraint rows), the 4096 Pedersen commitments and the "
+                                                       "provers' set-up inside the timed region as well"},
+                     "single_thread": {"value": P_NB * P_Q / (ms_s[0] / nsolo) * 1e3, "unit": "R1CS constraints/s",
+                                       "ms_per_batch": ms_s[0] / nsolo, "note": "one worker thread, batches back to back (with event timing on)"},
+                     "roofline": {"bound": "hbm", "kernel": "k_fixed_msm_ipp<16,128> (+ its block sum): the L / R table-lookup MSMs of one IPP round, 512 MSMs of 1025 terms",
+                                  "achieved": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": per_launch_bytes / (solo_msm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": (pmc_p or {}).get("traffic_bytes_round_msm"),
+                                  "avg_launch_ms": solo_msm_ms, "launches": int(ms_s[6]), "algorithmic_bytes_per_launch": per_launch_bytes,
+                                  "timed": "HIP-event pairs on the launch stream around the kernel, one worker thread (no other batch on the GPU)",
+                                  "residency_in_the_stream_ms": ms_p[5] / max(ms_p[6], 1),
+                                  "note": "VALU-integer bound like every kernel here: 16 table additions (~1 650 instructions each) per 96 algorithmic bytes; the binding roofline is roofline_valu_issue beside this one"},
+                     "gpu_busy": {"frac": ms_p[4] / ms_p[0], "busy_ms_per_batch": ms_p[4] / NBAT, "wall_ms_per_batch": ms_p[0] / NBAT,
+                                  "device_phase_ms_per_batch": {"ipp_rounds": ms_p[7] / NBAT, "phase_commitments": ms_p[8] / NBAT, "polynomials": ms_p[9] / NBAT,
+                                                                "T_commitments": ms_p[10] / NBAT, "ipp_setup": ms_p[11] / NBAT},
+                                  "what": "union over the worker contexts of the device-phase intervals (HIP events, first to last launch of every call) / wall "
+                                          "clock of the stream, measured in a separate stream with event timing on"},
+                     "roofline_valu_issue": ({"bound": "VALU issue slots (mix-weighted)", "achieved": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3),
+                                              "peak": VALU_ISSUE_PEAK_MIX, "unit": "wave-instr/s",
+                                              "frac": pmc_p["valu_wave_instr_per_batch"] / (wall / NBAT * 1e-3) / VALU_ISSUE_PEAK_MIX,
+                                              "valu_wave_instr_per_batch": pmc_p["valu_wave_instr_per_batch"], "source": pmc_p.get("source")} if pmc_p else None),
+                     "cpu_baseline": cpu_prove}
 
-        # ---- configs[3] on ONE GPU: the k-shuffle gadget at k = 2^14 (q = 65 533 constraints, n = 32 766 multipliers, all
-        # second-phase; m = 32 768 commitments; 98 347-term mega_check): one proof, prove then verify, wall clock of
-        # Prover::prove / Verifier::verify with the circuit built beforehand (as the reference's benches/shuffle.rs times them)
-        if not os.environ.get("BPGPU_BENCH_NO_SHUFFLE"):
-            ks = 1 << 14
-            rnd = __import__("random").Random(77)
-            xs = [rnd.getrandbits(64) for _ in range(ks)]
-            ys = list(xs)
-            rnd.shuffle(ys)
-            sarr = (C.c_uint64 * (2 * ks))(*(xs + ys))
-            sproof, splen, scom, sms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
-            runs = []
-            for rep in range(4):
-                rc = host.bph_shuffle_prove_verify(C.c_size_t(ks), sarr, C.c_uint64(OS_ENTROPY), C.c_size_t(1 << 15), sproof, C.byref(splen), scom, sms)
-                assert rc == 0, f"bph_shuffle_prove_verify rc={rc}"          # rc == 0: the proof was accepted by the GPU verifier
-                if rep:
-                    runs.append(list(sms))
-            med = [sorted(r[i] for r in runs)[1] for i in range(6)]
-            qs = 4 * (ks - 1) + 1
-            shuffle = {"workload": f"k-shuffle gadget, k = 2^14: q = {qs} constraints, n = {2 * (ks - 1)} multipliers (phase 2), m = {2 * ks}, padded n = 2^15",
-                       "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "best_ms": min(r[3] for r in runs),
-                                 "circuit_building_ms": med[2]},
-                       "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "best_ms": min(r[5] for r in runs),
-                                  "circuit_building_ms": med[4]},
-                       "note": "one proof on one GPU, medians (and best) of 3; every proof verified (the call fails otherwise); OsRng blinding "
-                               "factors.  A third of prove and half of verify is the host mirror running the gadget (65 533 constraint rows "
-                               "carrying the challenge): these two figures move with whatever else the box's CPUs are doing; circuit_building = "
-                               "the 32 768 commit calls before prove / verify (a dependent hash chain on the host)"}
+            # ---- configs[3] on ONE GPU: the k-shuffle gadget at k = 2^14 (q = 65 533 constraints, n = 32 766 multipliers, all
+            # second-phase; m = 32 768 commitments; 98 347-term mega_check): one proof, prove then verify, wall clock of
+            # Prover::prove / Verifier::verify with the circuit built beforehand (as the reference's benches/shuffle.rs times them)
+            if not os.environ.get("BPGPU_BENCH_NO_SHUFFLE"):
+                ks = 1 << 14
+                rnd = __import__("random").Random(77)
+                xs = [rnd.getrandbits(64) for _ in range(ks)]
+                ys = list(xs)
+                rnd.shuffle(ys)
+                sarr = (C.c_uint64 * (2 * ks))(*(xs + ys))
+                sproof, splen, scom, sms = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+                runs = []
+                for rep in range(4):
+                    rc = host.bph_shuffle_prove_verify(C.c_size_t(ks), sarr, C.c_uint64(OS_ENTROPY), C.c_size_t(1 << 15), sproof, C.byref(splen), scom, sms)
+                    assert rc == 0, f"bph_shuffle_prove_verify rc={rc}"          # rc == 0: the proof was accepted by the GPU verifier
+                    if rep:
+                        runs.append(list(sms))
+                med = [sorted(r[i] for r in runs)[1] for i in range(6)]
+                qs = 4 * (ks - 1) + 1
+                shuffle = {"workload": f"k-shuffle gadget, k = 2^14: q = {qs} constraints, n = {2 * (ks - 1)} multipliers (phase 2), m = {2 * ks}, padded n = 2^15",
+                           "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "best_ms": min(r[3] for r in runs),
+                                     "circuit_building_ms": med[2]},
+                           "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "best_ms": min(r[5] for r in runs),
+                                      "circuit_building_ms": med[4]},
+                           "note": "one proof on one GPU, medians (and best) of 3; every proof verified (the call fails otherwise); OsRng blinding "
+                                   "factors.  A third of prove and half of verify is the host mirror running the gadget (65 533 constraint rows "
+                                   "carrying the challenge): these two figures move with whatever else the box's CPUs are doing; circuit_building = "
+                                   "the 32 768 commit calls before prove / verify (a dependent hash chain on the host)"}
+        except Exception as e:      # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            failed = {"error": f"{type(e).__name__}: {e}"}
+            prove = prove or failed
+            shuffle = shuffle or failed
 
     # ======== N > 1: configs[3] in its sharded form -- ONE 2^14-shuffle proof split over the ranks (every multi-scalar multiplication
     # by generator / point range, partial points all-gathered over RCCL and added: SURVEY 8e.2), proved and verified on all of them
