@@ -180,7 +180,9 @@ __global__ void __launch_bounds__(64) k_verify_transcript(size_t nb, size_t nvar
                                                           const Words8 *init_state, const Words8 *points, const Words8 *scalars,
                                                           Words8 *challenges, int32_t *tr_bad, Label gadget_label, Words8 *chi,
                                                           size_t nchi) {
-  __builtin_amdgcn_s_setprio(3);   // serial hash chain at the head of every batch's dependency chain (see k_vs_prep)
+  // (no raised wave priority here, unlike the other short links of a batch's chain: a lone wave of dependent 64-bit operations
+  // issues back to back, so at priority 3 the 16 transcript waves of each of ~20 batches in flight kept their SIMDs to
+  // themselves for 0.7 ms at a time -- measured 3.54 -> 3.95 M verifications/s for the device-transcript leg without it)
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb) return;
   const Words8 *pt = points + p * nvar * 2;
