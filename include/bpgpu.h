@@ -457,6 +457,12 @@ int bpgpu_r1cs_verify_screened(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
 int bpgpu_r1cs_verify_screened_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                    const void *points_dev, const void *scalars_dev, const void *challenges_dev, const void *rho_dev,
                                    void *ok_dev, size_t *fallback_batches);
+/* the whole of Verifier::verify that way: the transcript replayed on the device (bpgpu_r1cs_verify_batch_fs: init_states = the
+ * 32-byte chain state per proof, 1-phase circuits) per batch, then the batch's combined check, the per-proof path (again with the
+ * device transcript) only for a batch that fails either; ok[] is what bpgpu_r1cs_verify_batch_fs returns */
+int bpgpu_r1cs_verify_screened_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                      const void *init_states_dev, const void *points_dev, const void *scalars_dev, const void *rho_dev,
+                                      void *ok_dev, size_t *fallback_batches);
 
 #ifdef __cplusplus
 }

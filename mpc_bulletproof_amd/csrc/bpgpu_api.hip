@@ -1530,12 +1530,13 @@ int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_ci
 }
 
 /* ---------------------------------------------------------------- Verifier::verify with the transcript on the device */
-static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
-                            const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
-                            void *challenges_out, const uint8_t *gadget_label = nullptr, void *chi_out = nullptr) try {
+// the transcript half: schedule (cached per context) + k_verify_transcript.  *chp = the challenges (challenges_out or a workspace),
+// *dbad = per-proof "a validated point is the identity" flags, *dchi = the gadget challenges of a parametric circuit (or null)
+static int fs_transcript_locked(bpgpu_ctx *ctx, const bpgpu_circuit *c, size_t nb, size_t k, const void *init_states, const void *points,
+                                const void *scalars, void *challenges_out, const uint8_t *gadget_label, void *chi_out, Words8 **chp,
+                                void **dbad_out, void **dchi_out) try {
   if (k >= 32) return BPGPU_E_LEN;
   if (c->nchi > 1 || (c->nchi == 1 && !gadget_label)) return BPGPU_E_ARG;   // one gadget challenge label per schedule
-  if (!nb) return BPGPU_OK;
   HIPCK(ctx, hipSetDevice(ctx->device));
   const size_t m = c->m, np = (size_t)1 << k, nchi = c->nchi;
   void *dsteps, *dch, *dbad, *dchi = nullptr;
@@ -1550,17 +1551,27 @@ static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
     HIPCK(ctx, hipStreamSynchronize(ctx->st));   // `steps` is a local
     ctx->sched_key[0] = m; ctx->sched_key[1] = k; ctx->sched_key[2] = np + (nchi << 40);
   }
-  Words8 *chp = challenges_out ? (Words8 *)challenges_out : (Words8 *)dch;
-  {
-    ProfScope ps(ctx, 5, ctx->st);
-    verify_transcript(ctx->st, nb, m, k, (const TrStep *)dsteps, ctx->sched_len, (const Words8 *)init_states,
-                      (const Words8 *)points, (const Words8 *)scalars, chp, (int32_t *)dbad, gadget_label, (Words8 *)dchi, nchi);
-  }
+  *chp = challenges_out ? (Words8 *)challenges_out : (Words8 *)dch;
+  *dbad_out = dbad;
+  *dchi_out = dchi;
+  ProfScope ps(ctx, 5, ctx->st);
+  verify_transcript(ctx->st, nb, m, k, (const TrStep *)dsteps, ctx->sched_len, (const Words8 *)init_states,
+                    (const Words8 *)points, (const Words8 *)scalars, *chp, (int32_t *)dbad, gadget_label, (Words8 *)dchi, nchi);
+  return BPGPU_OK;
+} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
+  return BPGPU_E_OOM;
+}
+static int verify_fs_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                            const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
+                            void *challenges_out, const uint8_t *gadget_label = nullptr, void *chi_out = nullptr) {
+  if (k >= 32) return BPGPU_E_LEN;
+  if (!nb) return BPGPU_OK;
+  Words8 *chp;
+  void *dbad, *dchi;
+  CK(fs_transcript_locked(ctx, c, nb, k, init_states, points, scalars, challenges_out, gadget_label, chi_out, &chp, &dbad, &dchi));
   CK(verify_batch_dev_locked(ctx, g, c, nb, n1, k, points, scalars, chp, ok, mega, nullptr, dchi));
   and_not(ctx->st, (int32_t *)ok, (const int32_t *)dbad, nb);
   return launch_ok(ctx);
-} catch (const std::bad_alloc &) {   // host-side staging (std::vector): no exception crosses the C ABI
-  return BPGPU_E_OOM;
 }
 int bpgpu_r1cs_verify_batch_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                    const void *init_states, const void *points, const void *scalars, void *ok, void *mega,
@@ -1831,9 +1842,11 @@ int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_
 /* Screened stream: the combined check of every batch first (one point per batch), the per-proof path only for the batches whose
  * point is not the identity (or that hold a malformed input).  Phase 1 and phase 2 each fork over the lanes and join; between them
  * the host reads 68 bytes per batch. */
+// init_states != null: the transcript is replayed on the device (challenges unused): per batch k_verify_transcript first, and a proof
+// whose transcript replay fails (a validated point is the identity) sends its batch to the per-proof path like any other failure
 static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                   const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, const uint8_t *rho,
-                                  uint8_t *ok, bool on_host, size_t *fallback_batches) try {
+                                  uint8_t *ok, bool on_host, size_t *fallback_batches, const uint8_t *init_states = nullptr) try {
   if (k >= 32) return BPGPU_E_LEN;
   if (fallback_batches) *fallback_batches = 0;
   if (!nb) return BPGPU_OK;
@@ -1865,17 +1878,20 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
     return rc;
   };
   // stage a batch's operands on its lane (host variant); returns device pointers either way
+  // (*Cc = the challenges, or with a device transcript the batch's 32-byte initial states)
+  const uint8_t *third = init_states ? init_states : challenges;
+  const size_t third_bytes = init_states ? 32 : nch * 32;
   auto operands = [&](bpgpu_ctx *ln, size_t lo, size_t cnt, const void **P, const void **S, const void **Cc, const void **R, void **dok) -> int {
     if (!on_host) {
-      *P = points + lo * nvar * 64; *S = scalars + lo * 5 * 32; *Cc = challenges + lo * nch * 32; *R = rho + lo * 32; *dok = ok + lo * 4;
+      *P = points + lo * nvar * 64; *S = scalars + lo * 5 * 32; *Cc = third + lo * third_bytes; *R = rho + lo * 32; *dok = ok + lo * 4;
       return BPGPU_OK;
     }
     void *dP, *dS, *dC, *dR;
     int rc;
-    if ((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) || (rc = ws_get(ln, 2, batch * nch * 32, &dC)) ||
+    if ((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) || (rc = ws_get(ln, 2, batch * third_bytes, &dC)) ||
         (rc = ws_get(ln, 3, batch * 32, &dR)) || (rc = ws_get(ln, 4, batch * 4, dok)) ||
         (rc = h2d(ln, dP, points + lo * nvar * 64, cnt * nvar * 64)) || (rc = h2d(ln, dS, scalars + lo * 5 * 32, cnt * 5 * 32)) ||
-        (rc = h2d(ln, dC, challenges + lo * nch * 32, cnt * nch * 32)) || (rc = h2d(ln, dR, rho + lo * 32, cnt * 32)))
+        (rc = h2d(ln, dC, third + lo * third_bytes, cnt * third_bytes)) || (rc = h2d(ln, dR, rho + lo * 32, cnt * 32)))
       return rc;
     *P = dP; *S = dS; *Cc = dC; *R = dR;
     return BPGPU_OK;
@@ -1888,8 +1904,15 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
     const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
     const void *P, *S, *Cc, *R;
     void *dok;
-    (void)((rc = operands(ln, lo, cnt, &P, &S, &Cc, &R, &dok)) ||
-           (rc = verify_combined_locked(ln, g, c, cnt, n1, k, P, S, Cc, R, (uint8_t *)dpart + 64 * ci)));
+    rc = operands(ln, lo, cnt, &P, &S, &Cc, &R, &dok);
+    void *dbad = nullptr, *dchi = nullptr;
+    if (rc == BPGPU_OK && init_states) {       // the batch's challenges from the device transcript
+      Words8 *chp = nullptr;
+      rc = fs_transcript_locked(ln, c, cnt, k, Cc, P, S, nullptr, nullptr, nullptr, &chp, &dbad, &dchi);
+      Cc = chp;
+    }
+    if (rc == BPGPU_OK) rc = verify_combined_locked(ln, g, c, cnt, n1, k, P, S, Cc, R, (uint8_t *)dpart + 64 * ci);
+    if (rc == BPGPU_OK && dbad) or_flag(ln->st, (const int32_t *)dbad, cnt, ln->d_flag);      // (after the combined check: it resets the flag)
     if (rc == BPGPU_OK && hipMemcpyAsync((int *)dflag + ci, ln->d_flag, 4, hipMemcpyDeviceToDevice, ln->st) != hipSuccess) rc = BPGPU_E_DEVICE;
     if (rc) ctx->err = ln->err;
   }
@@ -1914,7 +1937,8 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
     const void *P, *S, *Cc, *R;
     void *dok;
     (void)((rc = operands(ln, lo, cnt, &P, &S, &Cc, &R, &dok)) ||
-           (rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, dok, nullptr, nullptr)) ||
+           (rc = init_states ? verify_fs_locked(ln, g, c, cnt, n1, k, Cc, P, S, dok, nullptr, nullptr)
+                             : verify_batch_dev_locked(ln, g, c, cnt, n1, k, P, S, Cc, dok, nullptr, nullptr)) ||
            (on_host && (rc = d2h(ln, ok + lo * 4, dok, cnt * 4))));
     if (rc) ctx->err = ln->err;
   }
@@ -1923,6 +1947,15 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
   return rc;
 } catch (const std::bad_alloc &) {
   return BPGPU_E_OOM;
+}
+int bpgpu_r1cs_verify_screened_fs_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
+                                      const void *init_states_dev, const void *points_dev, const void *scalars_dev, const void *rho_dev,
+                                      void *ok_dev, size_t *fallback_batches) {
+  if (!ctx || !g || !c || (nb && (!init_states_dev || !points_dev || !scalars_dev || !rho_dev || !ok_dev))) return BPGPU_E_ARG;
+  if (c->nchi) return BPGPU_E_ARG;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  return verify_screened_locked(ctx, g, c, nb, n1, k, (const uint8_t *)points_dev, (const uint8_t *)scalars_dev, nullptr,
+                                (const uint8_t *)rho_dev, (uint8_t *)ok_dev, false, fallback_batches, (const uint8_t *)init_states_dev);
 }
 int bpgpu_r1cs_verify_screened_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                                    const void *points_dev, const void *scalars_dev, const void *challenges_dev, const void *rho_dev,

@@ -280,6 +280,14 @@ __global__ void k_and_not(int32_t *ok, const int32_t *bad, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && bad[i]) ok[i] = 0;
 }
+// flag |= 2 if any bad[i] (the screened verification: a batch with a failed transcript replay takes the per-proof path)
+__global__ void k_or_flag(const int32_t *bad, size_t n, int *flag) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && bad[i]) atomicOr(flag, 2);
+}
+void or_flag(hipStream_t st, const int32_t *bad, size_t n, int *flag) {
+  if (n) hipLaunchKernelGGL(k_or_flag, dim3((n + 255) / 256), dim3(256), 0, st, bad, n, flag);
+}
 void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n) {
   if (n) hipLaunchKernelGGL(k_and_not, dim3((n + 255) / 256), dim3(256), 0, st, ok, bad, n);
 }

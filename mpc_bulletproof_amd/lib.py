@@ -13,7 +13,7 @@ SYMBOLS = [
     "bpgpu_verification_scalars", "bpgpu_ipp_begin", "bpgpu_ipp_begin_gens", "bpgpu_ipp_destroy", "bpgpu_ipp_len", "bpgpu_ipp_round",
     "bpgpu_ipp_fold", "bpgpu_ipp_finish", "bpgpu_ipp_folded_gens", "bpgpu_ipp_run_fs", "bpgpu_r1cs_prover_polys", "bpgpu_r1cs_prover_polys_ark", "bpgpu_r1cs_prover_eval", "bpgpu_r1cs_prover_ipp_begin", "bpgpu_prover_destroy", "bpgpu_r1cs_prover_commit", "bpgpu_r1cs_prover_session_polys",
     "bpgpu_generator_mul", "bpgpu_circuit_create", "bpgpu_circuit_create_ark", "bpgpu_circuit_create_param", "bpgpu_circuit_destroy", "bpgpu_flatten_constraints",
-    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_stream", "bpgpu_r1cs_verify_stream_dev", "bpgpu_r1cs_verify_screened", "bpgpu_r1cs_verify_screened_dev", "bpgpu_r1cs_verify_combined",
+    "bpgpu_r1cs_verify_batch", "bpgpu_r1cs_verify_batch_dev", "bpgpu_r1cs_verify_stream", "bpgpu_r1cs_verify_stream_dev", "bpgpu_r1cs_verify_screened", "bpgpu_r1cs_verify_screened_dev", "bpgpu_r1cs_verify_screened_fs_dev", "bpgpu_r1cs_verify_combined",
     "bpgpu_r1cs_verify_combined_dev", "bpgpu_r1cs_verify_batch_fs", "bpgpu_r1cs_verify_batch_fs_dev",
     "bpgpu_r1cs_verify_batch_wire", "bpgpu_r1cs_verify_batch_wire_dev", "bpgpu_r1cs_verify_batch_param", "bpgpu_r1cs_verify_batch_fs2",
     "bpgpu_r1cs_verify_batch_fs2_dev",
@@ -568,6 +568,13 @@ class BpGpu:
         nf = C.c_size_t(0)
         self._ck(_lib.bpgpu_r1cs_verify_screened_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                      d_points, d_scalars, d_challenges, d_rho, d_ok, C.byref(nf)))
+        return nf.value
+
+    def r1cs_verify_screened_fs_dev(self, gens, circuit, nb, n1, k, d_init_states, d_points, d_scalars, d_rho, d_ok):
+        """the same with the transcript replayed on the device (whole Verifier::verify; 1-phase circuits) -> fallback batches"""
+        nf = C.c_size_t(0)
+        self._ck(_lib.bpgpu_r1cs_verify_screened_fs_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
+                                                        d_init_states, d_points, d_scalars, d_rho, d_ok, C.byref(nf)))
         return nf.value
 
     def r1cs_verify_screened(self, gens, circuit, nb, n1, k, points, scalars, challenges, rho):

@@ -542,6 +542,58 @@ def test_verify_screened_combined_check_first_per_proof_on_failure(gpu, opts, on
         s0.close()
 
 
+def test_verify_screened_with_device_transcript(gpu, opts):
+    """bpgpu_r1cs_verify_screened_fs_dev: the transcript replayed on the device per batch, then the batch's combined check.  150 valid
+    proofs: no fallback.  With two tampered proofs, one off-curve point and one proof whose A_I1 is the identity (the transcript's
+    validate_and_append_point rejects it): exactly those four batches fall back, and the verdicts are bpgpu_r1cs_verify_batch_fs's
+    (= the oracle's whole Verifier::verify)."""
+    import random
+    sys_path_oracle()
+    import pymodel as pm
+    nb, tamper = 150, {5, 99}
+    opts(stream_batch=16, screen_batch=16, stream_lanes=3)
+    good, cap = bh.make_range_batch(8, nb)
+    bad, _ = bh.make_range_batch(8, nb, tamper=tamper)
+    s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], good[0][1], good[0][0], cap)
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    rnd = random.Random(777)
+    rho = b"".join(o.s2b(rnd.randrange(1, o.N)) for _ in range(nb))
+    init = pm.Transcript(b"RangeProofTest").state * nb
+    nvar = 11 + s0.m + 2 * s0.k
+    try:
+        def pack(recs):
+            pts = sc = b""
+            for proof, com in recs:
+                k, p, q = bh.verify_inputs(proof, com)
+                pts, sc = pts + p, sc + q
+            return pts, sc
+
+        def run(pts, sc):
+            di, dp, ds, dr, dok = gpu.to_device(init), gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(rho), gpu.malloc(4 * nb)
+            nf = gpu.r1cs_verify_screened_fs_dev(g, circ, nb, s0.n1, s0.k, di, dp, ds, dr, dok)
+            ok = [int.from_bytes(gpu.download(dok, 4 * nb)[4 * i:4 * i + 4], "little") for i in range(nb)]
+            for d in (di, dp, ds, dr, dok):
+                gpu.free(d)
+            return ok, nf
+        pts, sc = pack(good)
+        assert run(pts, sc) == ([1] * nb, 0)
+        pts, sc = pack(bad)
+        off = (120 * nvar + 1) * 64                   # proof 120: A_O1 off the curve
+        y = (int.from_bytes(pts[off + 32:off + 64], "little") + 1) % (1 << 251)
+        pts = pts[:off + 32] + y.to_bytes(32, "little") + pts[off + 64:]
+        off = 40 * nvar * 64                          # proof 40: A_I1 = identity
+        pts = pts[:off] + bytes(64) + pts[off + 64:]
+        want, _, _ = gpu.r1cs_verify_batch_fs(g, circ, nb, s0.n1, s0.k, s0.m, init, pts, sc, want_mega=False)
+        assert want == [0 if i in (5, 99, 120, 40) else 1 for i in range(nb)]
+        ok, nf = run(pts, sc)
+        assert ok == want and nf == 4                  # batches 0 (proof 5), 2 (40), 6 (99), 7 (120)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s0.close()
+
+
 @pytest.mark.parametrize("world", [2, 3, 8])     # 8: more ranks than some of the vectors have entries (empty shares)
 def test_shard_partial_sums_add_up(gpu, world):
     """bpgpu_set_shard / bpgpu_r1cs_verify_shard (ONE large proof over the GPUs of a node) on one context, rank after
