@@ -120,3 +120,26 @@ def test_options_are_per_context_and_validated():
     hdr = open(os.path.join(ROOT, "include", "bpgpu.h")).read()
     ids = {int(x) for x in re.findall(r"#define BPGPU_OPT_(?!COUNT)[A-Z_0-9]+ (\d+)", hdr)}
     assert ids == set(m.lib.OPT.values()) and max(ids) + 1 == int(re.search(r"#define BPGPU_OPT_COUNT (\d+)", hdr).group(1))
+
+
+def test_round3_entry_points_reject_null_arguments_without_a_device():
+    """The entry points added in round 3 return BPGPU_E_ARG for a missing context / operands before anything touches a device
+    (the header's contract: functions never throw and never abort)."""
+    import ctypes as C
+    import mpc_bulletproof_amd as m
+    lib = C.CDLL(m.lib.SO_PATH)
+    E = m.lib.E_ARG
+    z, n = C.c_size_t(0), C.c_size_t(4)
+    nf = C.c_size_t(7)
+    assert lib.bpgpu_r1cs_verify_stream(None, None, None, n, z, z, None, None, None, None) == E
+    assert lib.bpgpu_r1cs_verify_stream_dev(None, None, None, n, z, z, None, None, None, None) == E
+    assert lib.bpgpu_r1cs_verify_screened(None, None, None, n, z, z, None, None, None, None, None, C.byref(nf)) == E
+    assert lib.bpgpu_r1cs_verify_screened_dev(None, None, None, n, z, z, None, None, None, None, None, C.byref(nf)) == E
+    assert lib.bpgpu_r1cs_verify_screened_fs_dev(None, None, None, n, z, z, None, None, None, None, None, C.byref(nf)) == E
+    assert lib.bpgpu_r1cs_verify_shard(None, None, None, z, z, None, None, None, None, z, C.c_size_t(1), None) == E
+    assert lib.bpgpu_set_shard(None, z, C.c_size_t(1)) == E
+    assert lib.bpgpu_r1cs_prover_commit(None, None, None, n, n, None, None, None, None, None, None, None, None) == E
+    assert lib.bpgpu_r1cs_prover_session_polys(None, None, None, None, None, None, None) == E
+    lib.bpgpu_profile_epoch.restype = C.c_void_p
+    assert lib.bpgpu_profile_epoch(None) is None
+    assert lib.bpgpu_profile_intervals(None, None, z, None, None, None, None) == E
