@@ -445,7 +445,8 @@ int bpgpu_r1cs_verify_combined_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
  * kernel chain and little work per proof, so its batches are larger than the per-proof path's), runs the combined check
  * sum_p rho_p * mega_check_p of every batch first (rho: nb x 32 B of caller-chosen random non-zero weights, unpredictable to
  * the provers, as for bpgpu_r1cs_verify_combined), sets ok[p] = 1 for every proof of a batch whose point is the identity and that
- * holds no malformed input, and runs the per-proof verification only for the other batches, so that ok[] is what
+ * holds no malformed input and no zero weight (a zeroed rho buffer must not accept anything), and runs the per-proof verification
+ * only for the other batches, so that ok[] is what
  * bpgpu_r1cs_verify_stream returns (up to the 2^-250 chance that random weights cancel an invalid proof).  One host-side wait
  * between the two phases (68 bytes per batch are read back).  fallback_batches (optional): how many batches took the per-proof
  * path.  No reference API (the reference verifies proof by proof); built from verifier.rs:457-553. */

@@ -1913,6 +1913,7 @@ static int verify_screened_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpg
     }
     if (rc == BPGPU_OK) rc = verify_combined_locked(ln, g, c, cnt, n1, k, P, S, Cc, R, (uint8_t *)dpart + 64 * ci);
     if (rc == BPGPU_OK && dbad) or_flag(ln->st, (const int32_t *)dbad, cnt, ln->d_flag);      // (after the combined check: it resets the flag)
+    if (rc == BPGPU_OK) zero_flag(ln->st, (const Words8 *)R, cnt, ln->d_flag);                // a zero weight voids the check for its batch
     if (rc == BPGPU_OK && hipMemcpyAsync((int *)dflag + ci, ln->d_flag, 4, hipMemcpyDeviceToDevice, ln->st) != hipSuccess) rc = BPGPU_E_DEVICE;
     if (rc) ctx->err = ln->err;
   }

@@ -288,6 +288,19 @@ __global__ void k_or_flag(const int32_t *bad, size_t n, int *flag) {
 void or_flag(hipStream_t st, const int32_t *bad, size_t n, int *flag) {
   if (n) hipLaunchKernelGGL(k_or_flag, dim3((n + 255) / 256), dim3(256), 0, st, bad, n, flag);
 }
+// flag |= 4 if any of the n scalars is zero (a zero weight would drop its proof from a combined check: the screened verification
+// then does not trust the check and verifies the batch proof by proof)
+__global__ void k_zero_flag(const Words8 *s, size_t n, int *flag) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t o = 0;
+#pragma unroll
+  for (int j = 0; j < 8; j++) o |= s[i].w[j];
+  if (o == 0) atomicOr(flag, 4);
+}
+void zero_flag(hipStream_t st, const Words8 *s, size_t n, int *flag) {
+  if (n) hipLaunchKernelGGL(k_zero_flag, dim3((n + 255) / 256), dim3(256), 0, st, s, n, flag);
+}
 void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n) {
   if (n) hipLaunchKernelGGL(k_and_not, dim3((n + 255) / 256), dim3(256), 0, st, ok, bad, n);
 }

@@ -219,6 +219,7 @@ void verify_transcript(hipStream_t st, size_t nb, size_t m, size_t k, const TrSt
                        const uint8_t *gadget_label = nullptr, Words8 *chi_out = nullptr, size_t nchi = 0);
 void and_not(hipStream_t st, int32_t *ok, const int32_t *bad, size_t n);
 void or_flag(hipStream_t st, const int32_t *bad, size_t n, int *flag);
+void zero_flag(hipStream_t st, const Words8 *s, size_t n, int *flag);
 
 // Verifier scalar assembly (r1cs/verifier.rs:457-532).  Writes
 //   fixed_sc[nb][2 + 2*padded_n] (B, B_blinding, g, h) and var_sc[nb][11 + m + 2k]

@@ -536,6 +536,13 @@ def test_verify_screened_combined_check_first_per_proof_on_failure(gpu, opts, on
         assert ok == want and nf == 3                  # batches 0 (proof 2), 4 (proofs 77, 78), 7 (proof 120)
         ok_stream = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch)
         assert ok_stream == want
+        # a zeroed weight buffer (a caller's bug) must not accept anything: every batch holds a zero weight and is verified per proof
+        rho_ok, rho = rho, bytes(32 * nb)
+        ok, nf = run(pts, sc, ch)
+        assert ok == want and nf == (nb + 15) // 16
+        rho = rho_ok[:32 * 77] + bytes(32) + rho_ok[32 * 78:]     # ONE zero weight, on a tampered proof: its batch falls back
+        ok, nf = run(pts, sc, ch)
+        assert ok == want and nf == 3
     finally:
         gpu.gens_destroy(g)
         gpu.circuit_destroy(circ)
