@@ -431,7 +431,8 @@ int bpgpu_r1cs_verify_shard(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
  * the usual verifier-service batching and BASELINE.json's "single big MSM"): with caller-chosen random
  * weights rho (nb x 32 B, e.g. from a CSPRNG) computes  sum_p rho_p * mega_check_p  as ONE point:
  * one fixed-base MSM over the generators with scalars sum_p rho_p s_{p,g} plus one bucket-method MSM over
- * the nb*(11+m+2k) proof points.  All nb proofs are valid iff the point (summed over all GPUs: all-gather
+ * the nb*(11+m+2k) proof points (a ZERO weight drops its proof from the check: the weights must be random and non-zero; the
+ * screened entry points below test for it).  All nb proofs are valid iff the point (summed over all GPUs: all-gather
  * of the 64-byte partials over RCCL, then a local add) is the identity.  Same input layout as
  * bpgpu_r1cs_verify_batch. */
 int bpgpu_r1cs_verify_combined(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb,
