@@ -549,6 +549,48 @@ def test_verify_screened_combined_check_first_per_proof_on_failure(gpu, opts, on
         s0.close()
 
 
+def test_verify_screened_random_shapes(gpu, opts):
+    """The screened call on ragged shapes: random proof counts, screening batch sizes that do not divide them, one to five lanes,
+    random sets of tampered proofs (incl. none and all) -- the verdicts always equal the per-proof call's, and the number of
+    fallback batches is the number of batches that hold a tampered proof."""
+    import random
+    rnd = random.Random(31337)
+    pool_n = 120
+    good, cap = bh.make_range_batch(8, pool_n, seed0=7000)
+    bad, _ = bh.make_range_batch(8, pool_n, seed0=7000, tamper=set(range(pool_n)))
+    s0 = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], good[0][1], good[0][0], cap)
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    try:
+        def inputs(rec):
+            proof, com = rec
+            s = o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap)
+            k, p, q = bh.verify_inputs(proof, com)
+            c = s.challenges()
+            s.close()
+            return p, q, c
+        gi, bi = [inputs(r) for r in good], [inputs(r) for r in bad]
+        for trial in range(10):
+            nb = rnd.choice((1, 2, 17, 50, 97, 120))
+            batch, lanes = rnd.choice((1, 7, 16, 33, 64, 200)), rnd.randrange(1, 6)
+            frac = rnd.choice((0.0, 0.02, 0.1, 0.5, 1.0))
+            tam = {i for i in range(nb) if rnd.random() < frac}
+            opts(stream_batch=rnd.choice((8, 16, 64)), screen_batch=batch, stream_lanes=lanes)
+            pick = [bi[i] if i in tam else gi[i] for i in range(nb)]
+            pts, sc, ch = (b"".join(x[j] for x in pick) for j in range(3))
+            rho = b"".join(o.s2b(rnd.randrange(1, o.N)) for _ in range(nb))
+            want = [0 if i in tam else 1 for i in range(nb)]
+            ok, nf = gpu.r1cs_verify_screened(g, circ, nb, s0.n1, s0.k, pts, sc, ch, rho)
+            assert ok == want, (trial, nb, batch, lanes, sorted(tam))
+            assert nf == len({i // batch for i in tam}), (trial, nb, batch, lanes, sorted(tam))
+            ok1, _, _ = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, False, False)
+            assert list(ok1) == want
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s0.close()
+
+
 def test_verify_screened_with_device_transcript(gpu, opts):
     """bpgpu_r1cs_verify_screened_fs_dev: the transcript replayed on the device per batch, then the batch's combined check.  150 valid
     proofs: no fallback.  With two tampered proofs, one off-curve point and one proof whose A_I1 is the identity (the transcript's
