@@ -45,34 +45,54 @@ P_NB, P_NVALS = 256, 16
 P_N, P_Q = P_NVALS * N_BITS, P_NVALS * (2 * N_BITS + 1)
 
 
-def _gen_workload(path, nb, seed0):
-    """child process (forked before the parent touches the GPU): prove nb single-value 64-bit range proofs with the
-    product path itself (C++ host mirror over the C ABI, provers in lock-step on the GPU), replay the verifier
-    transcripts on the host and write the operands of bpgpu_r1cs_verify_batch to `path`."""
+def _gen_workload(path, nb, seed0, nbatches=1):
+    """child process (forked before the parent touches the GPU): prove nbatches x nb single-value 64-bit range proofs -- every
+    one a DIFFERENT proof (its own value, blinding factors, hence challenges and verification scalars) -- with the product path
+    itself (C++ host mirror over the C ABI, provers in lock-step on the GPU), replay the verifier transcripts on the host and
+    write the operands of bpgpu_r1cs_verify_batch: batch 0 with everything the secondary legs need to `path` (a pickle), the
+    points / scalars / challenges of ALL batches, batch-major, to `path`.pts / .sc / .ch (raw bytes)."""
     import ctypes as C
     import pickle
     host = C.CDLL(os.path.join(ROOT, "tests", "host", "libbph_capi.so"))
-    vals = [(0x9E3779B97F4A7C15 * (i + 1) + seed0) & ((1 << N_BITS) - 1) for i in range(nb)]
-    arr = (C.c_uint64 * nb)(*vals)
     lab = (C.c_uint8 * len(LABEL)).from_buffer_copy(LABEL)
-    proofs, coms, plen = (C.c_uint8 * (nb * 4096))(), (C.c_uint8 * (nb * 64))(), C.c_size_t(0)
-    prove_s = None
-    for rep in range(2):      # the second call has its workspaces and generator tables in place: that one is timed
-        t0 = time.perf_counter()
-        rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(1), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr,
-                                        C.c_uint64(seed0), C.c_size_t(N_BITS), proofs, C.byref(plen), coms)
-        prove_s = time.perf_counter() - t0
-        assert rc == 0, f"bph_range_prove_batch rc={rc}"
-    pl = plen.value
     k = N_BITS.bit_length() - 1
     nvar = 11 + 1 + 2 * k
-    pts, sc, ch = (C.c_uint8 * (nb * nvar * 64))(), (C.c_uint8 * (nb * 5 * 32))(), (C.c_uint8 * (nb * (6 + k) * 32))()
-    init, dims = (C.c_uint8 * 32)(), (C.c_size_t * 6)()
     cap = 8 * N_BITS + 8
-    rp, kind, idx, coeff = (C.c_uint32 * (2 * N_BITS + 2))(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint8 * (32 * cap))()
-    rc = host.bph_range_verify_inputs(C.c_size_t(nb), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), coms, proofs,
-                                      C.c_size_t(pl), C.c_size_t(N_BITS), pts, sc, ch, init, dims, rp, kind, idx, coeff)
-    assert rc == 0, f"bph_range_verify_inputs rc={rc}"
+    tmp = path + f".tmp{os.getpid()}"
+    files = {e: open(tmp + e, "wb") for e in (".pts", ".sc", ".ch")}
+    digests = set()
+    t_gen = time.perf_counter()
+    first = None
+    for b in range(nbatches):
+        vals = [(0x9E3779B97F4A7C15 * (b * nb + i + 1) + seed0) & ((1 << N_BITS) - 1) for i in range(nb)]
+        arr = (C.c_uint64 * nb)(*vals)
+        proofs, coms, plen = (C.c_uint8 * (nb * 4096))(), (C.c_uint8 * (nb * 64))(), C.c_size_t(0)
+        for rep in range(2 if b == 0 else 1):      # batch 0: the second call has its workspaces and generator tables in place -- that one is timed
+            t0 = time.perf_counter()
+            rc = host.bph_range_prove_batch(C.c_size_t(nb), C.c_size_t(1), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), arr,
+                                            C.c_uint64(seed0 + b * nb), C.c_size_t(N_BITS), proofs, C.byref(plen), coms)
+            if b == 0:
+                prove_s = time.perf_counter() - t0
+            assert rc == 0, f"bph_range_prove_batch rc={rc}"
+        pl = plen.value
+        pts, sc, ch = (C.c_uint8 * (nb * nvar * 64))(), (C.c_uint8 * (nb * 5 * 32))(), (C.c_uint8 * (nb * (6 + k) * 32))()
+        init, dims = (C.c_uint8 * 32)(), (C.c_size_t * 6)()
+        rp, kind, idx, coeff = (C.c_uint32 * (2 * N_BITS + 2))(), (C.c_uint32 * cap)(), (C.c_uint32 * cap)(), (C.c_uint8 * (32 * cap))()
+        rc = host.bph_range_verify_inputs(C.c_size_t(nb), C.c_size_t(N_BITS), lab, C.c_size_t(len(LABEL)), coms, proofs,
+                                          C.c_size_t(pl), C.c_size_t(N_BITS), pts, sc, ch, init, dims, rp, kind, idx, coeff)
+        assert rc == 0, f"bph_range_verify_inputs rc={rc}"
+        files[".pts"].write(pts)
+        files[".sc"].write(sc)
+        files[".ch"].write(ch)
+        digests.add(hashlib.sha256(bytes(ch)).digest())
+        if b == 0:
+            first = (proofs, coms, pl, pts, sc, ch, init, dims, rp, kind, idx, coeff)
+    gen_s = time.perf_counter() - t_gen
+    assert len(digests) == nbatches, "the generated batches are not all different"
+    for e, f in files.items():
+        f.close()
+        os.replace(tmp + e, path + e)
+    proofs, coms, pl, pts, sc, ch, init, dims, rp, kind, idx, coeff = first
     n1, n, kk, m, q, nnz = list(dims)
     assert kk == k and m == 1
     G, H, B = (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * (64 * N_BITS))(), (C.c_uint8 * 64)()
@@ -91,11 +111,42 @@ def _gen_workload(path, nb, seed0):
           "proofs": bytes(proofs)[:nb * pl], "proof_len": pl, "commitments": bytes(coms), "points": bytes(pts),
           "scalars": bytes(sc), "challenges": bytes(ch), "init_state": bytes(init), "dims": (n1, n - n1, k, m),
           "csr": (list(rp)[:q + 1], list(kind)[:nnz], list(idx)[:nnz], bytes(coeff)[:32 * nnz]),
-          "G": bytes(G), "H": bytes(H), "B": bytes(B), "prove_seconds": prove_s}
-    tmp = path + f".tmp{os.getpid()}"
+          "G": bytes(G), "H": bytes(H), "B": bytes(B), "prove_seconds": prove_s, "nbatches": nbatches, "gen_seconds": gen_s}
     with open(tmp, "wb") as f:
         pickle.dump(wl, f)
     os.replace(tmp, path)
+
+
+def _load_many(cache, wl):
+    """points / scalars / challenges of ALL generated batches (batch-major raw bytes) and their number"""
+    out = []
+    for e in (".pts", ".sc", ".ch"):
+        with open(cache + e, "rb") as f:
+            out.append(f.read())
+    nbat = wl.get("nbatches", 1)
+    assert len(out[0]) == nbat * len(wl["points"]) and out[1][:len(wl["scalars"])] == wl["scalars"]
+    return out[0], out[1], out[2], nbat
+
+
+def _tampered_batch(pts, sc, ch, nb, nvar):
+    """batch 0 with four proofs made invalid in four different ways -> (points, scalars, challenges, expected accept bits):
+    t_x off by one, a challenge flipped, a proof point replaced by another proof's, an off-curve point"""
+    pts, sc, ch = bytearray(pts), bytearray(sc), bytearray(ch)
+    bad = sorted({3 % nb, nb // 3, (2 * nb) // 3 + 1, nb - 1})
+    ways = ("t_x", "challenge", "foreign_point", "off_curve")
+    cl = len(ch) // nb
+    for w, i in zip(ways, bad):
+        if w == "t_x":
+            sc[i * 160] ^= 1
+        elif w == "challenge":
+            ch[i * cl + 32] ^= 2
+        elif w == "foreign_point":
+            j = (i + 1) % nb
+            pts[i * nvar * 64 + 64:i * nvar * 64 + 128] = pts[j * nvar * 64 + 64:j * nvar * 64 + 128]
+        else:
+            pts[i * nvar * 64 + 32] ^= 1          # y of the first point: (x, y ^ 1) is not on the curve
+    exp = b"".join((0 if i in bad else 1).to_bytes(4, "little") for i in range(nb))
+    return bytes(pts), bytes(sc), bytes(ch), exp
 
 
 # ---- CPU legs: the oracle (tests/oracle_lib.py -> oracle/liboracle.so) runs ONLY inside these three worker functions, in
@@ -182,13 +233,19 @@ def _one_call_child(cache, window_bits):
     n1, n2, k, m = wl["dims"]
     pts, sc, ch = wl["points"], wl["scalars"], wl["challenges"]
     nb = len(sc) // 160
+    pts_all, sc_all, ch_all, nbat = _load_many(cache, wl)
+
+    def many(buf_all, one, reps):
+        """`reps` batches of the workload, all different when it holds that many (else the cycle repeated)"""
+        return buf_all[:reps * len(one)] if reps <= nbat else (buf_all * ((reps + nbat - 1) // nbat))[:reps * len(one)]
+
     all_ok = (1).to_bytes(4, "little") * nb
     gpu = mb.BpGpu(int(os.environ.get("LOCAL_RANK", "0")))
     circ = gpu.circuit_create(*wl["csr"], n1 + n2, m)
     gens = gpu.gens_create(wl["G"], wl["H"], wl["B"], wl["B"], window_bits)
     out = {}
     for tag, reps in (("20k", 20), ("64k", 64), ("256k", 256)):
-        d_p2, d_s2, d_c2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps)
+        d_p2, d_s2, d_c2 = gpu.to_device(many(pts_all, pts, reps)), gpu.to_device(many(sc_all, sc, reps)), gpu.to_device(many(ch_all, ch, reps))
         d_o2 = gpu.malloc(4 * nb * reps)
         ts = []
         for rep_ in range(8):
@@ -211,7 +268,8 @@ def _one_call_child(cache, window_bits):
     rho1 = b"".join(rnd_.randrange(1, ORDER_N).to_bytes(32, "little") for _ in range(nb))
     screened = {}
     for tag, reps in (("20k", 20), ("256k", 256)):
-        d_p2, d_s2, d_c2, d_r2 = gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(ch * reps), gpu.to_device(rho1 * reps)
+        d_p2, d_s2, d_c2, d_r2 = (gpu.to_device(many(pts_all, pts, reps)), gpu.to_device(many(sc_all, sc, reps)), gpu.to_device(many(ch_all, ch, reps)),
+                                  gpu.to_device(rho1 * reps))
         d_o2 = gpu.malloc(4 * nb * reps)
         ts = []
         for rep_ in range(8):
@@ -226,7 +284,7 @@ def _one_call_child(cache, window_bits):
         screened[tag] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3}
         if tag == "256k":      # one proof with t_x off by one: its screening batch (only) is verified proof by proof
             bad_i = 100 * nb + 517
-            sc_bad = bytearray(sc * reps)
+            sc_bad = bytearray(many(sc_all, sc, reps))
             sc_bad[bad_i * 160] ^= 1
             gpu.free(d_s2)
             d_s2 = gpu.to_device(bytes(sc_bad))
@@ -247,7 +305,8 @@ def _one_call_child(cache, window_bits):
             gpu.free(d)
     # ... and the whole Verifier::verify that way: transcript on the device per batch, then the combined check
     reps = 256
-    d_i2, d_p2, d_s2, d_r2 = gpu.to_device(wl["init_state"] * (nb * reps)), gpu.to_device(pts * reps), gpu.to_device(sc * reps), gpu.to_device(rho1 * reps)
+    d_i2, d_p2, d_s2, d_r2 = (gpu.to_device(wl["init_state"] * (nb * reps)), gpu.to_device(many(pts_all, pts, reps)), gpu.to_device(many(sc_all, sc, reps)),
+                              gpu.to_device(rho1 * reps))
     d_o2 = gpu.malloc(4 * nb * reps)
     ts = []
     for rep_ in range(7):
@@ -269,7 +328,8 @@ def _one_call_child(cache, window_bits):
     out["screened"] = screened
     # ... and the same from page-locked HOST memory: every batch's upload and verdict download ride on its lane
     reps = 64
-    h_p, h_s, h_c = mb.lib.host_alloc(len(pts) * reps, pts * reps), mb.lib.host_alloc(len(sc) * reps, sc * reps), mb.lib.host_alloc(len(ch) * reps, ch * reps)
+    h_p, h_s, h_c = (mb.lib.host_alloc(len(pts) * reps, many(pts_all, pts, reps)), mb.lib.host_alloc(len(sc) * reps, many(sc_all, sc, reps)),
+                     mb.lib.host_alloc(len(ch) * reps, many(ch_all, ch, reps)))
     ts = []
     for rep_ in range(6):
         gpu.sync()
@@ -280,6 +340,7 @@ def _one_call_child(cache, window_bits):
     ts = sorted(ts[2:])
     out["host_64k"] = {"value": nb * reps / ts[len(ts) // 2], "unit": "verifications/s", "proofs": nb * reps, "ms_per_call": ts[len(ts) // 2] * 1e3,
                        "bytes_uploaded": (len(pts) + len(sc) + len(ch)) * reps}
+    out["distinct_batches"] = nbat
     out["hw_queues_exported_by_the_caller"] = os.environ.get("GPU_MAX_HW_QUEUES")     # None: the library's own default is in force
     out["note"] = ("bpgpu_r1cs_verify_stream(_dev) in a process of its own: one context, one call, no environment variable exported by the caller; the "
                    "library owns the ring of 20 lanes.  20k = a burst of 20 batches on an idle GPU (the first front launches and the last back launches "
@@ -364,6 +425,10 @@ def main():
     ap.add_argument("--inflight", type=int, default=int(os.environ.get("BPGPU_INFLIGHT", "20")),
                     help="steps in flight: consecutive steps alternate between this many independent contexts "
                          "(streams + workspaces), so the kernels of several batches overlap on the GPU")
+    ap.add_argument("--distinct-batches", type=int, default=int(os.environ.get("BPGPU_DISTINCT_BATCHES", "256")),
+                    help="number of DIFFERENT batches of proofs the workload holds; the timed region (and the one-call legs) cycle "
+                         "through them, so the fixed-base table rows a step gathers (110 MB of a 57 GB table) are never the rows of "
+                         "a recent step: 256 batches touch 28 GB of rows per cycle against 256 MiB of Infinity Cache")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-combined", action="store_true", help="skip the secondary verification measurements (one-call stream, H2D-"
                                                                "inclusive, device transcript, wire format, combined batch check, single batch)")
@@ -398,10 +463,11 @@ def main():
     import tempfile
     ncpu = max(1, min(os.cpu_count() or 1, 32))
     seed0 = 0xB0117E7
-    cache = f"{a.workload_cache}.{nb}" if a.workload_cache else os.path.join(
-        tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}.pkl")
+    nbat_req = max(1, a.distinct_batches)
+    cache = f"{a.workload_cache}.{nb}x{nbat_req}" if a.workload_cache else os.path.join(
+        tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}x{nbat_req}.pkl")
     if not os.path.exists(cache) and local_rank == 0:
-        child = mp.get_context("fork").Process(target=_gen_workload, args=(cache, nb, seed0))
+        child = mp.get_context("fork").Process(target=_gen_workload, args=(cache, nb, seed0, max(1, a.distinct_batches)))
         child.start()
         child.join()
         if child.exitcode != 0:
@@ -454,12 +520,43 @@ def main():
     gpu = ctxs[0]
     circ = gpu.circuit_create(rp, kind, idx, coeff, n1 + n2, m)
     gens = gpu.gens_create(wl["G"], wl["H"], wl["B"], wl["B"], a.window_bits)
-    d_pts, d_sc, d_ch = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch)
+    import ctypes as C_
+    # every step verifies a DIFFERENT batch of the workload (cycling through `nbat` of them; rank r starts a share of the cycle
+    # further on): the table rows a step gathers are not the rows of any recent step
+    pts_all, sc_all, ch_all, nbat = _load_many(cache, wl)
+    d_pts_all, d_sc_all, d_ch_all = gpu.to_device(pts_all), gpu.to_device(sc_all), gpu.to_device(ch_all)
+    lp, ls, lc = len(pts), len(sc), len(ch)
+
+    def batch_ptrs(j):
+        j %= nbat
+        return (C_.c_void_p(d_pts_all.value + j * lp), C_.c_void_p(d_sc_all.value + j * ls), C_.c_void_p(d_ch_all.value + j * lc))
+
+    d_pts, d_sc, d_ch = batch_ptrs(0)
     d_oks = [gpu.malloc(4 * nb) for _ in ctxs]
     counter = [0]
+    rank_off = (rank * nbat) // max(1, world)
     all_ok = (1).to_bytes(4, "little") * nb
+    # untimed pre-check of the exact launches the timed region runs, on a batch that holds INVALID proofs (a verdict kernel that
+    # always wrote 1 would pass the all-ones checks below): accept bits against the expected pattern, on every context
+    nvar_ = 11 + m + 2 * k
+    t_pts, t_sc, t_ch, t_exp = _tampered_batch(pts, sc, ch, nb, nvar_)
+    d_tp, d_ts, d_tc = gpu.to_device(t_pts), gpu.to_device(t_sc), gpu.to_device(t_ch)
+    for c, d in zip(ctxs, d_oks):
+        c.r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_tp, d_ts, d_tc, d)
+    for c, d in zip(ctxs, d_oks):
+        c.sync()
+        assert c.download(d, 4 * nb) == t_exp, "GPU verification: wrong accept bits on the batch with tampered proofs"
+        c.input_flag()
+    for d in (d_tp, d_ts, d_tc):
+        gpu.free(d)
 
     def step():
+        i = counter[0] % len(ctxs)
+        p_, s_, c_ = batch_ptrs(counter[0] + rank_off)
+        counter[0] += 1
+        ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, p_, s_, c_, d_oks[i])
+
+    def step_same():
         i = counter[0] % len(ctxs)
         counter[0] += 1
         ctxs[i].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[i])
@@ -514,6 +611,9 @@ def main():
     dt = timed(lambda i: step(), a.steps)
     for c, d in zip(ctxs, d_oks):
         assert c.download(d, 4 * nb) == all_ok
+    # the same region REPLAYING one batch (what rounds 1-3 reported): its 110 MB of table rows stay in the Infinity Cache
+    counter[0] = 0
+    dt_same = timed(lambda i: step_same(), a.steps)
 
     # ======== kernel timing, measured live with HIP events on the launch streams (bpgpu_profile_*), in two further regions:
     #   (1) the same K steps (at most 256) REPLAYED with an event pair around every launch of every context: the union of the
@@ -582,16 +682,16 @@ def main():
 
         # ---- secondary: SURVEY 8d's metric as written -- the proof points, proof scalars and challenges of every step are
         # uploaded from page-locked host memory inside the timed region (asynchronous copies on the step's stream)
-        packed = pts + sc + ch                      # one page-locked staging buffer, one asynchronous copy per step
-        h_in = mb.lib.host_alloc(len(packed), packed)
-        d_in = [c.malloc(len(packed)) for c in ctxs]
-        import ctypes as C_
+        lpk = lp + ls + lc                          # one page-locked staging buffer holding every batch packed, one asynchronous copy per step
+        h_in = mb.lib.host_alloc(lpk * nbat, b"".join(pts_all[j * lp:(j + 1) * lp] + sc_all[j * ls:(j + 1) * ls] + ch_all[j * lc:(j + 1) * lc]
+                                                      for j in range(nbat)))
+        d_in = [c.malloc(lpk) for c in ctxs]
 
         def hstep(i):
             j = i % len(ctxs)
             c, dp = ctxs[j], d_in[j]
-            c.upload_async(dp, h_in, len(packed))
-            c.r1cs_verify_batch_dev(gens, circ, nb, n1, k, dp, C_.c_void_p(dp.value + len(pts)), C_.c_void_p(dp.value + len(pts) + len(sc)),
+            c.upload_async(dp, h_in.value + ((i + rank_off) % nbat) * lpk, lpk)
+            c.r1cs_verify_batch_dev(gens, circ, nb, n1, k, dp, C_.c_void_p(dp.value + lp), C_.c_void_p(dp.value + lp + ls),
                                     d_oks[j])
 
         for i in range(len(ctxs)):
@@ -601,7 +701,7 @@ def main():
             assert c.download(d, 4 * nb) == all_ok
         hdt = timed(hstep, a.steps)
         h2d = {"value": world * nb * a.steps / hdt, "unit": "verifications/s", "ms_per_step": hdt / a.steps * 1e3,
-               "bytes_per_step": len(packed),
+               "bytes_per_step": lpk,
                "note": "as `value`, plus the upload of every step's proof points, proof scalars and challenges from page-locked "
                        "host memory inside the timed region (SURVEY 8d: 'incl. H2D of proof scalars + points').  The bench contract "
                        "defines `value` with inputs resident in HBM, so this PCIe-inclusive rate is reported here, beside it"}
@@ -612,7 +712,8 @@ def main():
 
         def fstep(i):
             j = i % len(ctxs)
-            ctxs[j].r1cs_verify_batch_fs_dev(gens, circ, nb, n1, k, d_init, d_pts, d_sc, d_oks[j])
+            p_, s_, _c = batch_ptrs(i + rank_off)
+            ctxs[j].r1cs_verify_batch_fs_dev(gens, circ, nb, n1, k, d_init, p_, s_, d_oks[j])
 
         for i in range(len(ctxs)):
             fstep(i)
@@ -650,7 +751,8 @@ def main():
         d_parts = [gpu.malloc(64) for _ in ctxs]
 
         def cstep(i):
-            ctxs[i % len(ctxs)].r1cs_verify_combined_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_rho, d_parts[i % len(ctxs)])
+            p_, s_, c_ = batch_ptrs(i + rank_off)
+            ctxs[i % len(ctxs)].r1cs_verify_combined_dev(gens, circ, nb, n1, k, p_, s_, c_, d_rho, d_parts[i % len(ctxs)])
 
         for i in range(len(ctxs)):
             cstep(i)
@@ -869,7 +971,12 @@ def main():
             with open(PMC_FILE) as f:
                 pmc = json.load(f)
         lib_hash = _lib_hash()
-        pmc_ok = bool(pmc) and nb == 1024 and a.window_bits == 20
+        # the counters belong to ONE binary: instructions per step counted on another build of libbpgpu.so are reported as stale, not as a roofline
+        pmc_ok = bool(pmc) and nb == 1024 and a.window_bits == 20 and pmc.get("lib_sha256_16") == lib_hash
+        pmc_stale = ({"measured_on_lib_sha256_16": pmc.get("lib_sha256_16"), "this_lib_sha256_16": lib_hash,
+                      "valu_wave_instr_per_step_1024": pmc.get("valu_wave_instr_per_step_1024"),
+                      "note": "profiles/pmc_constants.json was counted on a different libbpgpu.so: no VALU roofline is computed from it (tools/pmc_constants.py regenerates it)"}
+                     if pmc and not pmc_ok and nb == 1024 and a.window_bits == 20 else None)
         roof = per_kernel = None
         step_s = dt / a.steps
         if solo:
@@ -881,22 +988,29 @@ def main():
             traffic = (pmc or {}).get("traffic_bytes_per_launch", {}).get(dom)
             res_step = replay["resident_ms_per_step"].get(dom)
             step_bytes = nb * (nterms * 96 + (6 + k + 5) * 32)
-            roof = {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_launch_ms": solo_ms,
-                    "algorithmic_bytes_per_launch": alg_bytes, "launches": solo_cnt,
-                    "timed": "HIP-event pairs on the launch stream around this kernel, un-pipelined steps on one context right after the timed "
-                             "region (the kernel's SOLO duration: the figure `rocprofv3 --kernel-trace` of a solo run measures, "
-                             "profiles/*_pmc_sq_summary.txt / pmc_constants.json solo_us)",
-                    "in_pipeline": {"resident_ms_per_step": res_step, "achieved": (alg_bytes / (res_step * 1e-3) / 1e9 if res_step else None),
-                                    "frac": (alg_bytes / (res_step * 1e-3) / 1e9 / HBM_PEAK_GBS if res_step else None),
-                                    "what": "union of this kernel's launch intervals over all contexts / steps of the every-launch replay: the share of "
-                                            "a step's wall clock during which the kernel is on the chip (<= ms_per_step of the replay); its launches "
-                                            "overlap each other and the other kernels' there"},
-                    "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS},
-                    "solo_reference_us": ((pmc or {}).get("solo_us", {}).get(dom) if (pmc or {}).get("lib_sha256_16") == lib_hash else None),
+            pmc_fresh = bool(pmc) and pmc.get("lib_sha256_16") == lib_hash
+            res_ms = res_step if res_step else solo_ms
+            ach_x = alg_bytes / (res_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": names[dom], "achieved": ach_x, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach_x / HBM_PEAK_GBS, "traffic": (traffic if pmc_fresh else None), "avg_launch_ms": res_ms,
+                    "algorithmic_bytes_per_launch": alg_bytes, "launches": replay["launches"].get(dom),
+                    "timed": "HIP-event pairs on the launch streams around EVERY launch of this kernel in a replay of the timed steps on all "
+                             "contexts; the duration is the UNION of its launch intervals / steps = the share of a step's wall clock during which "
+                             "the kernel is on the chip.  Exclusive by construction: it cannot exceed the replay's ms_per_step "
+                             f"({replay['ms_per_step']:.4f} ms; the timed region's: {step_s * 1e3:.4f} ms)",
+                    "solo": {"avg_launch_ms": solo_ms, "launches": solo_cnt, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS,
+                             "what": "the same kernel in un-pipelined steps on one context (what `rocprofv3 --kernel-trace` of a solo run measures, "
+                                     "pmc_constants.json solo_us): the LATENCY of a launch that occupies a third of the SIMDs -- several such "
+                                     "launches are co-resident in the timed run, so this duration exceeds ms_per_step and is NOT the roofline input",
+                             "solo_reference_us": ((pmc or {}).get("solo_us", {}).get(dom) if pmc_fresh else None)},
+                    "whole_step": {"algorithmic_bytes": step_bytes, "achieved": step_bytes / step_s / 1e9, "frac": step_bytes / step_s / 1e9 / HBM_PEAK_GBS,
+                                   "what": "all algorithmic bytes of a step / the timed region's ms_per_step"},
+                    "traffic_stale": (None if pmc_fresh or not traffic else {"bytes": traffic, "measured_on_lib_sha256_16": (pmc or {}).get("lib_sha256_16")}),
+                    "valu_issue_frac": None,
                     "note": "The path is VALU-integer bound, not HBM bound: 252-bit modular arithmetic spends ~1 650 instructions per 96 "
-                            "algorithmic bytes (roofline_valu_issue).  `traffic` (PMC, 2 x FETCH_SIZE + WRITE_SIZE) exceeds the algorithmic bytes "
-                            "because every term gathers 13 random 64-byte rows of the 57 GB fixed-base table -- bytes spent to delete doublings"}
+                            "algorithmic bytes (valu_issue_frac here = roofline_valu_issue.frac, the binding roofline).  `traffic` (PMC, per launch, "
+                            "FETCH_SIZE / WRITE_SIZE as MI355X_MICROARCH.md prescribes, counted on a run over DISTINCT batches) exceeds the algorithmic "
+                            "bytes because every term gathers 13 random 64-byte rows of the 57 GB fixed-base table (each a 128-byte line) -- bytes spent to delete doublings"}
             if pmc_ok:
                 # per kernel: VALU wave-instructions (rocprofv3 --pmc SQ_INSTS_VALU, solo) / its solo duration measured HERE / the issue
                 # peak of the SIMDs its waves occupy (waves < 1024: one SIMD each)
@@ -922,23 +1036,39 @@ def main():
                     "valu_wave_instr_per_step": instr, "measured_on_lib_sha256_16": pmc.get("lib_sha256_16"),
                     "this_lib_sha256_16": lib_hash, "binary_matches": pmc.get("lib_sha256_16") == lib_hash,
                     "per_kernel_solo": per_kernel,
-                    "note": "THE BINDING ROOFLINE.  instructions per step: rocprofv3 --pmc SQ_INSTS_VALU of a solo run (" + pmc.get("source", "profiles/") +
-                            "); peak = 1024 SIMDs x 2.4 GHz / 4.25 cycles per wave64 instruction, the issue rate of THIS instruction "
-                            "mix (74 % v_mad_i64_i32) in the doubling / addition micro-benchmarks; per_kernel_solo: each kernel alone, against "
-                            "the SIMDs its waves occupy"}
+                    "flat_4_cycle_frac": instr / step_s / (N_SIMD * 2.4e9 / 4.0),
+                    "note": "The binding roofline of this path.  instructions per step: rocprofv3 --pmc SQ_INSTS_VALU of a solo run (" + pmc.get("source", "profiles/") +
+                            "); peak = 1024 SIMDs x 2.4 GHz / 4.25 cycles per wave64 instruction.  The 4.25 is a v_mad_i64_i32-MIX figure, self-measured: "
+                            "the issue rate of THIS instruction mix (74 % v_mad_i64_i32, a quarter-rate 64-bit multiply-add) in the doubling / addition "
+                            "micro-benchmarks at 8 waves/SIMD (profiles/r01_microbench_primitives.log); the guide prices plain wave64 VALU at 2 cycles "
+                            "with >= 2 waves/SIMD, which no kernel of this mix can reach.  flat_4_cycle_frac: against one instruction per 4 cycles.  "
+                            "per_kernel_solo: each kernel alone, against the SIMDs its waves occupy"}
+            if roof:
+                roof["valu_issue_frac"] = valu["frac"]
         out = {
             "metric": "range-proof verifications/sec (64-bit, m=1)",
             "value": world * nb * a.steps / dt, "unit": "verifications/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u32x9 (29-bit limbs, 252-bit prime fields)", "data": "synthetic",
             "config": {"workload": f"batch verify {nb} x 64-bit range-gadget R1CS proofs (m=1, n=64, 154-term "
-                                   f"mega_check MSM per proof, per-proof accept bits) per GPU",
+                                   f"mega_check MSM per proof, per-proof accept bits) per GPU; every step verifies a different batch "
+                                   f"({nbat} distinct batches = {nbat * nb} different proofs, cycled)",
+                       "distinct_batches": nbat,
+                       "value_replaying_one_batch": world * nb * a.steps / dt_same,
+                       "second_metric": ({"name": "R1CS constraints/s of the prover (configs[2]: 256 provers x (16 x 64 bit))", "value": prove.get("value"),
+                                          "unit": "R1CS constraints/s", "cpu_baseline": (cpu_prove or {}).get("value")} if prove else None),
+                       "h2d_inclusive_value": (h2d or {}).get("value"),
                        "window_bits": a.window_bits, "proofs_per_step_per_gpu": nb, "steps_in_flight": steps_in_flight,
                        "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "untimed_before_the_timed_region": f"max(warmup, steps_in_flight) steps, result check, {warm_s:.1f} s of further untimed "
                                                           "steps (clocks), one hand-over step per context"},
             "roofline": roof,
             "roofline_valu_issue": valu,
+            "roofline_valu_issue_stale": pmc_stale,
+            "value_replaying_one_batch": {"value": world * nb * a.steps / dt_same, "unit": "verifications/s", "ms_per_step": dt_same / a.steps * 1e3,
+                                          "note": "the same timed region verifying ONE batch over and over (rounds 1-3's figure): its 110 MB of fixed-base "
+                                                  "table rows stay in the 256 MiB Infinity Cache; `value` cycles through distinct batches"},
+            "r1cs_constraints_per_s": (prove or {}).get("value"),
             "roofline_int": {"bound": "valu_int (v_mad_u64_u32)", "scope": "variable-base + fixed-base halves of one step's mega_check MSMs / wall time per step",
                              "achieved": (fp_var + fp_fixed) * 94 / step_s / 1e12, "peak": MAD_PEAK_TOPS, "unit": "Tmad/s",
                              "frac": (fp_var + fp_fixed) * 94 / step_s / 1e12 / MAD_PEAK_TOPS},

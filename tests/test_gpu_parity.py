@@ -1317,6 +1317,64 @@ def test_verify_batch_c20_benchmarked_instance(gpu):
         s0.close()
 
 
+@pytest.mark.parametrize("nb", [1024, 1027])
+def test_verify_batch_bench_instance_64bit_c20_default_mode(gpu, nb):
+    """EXACTLY the composite bench.py times: the 64-bit gadget (padded n = 64, k = 6 -> the vs_prep fast path +
+    k_verify_scalars_fast), 20-bit-window tables of the 130 generators (57 GB), nb >= 1024 in the default mode
+    (k_verify_front<4> -> k_verify_scalars_fast -> k_verify_windows -> k_verify_horner_groups -> k_verify_back<20,16> ->
+    k_verify_verdict), on a batch that holds tampered proofs: accept bits, every mega_check point (identity for the valid
+    proofs, the oracle's non-identity point for the tampered ones) and all 154 MSM scalars of every slot in
+    verifier.rs:517-532 order equal the oracle's.  nb = 1027 leaves the last 4-proof block / table wave partly empty."""
+    n_bits, distinct = 64, 20
+    recs, cap = bh.make_range_batch(n_bits, distinct, seed0=9400)
+    variants = []
+    for t in range(2):
+        for i, (proof, com) in enumerate(recs):
+            if t:
+                bad = bytearray(proof)
+                bad[8 + 11 * 64 + (i % 3) * 32] ^= 1 + (i % 7)       # t_x / t_x_blinding / e_blinding
+                proof = bytes(bad)
+            s = o.VerifySession(o.K_RANGE, n_bits, b"RangeProofTest", [], com, proof, cap)
+            k, p, q = bh.verify_inputs(proof, com)
+            assert (s.rc == 0) == (t == 0)
+            variants.append((p, q, s.challenges(), 1 if s.rc == 0 else 0, s.mega_check(), s.msm_terms()[0]))
+            if t == 0 and i == 0:
+                s0 = s
+                rp, kind, idx, coeff = s.csr()
+            else:
+                s.close()
+    assert (s0.nterms, s0.k, s0.n1) == (154, 6, 64)
+    circ = gpu.circuit_create(rp, kind, idx, coeff, s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 20)
+    try:
+        tam = {i for i in range(nb) if i % 53 == 11 or i in (0, 1023, nb - 1)}
+        pick = [(i % distinct) + (distinct if i in tam else 0) for i in range(nb)]
+        pts = b"".join(variants[j][0] for j in pick)
+        sc = b"".join(variants[j][1] for j in pick)
+        ch = b"".join(variants[j][2] for j in pick)
+        ok, mega, full = gpu.r1cs_verify_batch(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch, True, True)
+        nt = s0.nterms
+        for i, j in enumerate(pick):
+            assert ok[i] == variants[j][3], i
+            assert mega[64 * i:64 * i + 64] == variants[j][4], i
+            assert (mega[64 * i:64 * i + 64] == bytes(64)) == (i not in tam), i
+            assert full[32 * nt * i:32 * nt * (i + 1)] == variants[j][5], i
+        assert ok == [0 if i in tam else 1 for i in range(nb)]
+        # ... and the call bench.py makes (operands resident, accept bits only: no mega_check / scalar outputs requested)
+        d_p, d_s, d_c, d_o = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch), gpu.malloc(4 * nb)
+        try:
+            gpu.r1cs_verify_batch_dev(g, circ, nb, s0.n1, s0.k, d_p, d_s, d_c, d_o)
+            gpu.sync()
+            assert gpu.download(d_o, 4 * nb) == b"".join(v.to_bytes(4, "little") for v in ok)
+        finally:
+            for d in (d_p, d_s, d_c, d_o):
+                gpu.free(d)
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        s0.close()
+
+
 # ------------------------------------------------------------------ device-side transcript (SURVEY 8f N1)
 def test_verify_with_device_transcript(gpu):
     """The whole of Verifier::verify for a 1-phase circuit on the device: the challenges the GPU derives
