@@ -464,8 +464,12 @@ def main():
     ncpu = max(1, min(os.cpu_count() or 1, 32))
     seed0 = 0xB0117E7
     nbat_req = max(1, a.distinct_batches)
-    cache = f"{a.workload_cache}.{nb}x{nbat_req}" if a.workload_cache else os.path.join(
+    cache = f"{a.workload_cache}.{nb}" if a.workload_cache else os.path.join(
         tempfile.gettempdir(), f"bpgpu_workload_{os.environ.get('MASTER_PORT', 'solo')}_{os.getppid()}_{nb}x{nbat_req}.pkl")
+    if a.workload_cache and os.path.exists(cache) and local_rank == 0:      # a cached workload with fewer batches than asked for is made again
+        with open(cache, "rb") as f:
+            if pickle.load(f).get("nbatches", 1) < nbat_req:
+                os.remove(cache)
     if not os.path.exists(cache) and local_rank == 0:
         child = mp.get_context("fork").Process(target=_gen_workload, args=(cache, nb, seed0, max(1, a.distinct_batches)))
         child.start()

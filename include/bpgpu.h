@@ -69,7 +69,13 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
 #define BPGPU_OPT_STREAM_LANES 10          /* lanes (streams + workspaces) a bpgpu_r1cs_verify_stream call spreads its batches over, 1..64 (default 20) */
 #define BPGPU_OPT_STREAM_BATCH 11          /* proofs per batch of a bpgpu_r1cs_verify_stream call (default 1024) */
 #define BPGPU_OPT_SCREEN_BATCH 12          /* proofs per combined check of a bpgpu_r1cs_verify_screened call (default 2560; capped so that one check's proof points stay within the one-instance bucket pipeline) */
-#define BPGPU_OPT_COUNT 13
+#define BPGPU_OPT_HORNER_FORM 13           /* Horner pass of the window-parallel chain / MSMs: 0 = by mode, 1 = a lane, 2 = a DPP quad, 3 = a whole wave (row-distributed field arithmetic) per proof / group */
+#define BPGPU_OPT_HORNER_ROW_MAX 14        /* latency mode and the MSMs take the wave-per-chain form up to this many chains (default 1536: one wave per SIMD and a half) */
+#define BPGPU_OPT_PIPPENGER_MIN 15         /* terms from which an MSM that is not served by the window-parallel launches takes the bucket method (default 512) */
+#define BPGPU_OPT_IPP_PIPPENGER_MIN 16     /* the same for the L / R MSMs of bpgpu_ipp_round's literal schedule (default 257) */
+#define BPGPU_OPT_FIXED_LPM 17             /* lanes per fixed-base MSM in the verification's back launch: 16, 32, 64; 0 = by mode */
+#define BPGPU_OPT_GROUPS_FORM 18           /* first Horner stage: 0 = by mode, 1 = a lane, 2 = a DPP quad per group of 8 windows */
+#define BPGPU_OPT_COUNT 19
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
 int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);
 /* synchronise and report whether an operand of the `_dev` (device-resident, asynchronous) calls issued since the last read -- or

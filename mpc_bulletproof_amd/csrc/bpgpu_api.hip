@@ -259,6 +259,27 @@ const char *bpgpu_strerror(int code) {
 __attribute__((constructor)) static void bpgpu_runtime_defaults() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 static int ctx_create(int device, bool single_stream, bpgpu_ctx **out);
+// the one validator of option values: bpgpu_set_option and the environment seeding of a new context both go through it
+static bool opt_valid(int option, int64_t value) {
+  if (option <= 0 || option >= BPGPU_OPT_COUNT) return false;
+  switch (option) {
+    case BPGPU_OPT_MSM_WP_MAX: return value >= 0;                                          // 0 = never
+    case BPGPU_OPT_VERIFY_STRAUS_NP: return value >= 1 && value <= 4;
+    case BPGPU_OPT_VS_LARGE_MIN: return value >= 1;
+    case BPGPU_OPT_TABLE_NP: return value == 0 || value == 1 || value == 2 || value == 4 || value == 8;
+    case BPGPU_OPT_IPP_TABLE_MAX_N: return value >= 0;
+    case BPGPU_OPT_STREAM_LANES: return value >= 1 && value <= 64;
+    case BPGPU_OPT_STREAM_BATCH: return value >= 1 && value <= ((int64_t)1 << 20);
+    case BPGPU_OPT_SCREEN_BATCH: return value >= 1 && value <= ((int64_t)1 << 20);
+    case BPGPU_OPT_HORNER_FORM: return value >= 0 && value <= 3;
+    case BPGPU_OPT_HORNER_ROW_MAX: return value >= 0 && value <= ((int64_t)1 << 20);
+    case BPGPU_OPT_PIPPENGER_MIN: return value >= 2 && value <= ((int64_t)1 << 30);
+    case BPGPU_OPT_IPP_PIPPENGER_MIN: return value >= 2 && value <= ((int64_t)1 << 30);
+    case BPGPU_OPT_FIXED_LPM: return value == 0 || value == 16 || value == 32 || value == 64;
+    case BPGPU_OPT_GROUPS_FORM: return value >= 0 && value <= 2;
+    default: return value == 0 || value == 1;
+  }
+}
 int bpgpu_create(int device, bpgpu_ctx **out) {
   // BPGPU_SINGLE_STREAM=1: one stream per context (deeply pipelined callers overlap ACROSS contexts and
   // hardware queues are a limited resource: GPU_MAX_HW_QUEUES)
@@ -281,8 +302,21 @@ static int ctx_create(int device, bool single, bpgpu_ctx **out) {
         {BPGPU_OPT_VS_LARGE_MIN, "BPGPU_VS_LARGE_MIN", 4096},         {BPGPU_OPT_TABLE_NP, "BPGPU_TABLE_NP", 0},
         {BPGPU_OPT_IPP_TABLE_MAX_N, "BPGPU_IPP_TABLE_MAX_N", (int64_t)1 << 16},
         {BPGPU_OPT_STREAM_LANES, "BPGPU_STREAM_LANES", 20},           {BPGPU_OPT_STREAM_BATCH, "BPGPU_STREAM_BATCH", 1024},
-        {BPGPU_OPT_SCREEN_BATCH, "BPGPU_SCREEN_BATCH", 2560}};
-    for (auto &s : seed) { const char *e = getenv(s.env); ctx->opt[s.opt] = e ? atoll(e) : s.dflt; }
+        {BPGPU_OPT_SCREEN_BATCH, "BPGPU_SCREEN_BATCH", 2560},         {BPGPU_OPT_HORNER_FORM, "BPGPU_HORNER_FORM", 0},
+        {BPGPU_OPT_HORNER_ROW_MAX, "BPGPU_HORNER_ROW_MAX", 1536},     {BPGPU_OPT_PIPPENGER_MIN, "BPGPU_PIPPENGER_MIN", 512},
+        {BPGPU_OPT_IPP_PIPPENGER_MIN, "BPGPU_IPP_PIPPENGER_MIN", 257}, {BPGPU_OPT_FIXED_LPM, "BPGPU_FIXED_LPM", 0},
+        {BPGPU_OPT_GROUPS_FORM, "BPGPU_GROUPS_FORM", 0}};
+    // the environment only SEEDS a new context's options, through the same validation as bpgpu_set_option: a value that the
+    // setter would refuse (a batch size of 0, a negative lane count, ...) leaves the default in force
+    for (auto &s : seed) {
+      ctx->opt[s.opt] = s.dflt;
+      const char *e = getenv(s.env);
+      if (e && *e) {
+        char *end = nullptr;
+        const long long v = strtoll(e, &end, 10);
+        if (end && *end == 0 && opt_valid(s.opt, (int64_t)v)) ctx->opt[s.opt] = (int64_t)v;
+      }
+    }
   }
   if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
       (single ? ((ctx->st2 = ctx->st), hipSuccess) : hipStreamCreateWithFlags(&ctx->st2, hipStreamNonBlocking)) != hipSuccess ||
@@ -344,18 +378,7 @@ int bpgpu_set_shard(bpgpu_ctx *ctx, size_t rank, size_t world) {
   return BPGPU_OK;
 }
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value) {
-  if (!ctx || option <= 0 || option >= BPGPU_OPT_COUNT) return BPGPU_E_ARG;
-  switch (option) {
-    case BPGPU_OPT_MSM_WP_MAX: if (value < 0) return BPGPU_E_ARG; break;                    // 0 = never
-    case BPGPU_OPT_VERIFY_STRAUS_NP: if (value < 1 || value > 4) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_VS_LARGE_MIN: if (value < 1) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_TABLE_NP: if (!(value == 0 || value == 1 || value == 2 || value == 4 || value == 8)) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_IPP_TABLE_MAX_N: if (value < 0) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_STREAM_LANES: if (value < 1 || value > 64) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_STREAM_BATCH: if (value < 1 || value > ((int64_t)1 << 20)) return BPGPU_E_ARG; break;
-    case BPGPU_OPT_SCREEN_BATCH: if (value < 1 || value > ((int64_t)1 << 20)) return BPGPU_E_ARG; break;
-    default: if (value != 0 && value != 1) return BPGPU_E_ARG; break;
-  }
+  if (!ctx || !opt_valid(option, value)) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   ctx->opt[option] = value;
   return BPGPU_OK;
@@ -554,6 +577,12 @@ int bpgpu_inner_product(bpgpu_ctx *ctx, const uint8_t *a, const uint8_t *b, size
 // ahead from 2^16 terms on: 0.96 against 1.05 ms, 1.07 against 1.59 ms at 2^17; a Straus lane per term + a sum: 1.05 ms).
 // points: ABI bytes (validated in the table launch; *d_flag on a malformed one) or, converted = true, AffDev rows.
 // *done: handled here (n <= 2^15, BPGPU_OPT_MSM_WP_MAX overrides, and at most 2^16 groups in all).
+static void wp_options(const bpgpu_ctx *ctx, VerifyWp &v) {   // the per-context launch-route options of the window-parallel chain
+  v.horner_form = (int)ctx->opt[BPGPU_OPT_HORNER_FORM];
+  v.row_max = (size_t)ctx->opt[BPGPU_OPT_HORNER_ROW_MAX];
+  v.fixed_lpm = (int)ctx->opt[BPGPU_OPT_FIXED_LPM];
+  v.groups_form = (int)ctx->opt[BPGPU_OPT_GROUPS_FORM];
+}
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done,
                         int *bad = nullptr, size_t max_n = 0) {
   const size_t wp_max = max_n ? max_n : (size_t)ctx->opt[BPGPU_OPT_MSM_WP_MAX];
@@ -578,6 +607,7 @@ static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, co
   void *dwp;
   CK(ws_get(ctx, 12, verify_wp_scratch_bytes(ng, G), &dwp));
   VerifyWp v{(const AffDev *)pts, ng, G, dwp, bad ? bad : ctx->d_flag, nullptr, true, converted};
+  wp_options(ctx, v);
   if (!verify_wp_layout_fits(v)) { ctx->err = "internal: window-parallel scratch layout exceeds its buffer (msm)"; return BPGPU_E_DEVICE; }
   VerifyDims d{};
   verify_wp_front_launch(ctx->st, v, d, nullptr, nullptr, 0, false);
@@ -597,7 +627,7 @@ static int msm_batch_dev_locked(bpgpu_ctx *ctx, size_t nb, size_t n, const void 
   CK(ws_get(ctx, 2, tot * sizeof(AffDev), &dpts));
   CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
   CK(ws_get(ctx, 4, nb * sizeof(JacRaw), &dsum));
-  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  const size_t pip_min = (size_t)ctx->opt[BPGPU_OPT_PIPPENGER_MIN];
   if (n >= pip_min) {
     // 32-bit bucket ids, sorted entries (term index | sign bit) and offsets: reject what they cannot address
     const size_t cW = 252 / (size_t)pippenger_window(n) + 1, chalf = (size_t)1 << (pippenger_window(n) - 1);
@@ -692,7 +722,7 @@ int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const uint8_t *scalars,
 /* ---------------------------------------------------------------- arkworks in-memory forms (k_ark.hip) */
 // sum_i scalars[i] * pts[i] for validated device operands (plain canonical scalars, Montgomery affine points) -> one JacRaw
 static int msm_core_locked(bpgpu_ctx *ctx, size_t n, const uint32_t *dsc, const AffDev *dpts, JacRaw *dsum) {
-  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  const size_t pip_min = (size_t)ctx->opt[BPGPU_OPT_PIPPENGER_MIN];
   bool done = false;
   CK(msm_wp_batch(ctx, 1, n, dsc, dpts, true, dsum, &done));
   if (done) return BPGPU_OK;
@@ -836,7 +866,7 @@ int bpgpu_msm_shared(bpgpu_ctx *ctx, size_t nsets, size_t n, const uint8_t *scal
   CK(ws_get(ctx, 3, tot * sizeof(JacRaw), &dres));
   CK(ws_get(ctx, 4, nsets * sizeof(JacRaw), &dsum));
   CK(ws_get(ctx, 5, nsets * 64, &dout));
-  static const size_t pip_min = getenv("BPGPU_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_PIPPENGER_MIN")) : 512;
+  const size_t pip_min = (size_t)ctx->opt[BPGPU_OPT_PIPPENGER_MIN];
   const bool bucket = n >= pip_min;
   CK(ws_get(ctx, 2, (bucket ? tot + n : n) * sizeof(AffDev), &dpts));
   CK(flag_reset(ctx));
@@ -1251,6 +1281,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     void *dwp;
     CK(ws_get(ctx, 12, verify_wp_scratch_bytes(nb, nvar), &dwp));
     VerifyWp v{(const AffDev *)points, nb, nvar, dwp, ctx->d_flag, (const int32_t *)dbadsc, ctx->latency_mode, false, (int)ctx->opt[BPGPU_OPT_TABLE_NP]};
+    wp_options(ctx, v);
     if (!verify_wp_layout_fits(v)) { ctx->err = "internal: window-parallel scratch layout exceeds its buffer (verify)"; return BPGPU_E_DEVICE; }
     int32_t *aux = nullptr;
     size_t aux_stride = 0;
@@ -1339,8 +1370,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     StrausArgs af = am;
     for (int j = 0; j < vnp; j++) af.pts[j] = (const AffDev *)points + j * lanes;
     af.from_boundary = 1; af.bad = ctx->d_flag; af.bad_inner = dbadpt;
-    static const int sprio = getenv("BPGPU_STRAUS_PRIO") ? atoi(getenv("BPGPU_STRAUS_PRIO")) : 0;
-    af.prio = sprio;
+    af.prio = 0;
     ProfScope ps(ctx, 6, ctx->st);
     fused = verify_msm_fused(ctx->st, vnp, af, (JacRaw *)dvres, nb * lanes, dstr, g->c, g->table, np, g->cap,
                              (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres, nb);
@@ -2166,7 +2196,7 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
     sc_mul_strided(st, nb, h, b, n, 1, s->Hf + h, s->n0, 1, s->t4);       // b_L * H_factors[n..2n]
     sLa = s->t1; sLb = s->t2; sRa = s->t3; sRb = s->t4; so = h;
   }
-  static const size_t pip_min = getenv("BPGPU_IPP_PIPPENGER_MIN") ? (size_t)atoll(getenv("BPGPU_IPP_PIPPENGER_MIN")) : 257;
+  const size_t pip_min = (size_t)ctx->opt[BPGPU_OPT_IPP_PIPPENGER_MIN];
   {
     // make the 2 nb MSM instances contiguous: L = [a_L | b_R | c_L] x [G_R | H_L | Q], then R = [a_R | b_L | c_R] x [G_L | H_R | Q]
     const size_t io = 2 * seg;

@@ -10,6 +10,7 @@
 #include "fixed_body.cuh"
 #include "vs_prep.cuh"
 #include "ec29_quad.cuh"
+#include "ec29_row.cuh"
 
 using namespace bp;
 
@@ -398,10 +399,30 @@ __device__ __forceinline__ void horner4_body(const HornerArgs &h, size_t blk) {
   }
   if (live && role == 0) raw_store(&h.varsum[p], jact_to_jac(acc));
 }
+// The same pass with a whole WAVE per proof (ec29_row.cuh: one field multiplication spread over the 16 lanes of a DPP row, the
+// four rows = the four products of a level): a doubling is ~270 instructions deep instead of 675 -- 0.58 us against 1.35 us --
+// for 16x the lanes of the quad form.  The form for a chain that has the chip to itself: a lone batch (latency mode), the MSMs.
+__device__ __forceinline__ void horner_row_body(const HornerArgs &h, size_t blk) {
+  __builtin_amdgcn_s_setprio(2);
+  const RowK K = rowk_init();
+  const size_t p = blk;
+  JacR acc = jacr_from_limbs(K, h.winsum[p * 64 + (size_t)(h.count - 1) * h.stride].v);
+#pragma unroll 1
+  for (int w = h.count - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int d = 0; d < h.dbl; d++) acc = rdbl(K, acc);
+    acc = radd(K, acc, jacr_addend_from_limbs(K, h.winsum[p * 64 + (size_t)w * h.stride].v));
+  }
+  jacr_store(K, h.varsum[p].v, acc);
+}
 // the Horner lanes (blocks [0, horner_blocks)) and the small fixed-base MSMs in one launch
 template <int C, int LPM>
 __global__ void __launch_bounds__(64) k_verify_back(HornerArgs h, unsigned horner_blocks, FixedSmallArgs f) {
-  if (blockIdx.x < horner_blocks) { if (h.quad) horner4_body(h, blockIdx.x); else horner_body(h, blockIdx.x); }
+  if (blockIdx.x < horner_blocks) {
+    if (h.quad == 2) horner_row_body(h, blockIdx.x);
+    else if (h.quad) horner4_body(h, blockIdx.x);
+    else horner_body(h, blockIdx.x);
+  }
   else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - horner_blocks);
 }
 // lane per proof: variable-base sum + fixed-base partial; ok = identity and every input of the proof well-formed
@@ -491,25 +512,20 @@ void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_sc
   WpLayout L = wp_layout(v);
   hipLaunchKernelGGL(k_verify_windows, dim3(v.nb), dim3(64), 0, st, L.t.tab, var_scalars, v.nvar, L.winsum);
 }
-static bool wp_grouped() {
-  static const bool g = !(getenv("BPGPU_HORNER_GROUPS") && atoi(getenv("BPGPU_HORNER_GROUPS")) == 0);
-  return g;
-}
+static bool wp_grouped() { return true; }   // (two-stage Horner: the one-stage pass stays in the code for reference)
 void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   static_assert(num_windows<SW>() == 64, "64 window sums per proof");
   if (!wp_grouped()) return;
   WpLayout L = wp_layout(v);
-  static const int quad_env = getenv("BPGPU_GROUPS_QUAD") ? atoi(getenv("BPGPU_GROUPS_QUAD")) : -1;
-  const bool quad = quad_env >= 0 ? quad_env != 0 : v.latency_mode;
+  const bool quad = v.groups_form ? v.groups_form == 2 : v.latency_mode;   // BPGPU_OPT_GROUPS_FORM: 0 = by mode, 1 = lane, 2 = quad per group
   if (quad) hipLaunchKernelGGL(k_verify_horner_groups4, dim3((v.nb * (64 / HG) + 15) / 16), dim3(64), 0, st, L.winsum, v.nb);
   else hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
 }
 template <int C>
-static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode) {
+static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode, int lpm_opt) {
   // lanes per fixed-base MSM: 16 = fewest instructions (4 butterfly levels), 32 = half the serial additions per lane
-  // (the fixed-base lanes are the longest link of this launch once the Horner pass runs on quads); BPGPU_FIXED_LPM overrides
-  static const int lpm_env = getenv("BPGPU_FIXED_LPM") ? atoi(getenv("BPGPU_FIXED_LPM")) : 0;
-  const int lpm = lpm_env == 16 || lpm_env == 32 || lpm_env == 64 ? lpm_env : (f.nb >= 1024 && !latency_mode ? 16 : 32);
+  // (the fixed-base lanes are the longest link of this launch once the Horner pass runs on quads); BPGPU_OPT_FIXED_LPM overrides
+  const int lpm = lpm_opt == 16 || lpm_opt == 32 || lpm_opt == 64 ? lpm_opt : (f.nb >= 1024 && !latency_mode ? 16 : 32);
   if (lpm == 16) hipLaunchKernelGGL((k_verify_back<C, 16>), dim3(hb + (unsigned)((f.nb + 3) / 4)), dim3(64), 0, st, h, hb, f);
   else if (lpm == 32) hipLaunchKernelGGL((k_verify_back<C, 32>), dim3(hb + (unsigned)((f.nb + 1) / 2)), dim3(64), 0, st, h, hb, f);
   else hipLaunchKernelGGL((k_verify_back<C, 64>), dim3(hb + (unsigned)f.nb), dim3(64), 0, st, h, hb, f);
@@ -518,20 +534,22 @@ static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const 
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
                     const uint32_t *fixed_scalars, size_t sc_stride, JacRaw *out_fixed) {
   WpLayout L = wp_layout(v);
-  // BPGPU_HORNER_QUAD=0: one lane per proof (ec29.cuh) instead of a DPP quad per proof (ec29_quad.cuh)
-  static const int quad = getenv("BPGPU_HORNER_QUAD") ? atoi(getenv("BPGPU_HORNER_QUAD")) != 0 : 1;
+  // v.horner_form: 0 = by mode (a wave per proof when the chain has the chip to itself: latency mode and at most v.row_max
+  // proofs / groups; else a quad per proof), 1 = lane, 2 = quad, 3 = wave (row form)
+  int quad = v.horner_form == 1 ? 0 : (v.horner_form == 3 ? 2 : 1);
+  if (v.horner_form == 0 && v.latency_mode && v.nb <= v.row_max) quad = 2;
   HornerArgs h{L.winsum, L.varsum, v.nb, 64, 1, SW, quad};
   if (wp_grouped()) { h.count = 64 / HG; h.stride = HG; h.dbl = SW * HG; }
-  const unsigned hb = (unsigned)(quad ? (v.nb + 15) / 16 : (v.nb + 63) / 64);
+  const unsigned hb = (unsigned)(quad == 2 ? v.nb : (quad ? (v.nb + 15) / 16 : (v.nb + 63) / 64));
   FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
   if (!table) {   // the generator half ran as its own launch: Horner pass only
     f.nb = 0;
-    launch_back<8>(st, h, hb, f, v.latency_mode);
+    launch_back<8>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
     return;
   }
-  if (c == 8) launch_back<8>(st, h, hb, f, v.latency_mode);
-  else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode);
-  else launch_back<20>(st, h, hb, f, v.latency_mode);
+  if (c == 8) launch_back<8>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
+  else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
+  else launch_back<20>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
 }
 const JacRaw *verify_wp_varsum(const VerifyWp &v) { return wp_layout(v).varsum; }
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {

@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
 }
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
   size_t total = (1 + n0) * (252 / c + 1);
-  static const size_t fill = getenv("BPGPU_IPP_FILL") ? (size_t)atoi(getenv("BPGPU_IPP_FILL")) : 1024;   // blocks wanted on the chip (2 048: 7 % slower rounds for 256 provers -- the 7-level block sum weighs more on shorter lanes)
+  const size_t fill = 1024;   // blocks wanted on the chip (2 048: 7 % slower rounds for 256 provers -- the 7-level block sum weighs more on shorter lanes)
   size_t by_work = (total + 511) / 512, by_fill = (fill + nmsm - 1) / (nmsm ? nmsm : 1);
   size_t ch = by_work < by_fill ? by_work : by_fill;
   return ch ? ch : 1;
@@ -245,8 +245,7 @@ static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t c
                          JacRaw *out, size_t nb, size_t chunks) {
   constexpr int TPB = 128;
   size_t total = (2 + 2 * n) * num_windows<C>();
-  static const int small_env = getenv("BPGPU_FIXED_SMALL") ? atoi(getenv("BPGPU_FIXED_SMALL")) : 1;
-  if (small_env && chunks == 1 && nb >= 64 && total <= 16384) {
+  if (chunks == 1 && nb >= 64 && total <= 16384) {
     if (nb >= 1024) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
     else hipLaunchKernelGGL((k_fixed_msm_small<C, 32>), dim3((nb + 1) / 2), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
     return;

@@ -15,6 +15,7 @@
 // floor of any variable-base MSM on this machine.
 #include "ec_dev.cuh"
 #include "ec29_quad.cuh"
+#include "ec29_row.cuh"
 
 using namespace bp;
 
@@ -571,6 +572,20 @@ __global__ void __launch_bounds__(64) k_pip_final(const JacRaw *win, int W, int 
   }
   if (live && role == 0) raw_store(&out[inst * out_stride], jact_to_jac(acc));
 }
+// The same with a WAVE per instance (ec29_row.cuh: a doubling ~270 instructions deep instead of 675): for the few instances of
+// an ordinary call this tail is a lone chain on an idle chip -- 0.15 ms instead of 0.37.
+__global__ void __launch_bounds__(64) k_pip_final_row(const JacRaw *win, int W, int c, JacRaw *out, size_t out_stride) {
+  const RowK K = rowk_init();
+  const size_t inst = blockIdx.x;
+  JacR acc = jacr_from_limbs(K, win[inst * W + W - 1].v);
+#pragma unroll 1
+  for (int w = W - 2; w >= 0; w--) {
+#pragma unroll 1
+    for (int d = 0; d < c; d++) acc = rdbl(K, acc);
+    acc = radd(K, acc, jacr_addend_from_limbs(K, win[inst * W + w].v));
+  }
+  jacr_store(K, out[inst * out_stride].v, acc);
+}
 
 // window choice: minimise  n * W (bucket adds) + W * 2^(c-1) * ~3 (running sums), c in [8, 16]
 int pippenger_window(size_t n) {
@@ -584,12 +599,10 @@ int pippenger_window(size_t n) {
 }
 static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 // the two-level sort pays from ~2^15 terms per instance on (fixed cost: two more scans and launches) and needs
-// >= 256 buckets per coarse split; BPGPU_PIP_TWO_LEVEL=0 keeps the atomic scatter
+// >= 256 buckets per coarse split (below: the atomic scatter)
 static bool pip_two_level(size_t ninst, size_t n, int c) {
-  static const int env = getenv("BPGPU_PIP_TWO_LEVEL") ? atoi(getenv("BPGPU_PIP_TWO_LEVEL")) : 1;
   (void)ninst;
-  static const size_t min_n = getenv("BPGPU_PIP_TWO_LEVEL_MIN") ? (size_t)atol(getenv("BPGPU_PIP_TWO_LEVEL_MIN")) : ((size_t)1 << 15);
-  return env != 0 && c >= 12 && c <= 16 && n >= min_n;
+  return c >= 12 && c <= 16 && n >= ((size_t)1 << 15);
 }
 static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP_TASK + nbk + 1; }
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
@@ -662,8 +675,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
     else hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
   }
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
-  static const bool by_len = !(getenv("BPGPU_PIP_TASK_SORT") && atoi(getenv("BPGPU_PIP_TASK_SORT")) == 0);
-  const bool sort_tasks = by_len && tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
+  const bool sort_tasks = tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
   if (sort_tasks) {
     (void)hipMemsetAsync(tl_hist, 0, 256, st);
     hipLaunchKernelGGL(k_pip_tasklen_hist, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk, tl_hist);
@@ -675,8 +687,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   (void)hipMemsetAsync(heavy, 0, 8, st);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy);
   hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy, buckets);
-  static const bool win_ab = !(getenv("BPGPU_PIP_WINDOW_AB") && atoi(getenv("BPGPU_PIP_WINDOW_AB")) == 0);
-  if (win_ab && pp.half >= 64) {
+  if (pp.half >= 64) {
     const int chunks = pip_window_ab_chunks(pp.half);
     hipLaunchKernelGGL(k_pip_window_a, dim3(pp.W, ninst, chunks), dim3(64), 0, st, pp, buckets, win_part, chunks);
     hipLaunchKernelGGL(k_pip_window_b, dim3(ninst * W), dim3(256), 0, st, pp, win_part, win, chunks);
@@ -689,7 +700,8 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
       hipLaunchKernelGGL(k_pip_window, dim3(pp.W, ninst, 1), dim3(PW_TPB), 0, st, pp, buckets, win, 1);
     }
   }
-  hipLaunchKernelGGL(k_pip_final, dim3((ninst * 4 + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
+  if (ninst <= 1536) hipLaunchKernelGGL(k_pip_final_row, dim3((unsigned)ninst), dim3(64), 0, st, win, pp.W, pp.c, out, out_stride);
+  else hipLaunchKernelGGL(k_pip_final, dim3((ninst * 4 + 63) / 64), dim3(64), 0, st, win, pp.W, pp.c, ninst, out, out_stride);
 }
 void pippenger(hipStream_t st, const AffDev *pts, const uint32_t *scalars, size_t n, int c, JacRaw *out, void *scratch) {
   pippenger_batch(st, pts, scalars, 1, n, c, out, 1, scratch);

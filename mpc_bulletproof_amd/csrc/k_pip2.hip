@@ -20,6 +20,7 @@
 #include "fixed_body.cuh"
 #include "vs_prep.cuh"
 #include "ec29_quad.cuh"
+#include "ec29_row.cuh"
 
 using namespace bp;
 
@@ -55,8 +56,7 @@ int pippenger2_window(size_t n) {      // minimise n W (bucket additions) + W 2^
   return best;
 }
 bool pippenger2_supported(size_t n) {
-  static const int off = getenv("BPGPU_PIP2") ? atoi(getenv("BPGPU_PIP2")) == 0 : 0;
-  return !off && n >= 256 && n <= ((size_t)1 << 16);
+  return n >= 256 && n <= ((size_t)1 << 16);
 }
 static void p2_dims(size_t n, int c, size_t *W, size_t *nbk, size_t *mt) {
   *W = 252 / c + 1;
@@ -283,19 +283,19 @@ __global__ void __launch_bounds__(P2R_TPB) k_p2_reduce(Pip2 p) {
 // ---- K6: ONE quad.  out_raw and / or out_xy (boundary bytes; costs one inversion)
 struct P2Final { const JacRaw *win; int W, c; const JacRaw *extra; int nextra; JacRaw *out_raw; Words8 *out_xy; };
 __device__ __forceinline__ void p2_final_body(const P2Final &f) {
-  const int role = threadIdx.x & 3;
-  if (threadIdx.x >= 4) return;
-  JacT acc = jact_from_jac(raw_load(&f.win[f.W - 1]));
+  // ONE wave, row form (ec29_row.cuh): the 252 doublings at ~270 instructions each instead of the quad's 675
+  const RowK K = rowk_init();
+  JacR acc = jacr_from_limbs(K, f.win[f.W - 1].v);
 #pragma unroll 1
   for (int w = f.W - 2; w >= 0; w--) {
 #pragma unroll 1
-    for (int d = 0; d < f.c; d++) acc = q4_dbl(acc, role);
-    acc = q4_add(acc, jact_from_jac(raw_load(&f.win[w])), role);
+    for (int d = 0; d < f.c; d++) acc = rdbl(K, acc);
+    acc = radd(K, acc, jacr_addend_from_limbs(K, f.win[w].v));
   }
 #pragma unroll 1
-  for (int e = 0; e < f.nextra; e++) acc = q4_add(acc, jact_from_jac(raw_load(&f.extra[e])), role);
-  Jac r = jact_to_jac(acc);
-  if (role == 0) {
+  for (int e = 0; e < f.nextra; e++) acc = radd(K, acc, jacr_addend_from_limbs(K, f.extra[e].v));
+  Jac r = jacr_gather(K, acc);
+  if (threadIdx.x == 0) {
     if (f.out_raw) raw_store(f.out_raw, r);
     if (f.out_xy) {
       if (!jac_is_inf(r) && is_zero_exact(r.Z)) r = jac_inf();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # bursts of 20 steps (the driver's bench call) under the tuning knobs of the verification chain: median of 12 bursts per setting
 R=$GRAFT_REPO_ROOT
-WL=$R/gpurun_out/wl_burst
+WL=/tmp/bpgpu_wl_burst      # (the workload of 256 distinct batches is 0.5 GB: kept out of gpurun_out/, which is copied back)
 [ -f $WL.1024 ] || python3 $R/bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > $R/gpurun_out/wl_burst.log 2>&1
 export GPU_MAX_HW_QUEUES=24
 KS=20,20,20,20,20,20,20,20,20,20,20,20,1024

@@ -8,7 +8,7 @@
 #   5. FETCH_SIZE / WRITE_SIZE passes of the solo run                                             -> gpurun_out/pmc_FETCH_SIZE, pmc_WRITE_SIZE
 set -e
 R=$GRAFT_REPO_ROOT
-WL=$R/gpurun_out/wl_prof
+WL=/tmp/bpgpu_wl_prof
 python3 $R/bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > $R/gpurun_out/wl_prof.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/prof_b20 $R/gpurun_out/prof_final $R/gpurun_out/pmc_sq $R/gpurun_out/pmc_FETCH_SIZE $R/gpurun_out/pmc_WRITE_SIZE

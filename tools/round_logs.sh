@@ -11,7 +11,7 @@ python3 tools/bench_prove.py > gpurun_out/logs_bench_prove.log 2>&1
 python3 tools/bench_prove_stream.py > gpurun_out/logs_bench_prove_stream.log 2>&1
 python3 tools/bench_shuffle.py > gpurun_out/logs_bench_shuffle.log 2>&1
 python3 tools/bench_ref_benches.py > gpurun_out/logs_bench_ref_benches.log 2>&1
-WL=$R/gpurun_out/wl_burst
+WL=/tmp/bpgpu_wl_burst      # (the workload of 256 distinct batches is 0.5 GB: kept out of gpurun_out/, which is copied back)
 [ -f $WL.1024 ] || python3 bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > gpurun_out/wl_burst.log 2>&1
 BURST_KS=1,1,1,4,4,20,20,20,64,64,256,256,1024,1024,4096 python3 tools/burst_probe.py $WL.1024 20 > gpurun_out/logs_burst_probe.log 2>&1
 python3 tools/prof_combined.py $WL.1024 20 > gpurun_out/logs_combined_bursts.log 2>&1

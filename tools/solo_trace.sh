@@ -3,7 +3,7 @@
 # analyse with tools/timeline.py
 set -e
 R=$GRAFT_REPO_ROOT
-WL=$R/gpurun_out/wl_burst
+WL=/tmp/bpgpu_wl_burst      # (the workload of 256 distinct batches is 0.5 GB: kept out of gpurun_out/, which is copied back)
 [ -f $WL.1024 ] || python3 $R/bench.py --no-cpu-baseline --no-combined --no-prover --steps 4 --warmup 2 --workload-cache $WL > $R/gpurun_out/wl_burst.log 2>&1
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/solo_trace $R/gpurun_out/solo_trace_lat
