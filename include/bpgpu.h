@@ -427,7 +427,11 @@ int bpgpu_r1cs_verify_batch_fs2_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const b
  *     vectors are folded on every rank alike; bpgpu_ipp_run_fs refuses such a session (BPGPU_E_ARG: the rounds need the exchange).
  *     world = 1 (the default) turns it off.
  *   bpgpu_r1cs_verify_shard: the rank's partial mega_check point of one proof (layouts of bpgpu_r1cs_verify_batch with nb = 1;
- *     gadget_challenges for a parametric circuit, else NULL).  The proof verifies iff the sum over the ranks is the identity. */
+ *     gadget_challenges for a parametric circuit, else NULL).  The proof verifies iff the sum over the ranks is the identity.
+ *     A malformed operand (off-curve or non-canonical point, non-canonical scalar / challenge) is seen only by the rank whose
+ *     share holds it, and the verdict has to be collective: that rank returns BPGPU_OK with the POISON encoding in partial_xy
+ *     (64 bytes 0xFF, which is not a point), so that bpgpu_points_sum over the gathered partials fails with BPGPU_E_ARG on
+ *     every rank alike -- no rank is left waiting in the all-gather.  Shape errors (BPGPU_E_LEN / _GENS) are the same on all ranks. */
 int bpgpu_set_shard(bpgpu_ctx *ctx, size_t rank, size_t world);
 int bpgpu_r1cs_verify_shard(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t n1, size_t k, const uint8_t *points,
                             const uint8_t *scalars, const uint8_t *challenges, const uint8_t *gadget_challenges, size_t rank, size_t world,

@@ -1439,12 +1439,22 @@ int bpgpu_r1cs_verify_shard(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_cir
   CK(h2d(ctx, dC, challenges, (6 + k) * 32));
   if (dchi) scalars_check(ctx->st, (const Words8 *)dchi, c->nchi, ctx->d_flag);
   const size_t shard[2] = {rank, world};
+  void *dbits;                       // the proof's malformed-scalar | malformed-point bits (slot 20 of verify_batch_dev_locked, nb = 1)
+  CK(ws_get(ctx, 20, 2 * sizeof(int32_t), &dbits));
+  HIPCK(ctx, hipMemsetAsync(dbits, 0, 2 * sizeof(int32_t), ctx->st));
   CK(verify_batch_dev_locked(ctx, g, c, 1, n1, k, dP, dS, dC, dok, dmega, nullptr, dchi, shard));
+  // A malformed operand (off-curve / non-canonical point, non-canonical scalar or challenge) is seen only by the rank whose share
+  // holds it: the context flag, or -- on the large-proof route, which validates this rank's slice of the points into the proof's
+  // own bits -- the per-proof bits of workspace slot 20 (scalars | points).  The verdict must be COLLECTIVE: this rank returns
+  // BPGPU_OK with the poison encoding (64 bytes 0xFF: not a point), and bpgpu_points_sum over the gathered partials fails with
+  // BPGPU_E_ARG on every rank alike.  (An error code on one rank only would leave the others waiting in their all-gather.)
   int bad = 0;
   CK(flag_read(ctx, &bad));
-  if (bad) return BPGPU_E_ARG;      // (a malformed operand: every rank sees the same inputs and fails alike)
+  int32_t bits[2] = {0, 0};
+  CK(d2h(ctx, bits, dbits, sizeof bits));
   CK(d2h(ctx, partial_xy, dmega, 64));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
+  if (bad || bits[0] || bits[1]) memset(partial_xy, 0xFF, 64);
   return BPGPU_OK;
 }
 int bpgpu_r1cs_verify_batch(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1,

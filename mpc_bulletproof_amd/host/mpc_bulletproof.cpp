@@ -136,6 +136,24 @@ uint64_t SeededRng::next_u64() {
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
   return z ^ (z >> 31);
 }
+// ten 64-bit words of OS entropy, drawn once per process: the key of the constraint rows' running hash (CsCore::hash_term)
+static void os_entropy(uint8_t *out, size_t len) {
+  size_t got = 0;
+  while (got < len) {
+    ssize_t r = getrandom(out + got, len - got, 0);
+    if (r < 0) { if (errno == EINTR) continue; break; }
+    got += (size_t)r;
+  }
+  if (got < len) {   // kernels without getrandom(2)
+    FILE *f = std::fopen("/dev/urandom", "rb");
+    if (f) { got += std::fread(out + got, 1, len - got, f); std::fclose(f); }
+  }
+  if (got < len) throw std::runtime_error("no entropy from getrandom(2) or /dev/urandom");
+}
+static const uint64_t *row_hash_key() {
+  static const struct Key { uint64_t k[10]; Key() { os_entropy((uint8_t *)k, sizeof k); } } key;
+  return key.k;
+}
 // Keccak sponge DRBG: the 1600-bit state is seeded with 32 bytes of getrandom(2); output is squeezed 136 bytes per permutation
 // (17 words; the first version hashed twice per 32 bytes, and 256 provers drawing 525 000 blinding scalars spent 150 ms in it);
 // rekey() absorbs its material into the rate and permutes.  Forward secrecy: the rate is zeroed before EVERY permutation (the
@@ -144,17 +162,7 @@ uint64_t SeededRng::next_u64() {
 namespace { void permute_words(uint64_t s[25]); }
 OsRng::OsRng(bool vector_keys) : vk_(vector_keys) {
   uint8_t key[32];
-  size_t got = 0;
-  while (got < sizeof key) {
-    ssize_t r = getrandom(key + got, sizeof key - got, 0);
-    if (r < 0) { if (errno == EINTR) continue; break; }
-    got += (size_t)r;
-  }
-  if (got < sizeof key) {   // kernels without getrandom(2)
-    FILE *f = std::fopen("/dev/urandom", "rb");
-    if (f) { got += std::fread(key + got, 1, sizeof key - got, f); std::fclose(f); }
-  }
-  if (got < sizeof key) throw std::runtime_error("OsRng: no entropy from getrandom(2) or /dev/urandom");
+  os_entropy(key, sizeof key);
   memset(st_, 0, sizeof st_);
   memcpy(st_, key, 32);
   st_[4] ^= 0x01;                        // domain byte after the key, pad bit at the end of the rate
@@ -376,7 +384,7 @@ std::vector<StarkPoint> unpack_points(const uint8_t *b, size_t n) {
 }  // namespace
 
 // ================================================================ Device ==========================
-Device::Device(int index) {
+Device::Device(int index) : index_(index) {
   int rc = bpgpu_create(index, &ctx_);
   if (rc) throw DeviceException(rc, std::string("bpgpu_create: ") + bpgpu_strerror(rc));
 }
@@ -384,6 +392,17 @@ Device::~Device() { bpgpu_destroy(ctx_); }
 static int g_default_device_index = 0;
 void Device::set_default_index(int index) { g_default_device_index = index; }
 Device &Device::default_device() { static Device d(g_default_device_index); return d; }
+// Circuits, generator tables and the circuit cache live on the DEFAULT device's GPU: a Device handed to prove_batch / the sharded
+// verify must be a further context of that same GPU (a worker thread's own stream and pool).  Kernels of another GPU's context
+// would dereference this GPU's memory.
+static Device &same_gpu(Device *device) {
+  Device &def = Device::default_device();
+  if (!device) return def;
+  if (device->index() != def.index())
+    throw std::invalid_argument("Device of another GPU index than the default device's: select the GPU with Device::set_default_index "
+                                "before the first use (one process per GPU)");
+  return *device;
+}
 void Device::check(int rc, const char *what) const {
   if (rc) throw DeviceException(rc, std::string(what) + ": " + bpgpu_strerror(rc) + " | " + bpgpu_last_error(ctx_));
 }
@@ -1053,18 +1072,23 @@ class CsCore {
   // 128-bit running hash of the rows (variables + coefficients, in row order), updated as they are pushed: lock-step provers
   // must share their constraint rows, and comparing 255 x 2064 rows with the first prover's cost every batch as much as
   // building them (BPH_CHECK_ROWS=1 still does it); the hash also keys the cache of uploaded circuits
-  uint64_t rows_hash[2] = {0x243F6A8885A308D3ULL, 0x13198A2E03707344ULL};
+  // The hash is KEYED: ten words drawn once per process from the OS (row_hash_key()) replace the additive / xor constants of the
+  // term mixing and the initial state, so that coefficients derived from untrusted input cannot be chosen offline to collide
+  // (an unkeyed multiply-rotate hash with public constants invites that; a collision would prove against another circuit's rows).
+  uint64_t rows_hash[2] = {row_hash_key()[8], row_hash_key()[9]};
   size_t rows_nnz = 0;
   // (one dependent multiply-rotate step per TERM; the five words of a term are mixed by independent multiplications -- hashing
   // word by word was a chain of 26 dependent multiplications per row, a third of the time the 2^14-shuffle's gadget takes)
   static uint64_t rotl(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+  const uint64_t *hkey_ = row_hash_key();
   void hash_term(uint64_t v, const uint64_t w[4]) {
-    const uint64_t a = (v + 0x9E3779B97F4A7C15ULL) * 0xD6E8FEB86659FD93ULL ^ rotl((w[0] ^ 0x243F6A8885A308D3ULL) * 0xC2B2AE3D27D4EB4FULL, 13) ^
-                       rotl((w[1] + 0x13198A2E03707344ULL) * 0x9FB21C651E98DF25ULL, 26) ^ rotl((w[2] ^ 0xA4093822299F31D0ULL) * 0xFF51AFD7ED558CCDULL, 39) ^
-                       rotl((w[3] + 0x082EFA98EC4E6C89ULL) * 0xC4CEB9FE1A85EC53ULL, 52);
-    const uint64_t b = (v ^ 0x452821E638D01377ULL) * 0x94D049BB133111EBULL + rotl((w[0] + 0xBE5466CF34E90C6CULL) * 0xBF58476D1CE4E5B9ULL, 17) +
-                       rotl((w[1] ^ 0xC0AC29B7C97C50DDULL) * 0xE7037ED1A0B428DBULL, 31) + rotl((w[2] + 0x3F84D5B5B5470917ULL) * 0x8EBC6AF09C88C6E3ULL, 43) +
-                       rotl((w[3] ^ 0x9216D5D98979FB1BULL) * 0x589965CC75374CC3ULL, 55);
+    const uint64_t *k = hkey_;
+    const uint64_t a = (v + k[0]) * 0xD6E8FEB86659FD93ULL ^ rotl((w[0] ^ k[1]) * 0xC2B2AE3D27D4EB4FULL, 13) ^
+                       rotl((w[1] + k[2]) * 0x9FB21C651E98DF25ULL, 26) ^ rotl((w[2] ^ k[3]) * 0xFF51AFD7ED558CCDULL, 39) ^
+                       rotl((w[3] + k[4]) * 0xC4CEB9FE1A85EC53ULL, 52);
+    const uint64_t b = (v ^ k[5]) * 0x94D049BB133111EBULL + rotl((w[0] + k[6]) * 0xBF58476D1CE4E5B9ULL, 17) +
+                       rotl((w[1] ^ k[7]) * 0xE7037ED1A0B428DBULL, 31) + rotl((w[2] + k[3]) * 0x8EBC6AF09C88C6E3ULL, 43) +
+                       rotl((w[3] ^ k[1]) * 0x589965CC75374CC3ULL, 55);
     rows_hash[0] = rotl(rows_hash[0] ^ a, 29) * 0x9E3779B97F4A7C15ULL;
     rows_hash[1] = rotl(rows_hash[1] + b, 31) * 0xC2B2AE3D27D4EB4FULL;
   }
@@ -1333,20 +1357,29 @@ R1CSProof Prover::prove(const BulletproofGens &bp_gens, RankGroup &group, Rng *r
   return prove_batch(ps, bp_gens, rs, device, &group)[0];
 }
 // partial points of the ranks -> their sums (count points per rank, in place in `mine`)
-static void combine_partials(Device &d, RankGroup &g, uint8_t *mine, size_t count) {
+// Returns the first non-zero bpgpu_points_sum code AFTER every column has been tried: every rank sees the same gathered bytes, so
+// every rank gets the same code -- a partial that is not a point (the poison encoding a rank's bpgpu_r1cs_verify_shard returns
+// for a malformed operand in its share) fails the whole group together, with no rank left waiting in a collective.
+static int combine_partials_rc(Device &d, RankGroup &g, uint8_t *mine, size_t count) {
   const size_t w = g.size();
   std::vector<uint8_t> all(w * count * 64), col(w * 64);
   g.all_gather(mine, count * 64, all.data());
+  int first = 0;
   for (size_t j = 0; j < count; j++) {
     for (size_t r = 0; r < w; r++) memcpy(&col[64 * r], &all[(r * count + j) * 64], 64);
-    d.check(bpgpu_points_sum(d.ctx(), col.data(), w, mine + 64 * j), "bpgpu_points_sum");
+    const int rc = bpgpu_points_sum(d.ctx(), col.data(), w, mine + 64 * j);
+    if (rc && !first) first = rc;
   }
+  return first;
+}
+static void combine_partials(Device &d, RankGroup &g, uint8_t *mine, size_t count) {
+  d.check(combine_partials_rc(d, g, mine, count), "bpgpu_points_sum");
 }
 std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const BulletproofGens &bp_gens,
                                            std::vector<Rng *> &rngs, Device *device, RankGroup *group) {
   const size_t nb = provers.size();
   if (!nb || rngs.size() != nb) throw std::invalid_argument("prove_batch: one Rng per prover");
-  Device &d = device ? *device : Device::default_device();
+  Device &d = same_gpu(device);
   if (group && group->size() <= 1) group = nullptr;
   if (group && nb != 1) throw std::invalid_argument("prove_batch: a rank group shards ONE proof");
   struct ShardGuard {      // the context computes this rank's partial sums for the duration of the call
@@ -1732,17 +1765,20 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens, Ra
   if (group.size() <= 1) { verify(proof, bp_gens); return; }
   CsCore &c = *c_;
   BatchInputs in = transcript_replay(proof, bp_gens);          // (every rank replays the transcript: sequential hashing, no shares)
-  Device &d = device ? *device : Device::default_device();
+  Device &d = same_gpu(device);
   bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
   bpgpu_circuit *circ = c.upload_circuit(in.n, in.m);
   uint8_t part[64];
   int rc = bpgpu_r1cs_verify_shard(d.ctx(), gens, circ, in.n1, in.k, in.points.data(), in.scalars.data(), in.challenges.data(), nullptr,
                                    group.rank(), group.size(), part);
   bpgpu_circuit_destroy(d.ctx(), circ);
+  // E_GENS / E_LEN depend on the shapes only, which every rank holds alike: all ranks throw here together.  A malformed point or
+  // scalar is seen by the rank whose share holds it: that rank's partial is the poison encoding, and the sum fails on ALL ranks.
   if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
-  if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
   d.check(rc, "bpgpu_r1cs_verify_shard");
-  combine_partials(d, group, part, 1);
+  const int rc2 = combine_partials_rc(d, group, part, 1);
+  if (rc2 == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+  d.check(rc2, "bpgpu_points_sum");
   memcpy(c.mega.xy.data(), part, 64);
   if (!c.mega.is_identity()) throw R1CSException(R1CSError::VerificationError);      // :549-551
 }

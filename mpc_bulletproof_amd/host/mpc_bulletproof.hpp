@@ -149,6 +149,7 @@ class Device {
   Device(const Device &) = delete;
   Device &operator=(const Device &) = delete;
   bpgpu_ctx *ctx() const { return ctx_; }
+  int index() const { return index_; }   // the GPU this context lives on
   static Device &default_device();   // lazily created; device 0 unless set_default_index was called first
   // one process per GPU: a rank selects its GPU (its local rank) before the first use of the default device
   static void set_default_index(int index);
@@ -157,6 +158,7 @@ class Device {
   StarkPoint msm(const std::vector<Scalar> &scalars, const std::vector<StarkPoint> &points) const;
  private:
   bpgpu_ctx *ctx_ = nullptr;
+  int index_ = 0;
 };
 
 // ---- Transcript: stand-in for merlin::HashChainTranscript + TranscriptProtocol (src/transcript.rs) -

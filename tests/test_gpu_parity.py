@@ -710,6 +710,123 @@ def test_shard_partial_sums_add_up(gpu, world):
         gpu.gens_destroy(g)
 
 
+def test_one_context_shared_by_concurrent_threads(gpu):
+    """"thread-safe and re-entrant" -- the reference calls this arithmetic from rayon workers (inner_product_proof.rs:233-247)
+    and fabric executor threads (transcript.rs:155-161, r1cs_mpc/mpc_prover.rs:621-657).  Eight threads drive ONE bpgpu_ctx at once
+    with a mix of bpgpu_msm (window-parallel and bucket sizes), bpgpu_msm_batch, bpgpu_batch_inverse, bpgpu_msm_shared,
+    bpgpu_inner_product, bpgpu_r1cs_verify_batch (with a tampered proof) and an erroring call (a malformed point); every result of
+    every repetition must equal the oracle's, whatever the interleaving.  (ctypes releases the GIL inside the calls.)"""
+    import threading
+    import mpc_bulletproof_amd as m
+    Gp = o.gens("G", 600)
+    jobs = []          # (name, callable, expected)
+    for n in (3, 41, 600):
+        sc = o.random_scalars(5000 + n, n)
+        pts = Gp[:64 * n]
+        jobs.append((f"msm{n}", (lambda sc=sc, pts=pts: gpu.msm(sc, pts)), o.msm(sc, pts)))
+    sc = o.random_scalars(5100, 4 * 20)
+    jobs.append(("msm_batch", (lambda sc=sc: gpu.msm_batch(4, 20, sc, Gp[:64 * 20] * 4)), o.msm_batch(sc, Gp[:64 * 20] * 4, 4, 20)))
+    inv_in = o.random_scalars(5200, 300)
+    jobs.append(("batch_inverse", (lambda: gpu.batch_inverse(inv_in)), o.batch_inverse(inv_in)))
+    ssc = o.random_scalars(5300, 3 * 29)
+    jobs.append(("msm_shared", (lambda: gpu.msm_shared(3, 29, ssc, Gp[:64 * 29])), o.msm_batch(ssc, Gp[:64 * 29] * 3, 3, 29)))
+    ia, ib = o.random_scalars(5400, 500), o.random_scalars(5401, 500)
+    jobs.append(("inner_product", (lambda: gpu.inner_product(ia, ib)), o.inner_product(ia, ib)))
+    nbv = 9
+    recs, cap = bh.make_range_batch(8, nbv, seed0=5500, tamper={4})
+    sess = [o.VerifySession(o.K_RANGE, 8, b"RangeProofTest", [], com, proof, cap) for proof, com in recs]
+    s0 = sess[0]
+    circ = gpu.circuit_create(*s0.csr(), s0.n1 + s0.n2, s0.m)
+    g = _gens(gpu, cap, 8)
+    vp = vs = vc = b""
+    for (proof, com), s_ in zip(recs, sess):
+        k, p_, q_ = bh.verify_inputs(proof, com)
+        vp, vs, vc = vp + p_, vs + q_, vc + s_.challenges()
+    want_v = ([1 if s_.rc == 0 else 0 for s_ in sess], b"".join(s_.mega_check() for s_ in sess))
+    jobs.append(("verify", (lambda: gpu.r1cs_verify_batch(g, circ, nbv, s0.n1, s0.k, s0.m, vp, vs, vc, True, False)[:2]), want_v))
+    badpts = bytearray(Gp[:64 * 5])
+    badpts[7] ^= 1
+
+    def erroring():
+        try:
+            gpu.msm(o.random_scalars(1, 5), bytes(badpts))
+        except m.BpGpuError as e:
+            return e.code
+        return 0
+    jobs.append(("malformed", erroring, m.lib.E_ARG))
+    errors = []
+    start = threading.Barrier(8)
+
+    def worker(t):
+        try:
+            start.wait()
+            for rep in range(6):
+                for j in range(len(jobs)):
+                    name, fn, want = jobs[(j + t * 3 + rep) % len(jobs)]
+                    got = fn()
+                    if got != want:
+                        errors.append((t, rep, name))
+        except Exception as e:      # noqa: BLE001
+            errors.append((t, "exception", repr(e)))
+    try:
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        assert not errors, errors[:5]
+    finally:
+        gpu.gens_destroy(g)
+        gpu.circuit_destroy(circ)
+        for s_ in sess:
+            s_.close()
+
+
+def test_shard_malformed_point_is_a_collective_verdict(gpu):
+    """on the large-proof route (nvar > 256: one proof's points validated slice by slice) an off-curve point is seen only
+    by the rank whose share holds it.  That rank must not fail alone (the others would wait in the all-gather) and must not return a
+    sum that silently omits the term: it returns the poison encoding (64 x 0xFF), every other rank its ordinary partial, and
+    bpgpu_points_sum over the gathered partials fails with BPGPU_E_ARG -- the same on every rank.  The small-proof route likewise."""
+    import mpc_bulletproof_amd as m
+    for kind, param, vals, cap, where in ((o.K_RANGE_MULTI, 1 | (256 << 16), [i & 1 for i in range(256)], 256, 6 + 200),
+                                          (o.K_RANGE, 8, [77], 8, 1)):
+        rc, proof, com = o.r1cs_prove(kind, param, b"RangeProofTest", vals, 4242, cap)
+        assert rc == 0
+        s = o.VerifySession(kind, param, b"RangeProofTest", [], com, proof, cap)
+        assert s.rc == 0
+        nvar = 11 + s.m + 2 * s.k
+        assert (nvar > 256) == (kind == o.K_RANGE_MULTI)
+        g = _gens(gpu, cap, 8)
+        circ = gpu.circuit_create(*s.csr(), s.n1 + s.n2, s.m)
+        try:
+            k, pts, sc = bh.verify_inputs(proof, com)
+            world = 2
+            good = [gpu.r1cs_verify_shard(g, circ, s.n1, s.k, pts, sc, s.challenges(), r, world) for r in range(world)]
+            assert gpu.points_sum(b"".join(good)) == bytes(64) and bytes([0xFF]) * 64 not in good
+            bad = bytearray(pts)
+            bad[64 * where + 32] ^= 1                       # y ^ 1: not on the curve
+            parts = [gpu.r1cs_verify_shard(g, circ, s.n1, s.k, bytes(bad), sc, s.challenges(), r, world) for r in range(world)]
+            owner = 0 if where < (nvar + 1) // 2 else 1     # contiguous shares, the first one larger by at most one
+            assert parts[owner] == bytes([0xFF]) * 64
+            if nvar > 256:       # large-proof route: a rank validates its own slice of the points only
+                assert parts[1 - owner] == good[1 - owner]
+            else:                # small-proof route: every rank's table launch reads all points (the other ranks' SCALARS are zeroed)
+                assert parts[1 - owner] == bytes([0xFF]) * 64
+            with pytest.raises(m.BpGpuError) as e:
+                gpu.points_sum(b"".join(parts))
+            assert e.value.code == m.lib.E_ARG
+            ok, _, _ = gpu.r1cs_verify_batch(g, circ, 1, s.n1, s.k, s.m, bytes(bad), sc, s.challenges(), want_mega=False)
+            assert ok == [0]                                 # (the unsharded call rejects the same proof)
+            # a non-canonical proof scalar: every rank assembles all scalars, so every rank poisons its partial
+            bsc = bytes([0xFF]) * 32 + sc[32:]
+            parts = [gpu.r1cs_verify_shard(g, circ, s.n1, s.k, pts, bsc, s.challenges(), r, world) for r in range(world)]
+            assert parts == [bytes([0xFF]) * 64] * world
+        finally:
+            gpu.circuit_destroy(circ)
+            gpu.gens_destroy(g)
+            s.close()
+
+
 def test_options_setter_rejects_bad_values(gpu):
     import mpc_bulletproof_amd as m
     for name, bad in (("verify_straus_np", 5), ("table_np", 3), ("vs_large_min", 0), ("ipp_literal", 2), ("msm_wp_max", -1)):
