@@ -200,8 +200,113 @@ __global__ void __launch_bounds__(TPB) k_fixed_msm_ipp(const AffDev *table, size
   Jac accj = block_sum<TPB>(xyzz_to_jac(acc), red);
   if (tid == 0) raw_store(&out[(size_t)blockIdx.y * gridDim.x + blockIdx.x], accj);
 }
+
+// The same MSMs with the lanes of a wave spread over EIGHT MSMs x eight pair-lanes (a unit = 8 provers' L, or 8 provers' R, MSMs:
+// they walk the same generators).  Why: a (generator, window) sub-table of the 16-bit-window table is exactly 2 MB -- one page
+// fragment -- and the table is 69 GB (32 800 of them): with 64 lanes on 64 different pairs every wave-load touches 64 pages, far
+// beyond any TLB's reach, and the kernel spends a third of its wave-cycles waiting although rows are requested two pairs ahead.
+// Here the eight MSM lanes of a pair read eight random rows of ONE page: 8 pages per wave-load, and the units of a launch sweep
+// the table in step.  The sum over the pair-lanes is a 3-level shuffle butterfly inside the wave: no LDS, no barrier.
+template <int C>
+__global__ void __launch_bounds__(64) k_fixed_msm_ipp_g(const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
+                                                        JacRaw *out, size_t nmsm, size_t pairs_per_chunk) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  constexpr int PL = 8;                                   // pair-lanes per MSM
+  const int pl = threadIdx.x >> 3, mj = threadIdx.x & 7;
+  const bool is_R = (blockIdx.y & 1) != 0;
+  size_t msm = 2 * ((size_t)(blockIdx.y >> 1) * 8 + mj) + (is_R ? 1 : 0);
+  const bool live = msm < nmsm;
+  if (!live) msm = is_R ? 1 : 0;                          // (whole waves stay active; a clamped lane's work is discarded)
+  const size_t per = 1 + n0, half = n0 / 2, h = cur / 2;
+  const uint32_t *sc = scalars + msm * per * 8;
+  const size_t total = per * W;
+  const size_t lo = (size_t)blockIdx.x * pairs_per_chunk;
+  const size_t hi = lo + pairs_per_chunk < total ? lo + pairs_per_chunk : total;
+  Xyzz acc = xyzz_inf();
+  auto load_sc = [&](size_t ll, uint32_t *s) {
+    if (ll < hi) {
+      const size_t t = ll / W;
+#pragma unroll
+      for (int k = 0; k < 8; k++) s[k] = sc[t * 8 + k];
+    }
+  };
+  auto fetch_row = [&](size_t ll, const uint32_t *s, uint32_t *dst, int &dg) {
+    dg = 0;
+    if (ll < hi) {
+      size_t t = ll / W;
+      int w = (int)(ll - t * W);
+      uint32_t r[9];
+      recode_add_k<C>(r, s);
+      dg = recode_digit<C>(r, w);
+      if (dg != 0) {
+        size_t gen = 0;                                    // B
+        if (t > 0) {
+          const bool isH = t - 1 >= half;
+          const size_t j = isH ? t - 1 - half : t - 1;
+          const bool use_hi = is_R ? isH : !isH;           // L: G_hi, H_lo;  R: G_lo, H_hi
+          const size_t i = (j / h) * cur + (use_hi ? h : 0) + j % h;
+          gen = (isH ? 2 + cap : 2) + i;
+        }
+        const AffDev *e = table + (gen * W + w) * HALF + ((dg < 0 ? -dg : dg) - 1);
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[k] = e->w[k];
+      }
+    }
+  };
+  // rows two pairs ahead, scalar words three (as k_fixed_msm_ipp)
+  uint32_t curw[16], n1[16], sA[8], sB[8];
+  int dcur = 0, d1 = 0;
+  size_t l = lo + pl;
+  load_sc(l, sA);
+  load_sc(l + PL, sB);
+  fetch_row(l, sA, curw, dcur);
+  load_sc(l + 2 * PL, sA);
+  fetch_row(l + PL, sB, n1, d1);
+#pragma unroll
+  for (int k = 0; k < 8; k++) sB[k] = sA[k];
+  while (l < hi) {
+    uint32_t n2[16];
+    int d2;
+    load_sc(l + 3 * PL, sA);
+    fetch_row(l + 2 * PL, sB, n2, d2);
+    if (dcur != 0) {
+      Aff q;
+      q.x = unpack<FP>(curw);
+      q.y = unpack<FP>(curw + 8);
+      if (dcur < 0) q.y = neg(q.y);
+      acc = xyzz_madd(acc, q);
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { curw[k] = n1[k]; n1[k] = n2[k]; }
+#pragma unroll
+    for (int k = 0; k < 8; k++) sB[k] = sA[k];
+    dcur = d1; d1 = d2;
+    l += PL;
+  }
+  Jac accj = xyzz_to_jac(acc);
+#pragma unroll 1
+  for (int off = 8; off < 64; off <<= 1) {               // over the pair-lanes: lanes mj, mj + 8, ... of the wave
+    Jac q;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      q.X.v[t] = __shfl_xor(accj.X.v[t], off, 64);
+      q.Y.v[t] = __shfl_xor(accj.Y.v[t], off, 64);
+      q.Z.v[t] = __shfl_xor(accj.Z.v[t], off, 64);
+    }
+    accj = jac_add(accj, q);
+  }
+  if (pl == 0 && live) raw_store(&out[msm * gridDim.x + blockIdx.x], accj);
+}
+static bool ipp_grouped(size_t nmsm) { return nmsm >= 16; }   // (fewer MSMs than lanes of a unit: the block-per-chunk kernel)
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm) {
   size_t total = (1 + n0) * (252 / c + 1);
+  if (ipp_grouped(nmsm)) {       // a wave = 8 MSMs x 8 pair-lanes: ~2 048 waves on the chip, at least 32 pairs per lane
+    const size_t units = 2 * ((nmsm / 2 + 7) / 8);
+    size_t by_fill = (2048 + units - 1) / units, by_work = (total + 255) / 256;
+    size_t chg = by_work < by_fill ? by_work : by_fill;
+    return chg ? chg : 1;
+  }
   const size_t fill = 1024;   // blocks wanted on the chip (2 048: 7 % slower rounds for 256 provers -- the 7-level block sum weighs more on shorter lanes)
   size_t by_work = (total + 511) / 512, by_fill = (fill + nmsm - 1) / (nmsm ? nmsm : 1);
   size_t ch = by_work < by_fill ? by_work : by_fill;
@@ -212,6 +317,11 @@ static void launch_fixed_ipp(hipStream_t st, const AffDev *table, size_t n0, siz
                              JacRaw *dst, size_t nmsm, size_t chunks) {
   size_t total = (1 + n0) * num_windows<C>();
   size_t per = (total + chunks - 1) / chunks;
+  if (ipp_grouped(nmsm)) {
+    per = (per + 7) & ~(size_t)7;                          // (a multiple of the pair-lanes; the last chunk may be short or empty)
+    hipLaunchKernelGGL((k_fixed_msm_ipp_g<C>), dim3(chunks, 2 * ((nmsm / 2 + 7) / 8)), dim3(64), 0, st, table, n0, cap, cur, scalars, dst, nmsm, per);
+    return;
+  }
   hipLaunchKernelGGL((k_fixed_msm_ipp<C, 128>), dim3(chunks, nmsm), dim3(128), 0, st, table, n0, cap, cur, scalars, dst, per);
 }
 // partials: nmsm * fixed_msm_ipp_chunks(c, n0, nmsm) points (unused when that is 1)

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <cstdio>
 #include <cstdlib>
 
@@ -1068,6 +1069,10 @@ class CsCore {
   PedersenGens pc_gens;
   Transcript &tr;
   RandomizedConstraintSystem *self_;
+  // ParametricCircuit's probe runs: the gadget challenges come from here instead of the transcript, their labels are recorded
+  const std::vector<Scalar> *probe_chi = nullptr;
+  std::vector<std::string> *probe_labels = nullptr;
+  size_t probe_next = 0;
   RowStore constraints;
   // 128-bit running hash of the rows (variables + coefficients, in row order), updated as they are pushed: lock-step provers
   // must share their constraint rows, and comparing 255 x 2064 rows with the first prover's cost every batch as much as
@@ -1689,7 +1694,14 @@ Variable Verifier::commit_public(const Scalar &v) { return commit(c_->pc_gens.co
 void Verifier::constrain(LinearCombination lc) { c_->push_row(std::move(lc)); }
 Scalar Verifier::eval(const LinearCombination &) const { return Scalar::zero(); }
 void Verifier::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
-Scalar Verifier::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }
+Scalar Verifier::challenge_scalar(const std::string &label) {
+  if (c_->probe_labels) {           // a ParametricCircuit probe: substituted value, label recorded
+    c_->probe_labels->push_back(label);
+    const size_t i = c_->probe_next++;
+    return c_->probe_chi && i < c_->probe_chi->size() ? (*c_->probe_chi)[i] : Scalar::zero();
+  }
+  return c_->tr.challenge_scalar(label);
+}
 StarkPoint Verifier::last_mega_check() const { return c_->mega; }
 Variable Verifier::commit(const StarkPoint &V) {
   size_t i = c_->V.size();
@@ -1704,17 +1716,33 @@ void Verifier::circuit_csr(std::vector<uint32_t> &row_ptr, std::vector<uint32_t>
 }
 
 Verifier::BatchInputs Verifier::transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens) {
+  return replay(proof, bp_gens, nullptr, nullptr);
+}
+Verifier::BatchInputs Verifier::transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit,
+                                                  std::vector<uint8_t> &gadget_challenges) {
+  return replay(proof, bp_gens, &circuit, &gadget_challenges);
+}
+Verifier::BatchInputs Verifier::replay(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit *pc,
+                                       std::vector<uint8_t> *chi) {
   CsCore &c = *c_;
   Transcript &tr = c.tr;
   BatchInputs in;
+  if (pc && (c.V.size() != pc->m() || c.num_vars != 0 || c.constraints.size() != 0 || !c.deferred.empty()))
+    throw std::invalid_argument("verify with a ParametricCircuit: make the circuit's commitments, and only them (the gadgets live in the circuit)");
   try {
     tr.append_u64("m", c.V.size());                                                     // verifier.rs:398
-    in.n1 = c.num_vars;
+    in.n1 = pc ? pc->n1() : c.num_vars;
     tr.validate_and_append_point("A_I1", proof.A_I1);                                   // :401-406
     tr.validate_and_append_point("A_O1", proof.A_O1);
     tr.validate_and_append_point("S1", proof.S1);
-    c.create_randomized_constraints();                                                  // :409
-    in.n = c.num_vars; in.padded_n = next_pow2(in.n); in.m = c.V.size();
+    if (pc) {                                                                           // :366-385 with the gadget closures' only transcript
+      tr.r1cs_2phase_domain_sep();                                                      //  effect: their challenge_scalar calls, in order
+      chi->resize(32 * pc->challenge_labels().size());
+      for (size_t j = 0; j < pc->challenge_labels().size(); j++) tr.challenge_scalar(pc->challenge_labels()[j]).to_bytes_le(chi->data() + 32 * j);
+    } else {
+      c.create_randomized_constraints();                                                // :409
+    }
+    in.n = pc ? pc->n() : c.num_vars; in.padded_n = next_pow2(in.n); in.m = c.V.size();
     if (bp_gens.gens_capacity < in.padded_n) throw R1CSException(R1CSError::InvalidGeneratorsLength);   // :421-423
     tr.append_point("A_I2", proof.A_I2);                                                // :428-430
     tr.append_point("A_O2", proof.A_O2);
@@ -1800,6 +1828,107 @@ void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens) {
   if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
   if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
   d.check(rc, "bpgpu_r1cs_verify_batch");
+  if (!ok) throw R1CSException(R1CSError::VerificationError);                           // :549-551
+}
+
+// ---- ParametricCircuit --------------------------------------------------------------------------------------------------
+namespace {
+struct ProbeRows { size_t n1 = 0, n = 0; std::vector<std::vector<std::pair<Variable, Scalar>>> rows; std::vector<std::string> labels; };
+}
+ParametricCircuit::ParametricCircuit(size_t m, const std::function<void(Verifier &, const std::vector<Variable> &)> &gadgets) : m_(m) {
+  auto run = [&](const std::vector<Scalar> &chi, ProbeRows &out) {
+    Transcript tr("parametric circuit probe");
+    Verifier v(PedersenGens(), tr);
+    std::vector<Variable> vars;
+    const StarkPoint dummy = StarkPoint::generator();
+    for (size_t i = 0; i < m; i++) vars.push_back(v.commit(dummy));
+    gadgets(v, vars);
+    CsCore &c = *v.c_;
+    out.n1 = c.num_vars;
+    c.probe_chi = &chi; c.probe_labels = &out.labels; c.probe_next = 0;
+    c.create_randomized_constraints();
+    c.probe_chi = nullptr; c.probe_labels = nullptr;
+    out.n = c.num_vars;
+    out.rows.resize(c.constraints.size());
+    for (size_t r = 0; r < c.constraints.size(); r++)
+      for (auto &kv : c.constraints[r].terms)
+        if (kv.first.kind != Variable::Zero) out.rows[r].push_back(kv);
+  };
+  ProbeRows r0;
+  run({}, r0);
+  const size_t nchi = r0.labels.size();
+  if (nchi == 0) throw std::invalid_argument("ParametricCircuit: the gadgets draw no challenge (use an ordinary circuit)");
+  if (nchi > 8) throw std::invalid_argument("ParametricCircuit: more than 8 gadget challenges");
+  n1_ = r0.n1; n_ = r0.n; q_ = r0.rows.size(); labels_ = r0.labels;
+  // c_j = rows(e_j) - rows(0), term by term (a term may be absent from one of the two: coefficient 0)
+  typedef std::map<Variable, Scalar> Row;
+  auto as_map = [](const std::vector<std::pair<Variable, Scalar>> &v) { Row mrow; for (auto &kv : v) mrow[kv.first] = kv.second; return mrow; };
+  std::vector<Row> c0(q_);
+  for (size_t r = 0; r < q_; r++) c0[r] = as_map(r0.rows[r]);
+  std::vector<std::vector<Row>> cj(nchi, std::vector<Row>(q_));
+  for (size_t j = 0; j < nchi; j++) {
+    std::vector<Scalar> e(nchi);
+    e[j] = Scalar::one();
+    ProbeRows rj;
+    run(e, rj);
+    if (rj.rows.size() != q_ || rj.n != n_ || rj.n1 != n1_ || rj.labels != labels_)
+      throw std::invalid_argument("ParametricCircuit: the circuit's shape depends on its challenges");
+    for (size_t r = 0; r < q_; r++) {
+      Row mj = as_map(rj.rows[r]);
+      for (auto &kv : mj) { auto it = c0[r].find(kv.first); const Scalar d = it == c0[r].end() ? kv.second : kv.second - it->second; if (d != Scalar::zero()) cj[j][r][kv.first] = d; }
+      for (auto &kv : c0[r]) if (!mj.count(kv.first) && kv.second != Scalar::zero()) cj[j][r][kv.first] = -kv.second;
+    }
+  }
+  {   // the affine model, checked on a random point: every term of every row
+    OsRng rng(false);
+    std::vector<Scalar> rho(nchi);
+    for (auto &x : rho) x = rng.scalar();
+    ProbeRows rr;
+    run(rho, rr);
+    if (rr.rows.size() != q_ || rr.n != n_ || rr.n1 != n1_) throw std::invalid_argument("ParametricCircuit: the circuit's shape depends on its challenges");
+    for (size_t r = 0; r < q_; r++) {
+      Row want = c0[r];
+      for (size_t j = 0; j < nchi; j++) for (auto &kv : cj[j][r]) want[kv.first] = want[kv.first] + rho[j] * kv.second;
+      Row got = as_map(rr.rows[r]);
+      for (auto &kv : want) { auto it = got.find(kv.first); if ((it == got.end() ? Scalar::zero() : it->second) != kv.second) throw std::invalid_argument("ParametricCircuit: a constraint coefficient is not affine in the gadget challenges"); }
+      for (auto &kv : got) if (!want.count(kv.first) && kv.second != Scalar::zero()) throw std::invalid_argument("ParametricCircuit: a constraint coefficient is not affine in the gadget challenges");
+    }
+  }
+  // CSR of bpgpu_circuit_create_param: (1 + nchi) q rows, block 0 = c0, block j = c_j
+  std::vector<uint32_t> rp{0}, kind, idx;
+  std::vector<uint8_t> coeff;
+  auto emit = [&](const Row &row) {
+    for (auto &kv : row) {
+      if (kv.second == Scalar::zero()) continue;
+      kind.push_back((uint32_t)kv.first.kind); idx.push_back((uint32_t)kv.first.index);
+      coeff.resize(coeff.size() + 32);
+      kv.second.to_bytes_le(coeff.data() + coeff.size() - 32);
+    }
+    rp.push_back((uint32_t)kind.size());
+  };
+  for (size_t r = 0; r < q_; r++) emit(c0[r]);
+  for (size_t j = 0; j < nchi; j++) for (size_t r = 0; r < q_; r++) emit(cj[j][r]);
+  Device &d = Device::default_device();
+  if (kind.empty()) { kind.push_back(0); idx.push_back(0); coeff.resize(32); }   // (never dereferenced: row_ptr ends at 0)
+  d.check(bpgpu_circuit_create_param(d.ctx(), q_, nchi, rp.data(), kind.data(), idx.data(), coeff.data(), n_, m_, &circ_), "bpgpu_circuit_create_param");
+}
+ParametricCircuit::~ParametricCircuit() { if (circ_) bpgpu_circuit_destroy(Device::default_device().ctx(), circ_); }
+
+void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit) {
+  CsCore &c = *c_;
+  Lap lap;
+  std::vector<uint8_t> chi;
+  BatchInputs in = replay(proof, bp_gens, &circuit, &chi);
+  lap("verify (parametric): transcript replay");
+  Device &d = Device::default_device();
+  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+  int32_t ok = 0;
+  int rc = bpgpu_r1cs_verify_batch_param(d.ctx(), gens, circuit.device_circuit(), 1, in.n1, in.k, in.points.data(), in.scalars.data(),
+                                         in.challenges.data(), chi.data(), &ok, c.mega.xy.data(), nullptr);
+  lap("verify (parametric): bpgpu_r1cs_verify_batch_param");
+  if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+  if (rc == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+  d.check(rc, "bpgpu_r1cs_verify_batch_param");
   if (!ok) throw R1CSException(R1CSError::VerificationError);                           // :549-551
 }
 

@@ -369,6 +369,33 @@ class RandomizedConstraintSystem : public ConstraintSystem {
 };
 
 class CsCore;   // shared implementation
+class Verifier;
+// ONE device circuit for EVERY proof of a gadget whose randomized (second-phase) constraints are AFFINE in the challenge scalars
+// it draws -- coefficient of a term = c0 + sum_j chi_j c_j, e.g. the shuffle gadget's (x_i - z) (tests/r1cs.rs:23-62).  Without
+// it the verifier re-executes the gadget for every proof (verifier.rs:366-385: the 2^14-shuffle's 65 533 constraint rows, half of
+// a verification's wall clock) and uploads the rows again; with it the rows cross the ABI ONCE per circuit shape
+// (bpgpu_circuit_create_param) and a verification is the transcript replay plus one bpgpu_r1cs_verify_batch_param call.
+class ParametricCircuit {
+ public:
+  // `gadgets(verifier, vars)` adds the circuit's gadgets to a scratch verifier that holds `m` committed variables (vars, in
+  // commitment order).  It is run nchi + 2 times with the gadget challenges replaced by probe values (all zero; one unit vector
+  // per challenge; a random point, on which the affine model is CHECKED term by term: a gadget that is not affine in its
+  // challenges -- or whose shape depends on them -- throws std::invalid_argument).  At most 8 challenges (bpgpu.h).
+  ParametricCircuit(size_t m, const std::function<void(Verifier &, const std::vector<Variable> &)> &gadgets);
+  ~ParametricCircuit();
+  ParametricCircuit(const ParametricCircuit &) = delete;
+  ParametricCircuit &operator=(const ParametricCircuit &) = delete;
+  size_t n1() const { return n1_; }                       // first-phase multipliers
+  size_t n() const { return n_; }                         // all multipliers
+  size_t m() const { return m_; }
+  size_t num_constraints() const { return q_; }
+  const std::vector<std::string> &challenge_labels() const { return labels_; }
+  bpgpu_circuit *device_circuit() const { return circ_; }
+ private:
+  size_t n1_ = 0, n_ = 0, m_ = 0, q_ = 0;
+  std::vector<std::string> labels_;
+  bpgpu_circuit *circ_ = nullptr;
+};
 class Prover : public RandomizedConstraintSystem {
  public:
   Prover(const PedersenGens &pc_gens, Transcript &transcript);     // prover.rs:285-300
@@ -412,6 +439,10 @@ class Verifier : public RandomizedConstraintSystem {
   void verify(const R1CSProof &proof, const BulletproofGens &bp_gens);   // :393-554; throws R1CSException
   // the same with the mega_check's 13 + m + 2n + 2 lg n terms split over the ranks of `group` (every rank gets the verdict)
   void verify(const R1CSProof &proof, const BulletproofGens &bp_gens, RankGroup &group, Device *device = nullptr);
+  // Verifier::verify against a ParametricCircuit: the caller makes the commitments (commit(), in the circuit's order) and does NOT
+  // add the gadgets -- the replay draws the gadget challenges under the circuit's labels, right after the phase separator, as the
+  // gadgets' own closures would (verifier.rs:366-385), and the device takes the weights c0 + sum_j chi_j c_j.  Same verdicts.
+  void verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit);
   // The host half of verify(): the transcript replay (verifier.rs:398-455,506; inner_product_proof.rs:259-278) and
   // the operand layout of bpgpu_r1cs_verify_batch -- what a service that batches many proofs of one circuit
   // collects per proof.  Throws like verify() on identity points / bad lengths.
@@ -422,6 +453,9 @@ class Verifier : public RandomizedConstraintSystem {
     std::vector<uint8_t> challenges;   // (6 + k) x 32: y z u x w r u_1..u_k
   };
   BatchInputs transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens);
+  // the same for a parametric circuit; `gadget_challenges` receives the nchi x 32 bytes of bpgpu_r1cs_verify_batch_param
+  BatchInputs transcript_replay(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit,
+                                std::vector<uint8_t> &gadget_challenges);
   // the constraint rows as the CSR arrays of bpgpu_circuit_create (valid after transcript_replay / verify)
   void circuit_csr(std::vector<uint32_t> &row_ptr, std::vector<uint32_t> &kind, std::vector<uint32_t> &idx,
                    std::vector<uint8_t> &coeff) const;
@@ -439,6 +473,8 @@ class Verifier : public RandomizedConstraintSystem {
   void specify_randomized_constraints(Callback cb) override;
   Scalar challenge_scalar(const std::string &label) override;
  private:
+  friend class ParametricCircuit;
+  BatchInputs replay(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit *pc, std::vector<uint8_t> *chi);
   std::unique_ptr<CsCore> c_;
 };
 

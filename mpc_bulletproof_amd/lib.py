@@ -52,7 +52,7 @@ def host_alloc(nbytes, data=None):
     if rc or not p.value:
         raise BpGpuError(rc or E_OOM, "bpgpu_host_alloc")
     if data is not None:
-        C.memmove(p, bytes(data), len(data))
+        C.memmove(p, data if isinstance(data, bytes) else bytes(data), len(data))
     return p
 
 
@@ -72,6 +72,16 @@ PROF_KINDS = len(PROF_NAMES)
 
 
 def _buf(b):
+    """a read-only operand for the C ABI WITHOUT copying it: the address of the bytes object's own storage (kept alive by the
+    caller's reference for the duration of the call).  Copying 100 MB of operands twice on the Python side was what made a 2^20-term
+    bpgpu_msm from "host buffers" look 15x slower than the resident call."""
+    if not isinstance(b, bytes):
+        b = bytes(b)
+    return C.c_char_p(b if len(b) else b"\0")
+
+
+def _inout(b):
+    """an IN/OUT operand (bpgpu_batch_inverse inverts in place): a private, writable copy"""
     b = bytes(b)
     return (C.c_uint8 * max(len(b), 1)).from_buffer_copy(b if len(b) else b"\0")
 
@@ -205,7 +215,7 @@ class BpGpu:
     # ---- scalar field
     def batch_inverse(self, scalars):
         n = len(scalars) // 32
-        b = _buf(scalars)
+        b = _inout(scalars)
         self._ck(_lib.bpgpu_batch_inverse(self.ctx, b, C.c_size_t(n)))
         return bytes(b)[:32 * n]
 
@@ -555,13 +565,14 @@ class BpGpu:
         self._ck(_lib.bpgpu_r1cs_verify_stream_dev(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                    d_points, d_scalars, d_challenges, d_ok))
 
-    def r1cs_verify_stream(self, gens, circuit, nb, n1, k, m, points, scalars, challenges):
-        """the same from host memory (bytes, or c_void_p of page-locked memory for all three operands) -> [ok]"""
+    def r1cs_verify_stream(self, gens, circuit, nb, n1, k, m, points, scalars, challenges, raw=False):
+        """the same from host memory (bytes, or c_void_p of page-locked memory for all three operands) -> [ok]
+        (raw = True: the nb x int32 verdicts as bytes -- turning 65 536 verdicts into a Python list costs milliseconds)"""
         ok = (C.c_int32 * max(nb, 1))()
         wrap = lambda b: b if isinstance(b, C.c_void_p) else _buf(b)     # noqa: E731
         self._ck(_lib.bpgpu_r1cs_verify_stream(self.ctx, gens, circuit, C.c_size_t(nb), C.c_size_t(n1), C.c_size_t(k),
                                                wrap(points), wrap(scalars), wrap(challenges), ok))
-        return list(ok)[:nb]
+        return bytes(ok)[:4 * nb] if raw else ok[:nb]
 
     def r1cs_verify_screened_dev(self, gens, circuit, nb, n1, k, d_points, d_scalars, d_challenges, d_rho, d_ok):
         """combined check per batch first, per-proof path only for the batches that fail it (device-resident operands and verdicts;

@@ -427,6 +427,55 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
   })
 }
 
+// Verifier::verify of a k-shuffle proof against a ParametricCircuit (host mirror: one device circuit per shape, cached here per k):
+// reps verifications of the same proof; ms_out[0] = building the circuit (0 when it was cached), [1] = the commit calls of one
+// verification (the transcript's dependent hash chain), [2] = median of Verifier::verify(proof, gens, circuit).
+// Returns 0 when every repetition accepted, else the mapped R1CSError of the first rejection.
+int bph_shuffle_verify_param(size_t k, const uint8_t *commitments, const uint8_t *proof_bytes, size_t proof_len, size_t gens_capacity,
+                             size_t reps, double ms_out[3]) {
+  GUARD({
+    const char *label = "ShuffleProofTest";
+    PedersenGens pc_gens;
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
+    static std::mutex mu;
+    static std::map<size_t, std::unique_ptr<ParametricCircuit>> cache;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    ms_out[0] = ms_out[1] = ms_out[2] = 0;
+    ParametricCircuit *pc;
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      auto &slot = cache[k];
+      if (!slot) {
+        auto t0 = now();
+        slot.reset(new ParametricCircuit(2 * k, [k](Verifier &v, const std::vector<Variable> &vars) {
+          gadgets::shuffle_gadget(v, std::vector<Variable>(vars.begin(), vars.begin() + k), std::vector<Variable>(vars.begin() + k, vars.end()));
+        }));
+        ms_out[0] = ms(t0, now());
+      }
+      pc = slot.get();
+    }
+    R1CSProof proof = R1CSProof::from_flat_bytes(std::vector<uint8_t>(proof_bytes, proof_bytes + proof_len));
+    std::vector<StarkPoint> Vs(2 * k);
+    for (size_t i = 0; i < 2 * k; i++) memcpy(Vs[i].xy.data(), commitments + 64 * i, 64);
+    std::vector<double> tv;
+    for (size_t rep = 0; rep < (reps ? reps : 1); rep++) {
+      Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+      Verifier verifier(pc_gens, transcript);
+      auto t0 = now();
+      for (size_t i = 0; i < 2 * k; i++) verifier.commit(Vs[i]);
+      auto t1 = now();
+      verifier.verify(proof, bp_gens, *pc);
+      auto t2 = now();
+      ms_out[1] = ms(t0, t1);
+      tv.push_back(ms(t1, t2));
+    }
+    std::sort(tv.begin(), tv.end());
+    ms_out[2] = tv[tv.size() / 2];
+    return 0;
+  })
+}
+
 // The same proof split over the ranks of a group: every rank (process) calls this with the same inputs and its own
 // rank; `allgather(mine, bytes, out, user)` must gather `bytes` bytes from every rank into out[world x bytes] in rank order
 // (torch.distributed behind a ctypes callback in the tests and in bench.py).  Every rank returns the same proof and verdict.

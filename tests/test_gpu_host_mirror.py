@@ -361,3 +361,42 @@ def test_config3_full_size_shuffle_2e14(host):
     ys_bad[5] ^= 1                                          # no longer a permutation of xs
     rc_bad, _ = run(xs + ys_bad)
     assert rc_bad != 0
+
+
+@pytest.mark.parametrize("lgk", [1, 3, 6, 14])
+def test_shuffle_verified_against_a_parametric_circuit(host, lgk):
+    """Verifier::verify(proof, gens, ParametricCircuit) -- the k-shuffle's randomized constraints (tests/r1cs.rs:23-62) handed to the
+    device ONCE as coefficients affine in the gadget challenge, the verifier no longer executing the gadget per proof
+    (verifier.rs:366-385) -- gives the verdicts of the ordinary Verifier::verify: valid proofs accepted (k = 2 ... 2^14, the last
+    one BASELINE.json configs[3]'s full size), a proof of a non-permutation, a tampered proof byte and a swapped commitment rejected
+    with the same error code."""
+    k = 1 << lgk
+    cap = max(2, 2 * k)
+    xs = [((0x9E3779B97F4A7C15 * (i + 1)) & ((1 << 64) - 1)) for i in range(k)]
+    ys = xs[1:] + xs[:1]
+    ms, ms3 = (C.c_double * 6)(), (C.c_double * 3)()
+
+    def prove(values):
+        arr = (C.c_uint64 * (2 * k))(*values)
+        proof, plen, com = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * k * 64))()
+        rc = host.bph_shuffle_prove_verify(C.c_size_t(k), arr, C.c_uint64(777 + lgk), C.c_size_t(cap), proof, C.byref(plen), com, ms)
+        return rc, bytes(proof)[:plen.value], bytes(com)
+
+    def verify_param(proof, com, reps=2):
+        return host.bph_shuffle_verify_param(C.c_size_t(k), (C.c_uint8 * len(com)).from_buffer_copy(com),
+                                             (C.c_uint8 * len(proof)).from_buffer_copy(proof), C.c_size_t(len(proof)), C.c_size_t(cap),
+                                             C.c_size_t(reps), ms3)
+
+    rc, proof, com = prove(xs + ys)
+    assert rc == 0
+    assert verify_param(proof, com) == 0
+    if k > 1:
+        ys_bad = list(ys)
+        ys_bad[0] ^= 1
+        rc_bad, proof_bad, com_bad = prove(xs + ys_bad)          # (the prover runs; the mirror's own verify rejects: rc != 0)
+        assert rc_bad != 0 and verify_param(proof_bad, com_bad) == rc_bad
+        t = bytearray(proof)
+        t[8 + 11 * 64 + 3] ^= 4                                     # t_x
+        assert verify_param(bytes(t), com) == rc_bad                # VerificationError either way
+        swapped = com[64:128] + com[:64] + com[128:]
+        assert verify_param(proof, swapped) == rc_bad

@@ -449,11 +449,13 @@ def test_verify_single_dummy_circuit_proof(gpu, opts, lg, tnp):
         gpu.gens_destroy(g)
 
 
-@pytest.mark.parametrize("on_host", [False, True])
+@pytest.mark.parametrize("on_host", [False, True, "page_locked"])
 def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
     """bpgpu_r1cs_verify_stream(_dev): 150 proofs (three tampered) of the 8-bit range gadget in ONE call, cut into batches of 16
     that take turns on three lanes: the verdicts equal the oracle's proof by proof; a second call on the same context reuses the
-    lanes; a following single-batch call on the parent context sees the same results (the lanes were joined)."""
+    lanes; a following single-batch call on the parent context sees the same results (the lanes were joined).  on_host: operands in
+    pageable host memory (staged copies on every lane's stream) or page-locked (read in place by the kernels: no copy commands)."""
+    import mpc_bulletproof_amd as m
     nb, tamper = 150, {2, 77, 149}
     opts(stream_batch=16, stream_lanes=3)
     recs, cap = bh.make_range_batch(8, nb, tamper=tamper)
@@ -469,7 +471,15 @@ def test_verify_stream_over_the_lane_ring(gpu, opts, on_host):
             s.close()
         want = [0 if i in tamper else 1 for i in range(nb)]
         for rep in range(2):
-            if on_host:
+            if on_host == "page_locked":
+                hp, hs, hc = m.lib.host_alloc(len(pts) + 64, bytes(64) + pts), m.lib.host_alloc(len(sc), sc), m.lib.host_alloc(len(ch), ch)
+                import ctypes as C_
+                ok = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, C_.c_void_p(hp.value + 64), hs, hc)     # (an interior address too)
+                raw = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, C_.c_void_p(hp.value + 64), hs, hc, raw=True)
+                assert raw == b"".join(v.to_bytes(4, "little") for v in ok)
+                for h in (hp, hs, hc):
+                    m.lib.host_free(h)
+            elif on_host:
                 ok = gpu.r1cs_verify_stream(g, circ, nb, s0.n1, s0.k, s0.m, pts, sc, ch)
             else:
                 dp, ds, dc, dok = gpu.to_device(pts), gpu.to_device(sc), gpu.to_device(ch), gpu.malloc(4 * nb)

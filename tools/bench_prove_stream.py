@@ -31,7 +31,7 @@ def run(nbatch, threads, prebuild):
 
 
 run(2, 1, 1)      # generator tables, workspaces, pools
-for prebuild in (1, 0):
+for prebuild in (() if os.environ.get("PROFILE_ROUND_MSM") else (1, 0)):
     for threads in (1, 2, 3, 4):
         nbatch = 12
         run(threads, threads, prebuild)   # this thread count's contexts warm
@@ -43,3 +43,20 @@ for prebuild in (1, 0):
         wall, build, prove, drop = best[:4]
         print(f"prebuild={prebuild} threads={threads}: {wall / nbatch:7.2f} ms/batch = {nbatch * nb * q / wall / 1e3:7.2f} M constraints/s "
               f"| per batch: build {build / nbatch:6.2f}  prove_batch {prove / nbatch:6.2f}  drop {drop / nbatch:5.2f} ms", flush=True)
+
+
+def run_profiled(nbatch, threads):
+    proofs, plen = (C.c_uint8 * (nbatch * nb * 4096))(), C.c_size_t(0)
+    com, ms = (C.c_uint8 * (nbatch * nb * nvals * 64))(), (C.c_double * 12)()
+    rc = host.bph_range_prove_stream(C.c_size_t(nbatch), C.c_size_t(threads), C.c_int(1), C.c_int(1), C.c_size_t(nb), C.c_size_t(nvals),
+                                     C.c_size_t(n_bits), lab, C.c_size_t(len(label)), arr, C.c_uint64(OS), C.c_size_t(n), proofs,
+                                     C.byref(plen), com, ms)
+    assert rc == 0, rc
+    return list(ms)
+
+
+if os.environ.get("PROFILE_ROUND_MSM"):      # HIP-event duration of the round MSM (k_fixed_msm_ipp* + its partial sums), one worker thread
+    run_profiled(2, 1)
+    ms = run_profiled(4, 1)
+    print(f"round MSM (L / R table walks of one IPP round, {2 * nb} MSMs of {n + 1} terms): {ms[5] / max(ms[6], 1):.3f} ms per launch over {int(ms[6])} launches; "
+          f"device phases per batch: rounds {ms[7] / 4:.2f}  commitments {ms[8] / 4:.2f}  polys {ms[9] / 4:.2f}  T {ms[10] / 4:.2f}  ipp setup {ms[11] / 4:.2f} ms")
