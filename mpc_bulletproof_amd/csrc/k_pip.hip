@@ -276,12 +276,15 @@ __global__ void __launch_bounds__(RS_TPB) k_pip_fine_sort(const uint32_t *goff, 
 // Load balance: a bucket list is cut into tasks of at most PIP_TASK entries (the partial top window
 // has only 2^(252 mod c) non-empty buckets holding n / 2^(252 mod c) points each; equal or
 // low-entropy scalars are worse).  tcount[b] = max(1, ceil(len / PIP_TASK)); its scan gives task ids.
-constexpr uint32_t PIP_TASK = 16;
-__global__ void __launch_bounds__(256) k_pip_taskcount(const uint32_t *counts, uint32_t *tcount, size_t nb) {
+// `task` is chosen per call: 16 entries for sparse buckets, 64 when the regular buckets hold a few dozen points each (2^20 terms at
+// c = 16: 32 +- 6) -- then almost every bucket IS one task, its lane writes the bucket itself, and the merge pass (0.19 ms of a
+// 2.1 ms MSM at 2^20 terms, a lane per bucket adding two or three partials) only sees the top window's heavy buckets.
+constexpr uint32_t PIP_TASK = 16, PIP_TASK_MAX = 64;
+__global__ void __launch_bounds__(256) k_pip_taskcount(const uint32_t *counts, uint32_t *tcount, size_t nb, uint32_t task) {
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nb) return;
   uint32_t c = counts[b];
-  tcount[b] = c ? (c + PIP_TASK - 1) / PIP_TASK : 1;
+  tcount[b] = c ? (c + task - 1) / task : 1;
 }
 __global__ void __launch_bounds__(256) k_pip_taskdesc(const uint32_t *toffsets, size_t nb, uint32_t *task_bucket) {
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,36 +308,36 @@ __global__ void __launch_bounds__(256) k_pip_taskdesc_search(const uint32_t *tof
 // bucket order the 64 tasks of a wave held anything from 1 to 16 entries and the wave ran for the longest: a third of the
 // lane-time of the biggest launch of a large MSM was idle.  A counting sort of the task ids by length (17 classes, longest
 // first, block-local histograms in LDS) makes the waves uniform; partial[] stays indexed by task id, so the merge is unchanged.
-constexpr int TL_TPB = 256, TL_CLASSES = PIP_TASK + 1;
-__device__ __forceinline__ uint32_t pip_task_len(uint32_t t, const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket) {
+constexpr int TL_TPB = 256, TL_CLASSES = PIP_TASK_MAX + 1, TL_CURSOR = 128;   // (cursor: offset of the scatter cursors behind the histogram, in words)
+__device__ __forceinline__ uint32_t pip_task_len(uint32_t t, const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket, uint32_t task) {
   const uint32_t b = task_bucket[t], slice = t - toffsets[b];
-  const uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1];
+  const uint32_t lo = offsets[b] + slice * task, end = offsets[b + 1];
   const uint32_t len = lo < end ? end - lo : 0;             // (an empty bucket still owns one, empty, task)
-  return len < PIP_TASK ? len : PIP_TASK;
+  return len < task ? len : task;
 }
 // a block walks a tile of TL_TILE tasks: 17 global atomics per 4 096 tasks (one block per 256 tasks spent 60 us of a
 // 2^20-term MSM queueing on the 17 counters)
 constexpr int TL_TILE = 4096;
 __global__ void __launch_bounds__(TL_TPB) k_pip_tasklen_hist(const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket,
-                                                             size_t nbk, uint32_t *hist) {
+                                                             size_t nbk, uint32_t *hist, uint32_t task) {
   __shared__ uint32_t h[TL_CLASSES];
   if (threadIdx.x < TL_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const size_t ntasks = toffsets[nbk], t0 = (size_t)blockIdx.x * TL_TILE;
   for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB)
-    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket)], 1u);
+    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket, task)], 1u);
   __syncthreads();
   if (threadIdx.x < TL_CLASSES && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 // cursor: TL_CLASSES zeroed counters; perm[position] = task id, classes in descending length
 __global__ void __launch_bounds__(TL_TPB) k_pip_task_scatter(const uint32_t *offsets, const uint32_t *toffsets, const uint32_t *task_bucket,
-                                                             size_t nbk, const uint32_t *hist, uint32_t *cursor, uint32_t *perm) {
+                                                             size_t nbk, const uint32_t *hist, uint32_t *cursor, uint32_t *perm, uint32_t task) {
   __shared__ uint32_t h[TL_CLASSES], base[TL_CLASSES];
   if (threadIdx.x < TL_CLASSES) h[threadIdx.x] = 0;
   __syncthreads();
   const size_t ntasks = toffsets[nbk], t0 = (size_t)blockIdx.x * TL_TILE;
   for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB)
-    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket)], 1u);
+    atomicAdd(&h[pip_task_len((uint32_t)t, offsets, toffsets, task_bucket, task)], 1u);
   __syncthreads();
   if (threadIdx.x < TL_CLASSES) {
     uint32_t before = 0;
@@ -344,18 +347,18 @@ __global__ void __launch_bounds__(TL_TPB) k_pip_task_scatter(const uint32_t *off
   }
   __syncthreads();
   for (size_t t = t0 + threadIdx.x; t < t0 + TL_TILE && t < ntasks; t += TL_TPB) {
-    const uint32_t len = pip_task_len((uint32_t)t, offsets, toffsets, task_bucket);
+    const uint32_t len = pip_task_len((uint32_t)t, offsets, toffsets, task_bucket, task);
     perm[base[len] + atomicAdd(&h[len], 1u)] = (uint32_t)t;
   }
 }
 __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, const uint32_t *offsets, const uint32_t *sorted,
                                                            const uint32_t *toffsets, const uint32_t *task_bucket, size_t nbk,
-                                                           const uint32_t *perm, JacRaw *partial) {
+                                                           const uint32_t *perm, JacRaw *partial, uint32_t task, JacRaw *buckets) {
   const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (id >= toffsets[nbk]) return;
   const size_t t = perm ? perm[id] : id;
   uint32_t b = task_bucket[t], slice = (uint32_t)t - toffsets[b];
-  uint32_t lo = offsets[b] + slice * PIP_TASK, end = offsets[b + 1], hi = lo + PIP_TASK < end ? lo + PIP_TASK : end;
+  uint32_t lo = offsets[b] + slice * task, end = offsets[b + 1], hi = lo + task < end ? lo + task : end;
   Jac acc = jac_inf();
   // Two dependent loads per entry (index, then a random 64-byte row) against a ~1 650-instruction addition: the index
   // of entry e + 2 and the row of entry e + 1 are requested before the addition of entry e starts (with the row of
@@ -386,7 +389,8 @@ __global__ void __launch_bounds__(64) k_pip_bucket_bounded(const AffDev *pts, co
     vcur = vnxt;
     vnxt = vnn;
   }
-  raw_store(&partial[t], acc);
+  // a bucket that is ONE task is finished here (k_pip_merge skips it)
+  raw_store(toffsets[b + 1] - toffsets[b] == 1 ? &buckets[b] : &partial[t], acc);
 }
 // bucket = sum of its task partials.  Lane per bucket; a bucket with more than PIP_HEAVY partials (the partial top
 // window, equal or low-entropy scalars such as the 0/1 bits of a range proof) is queued for k_pip_merge_heavy
@@ -397,6 +401,7 @@ __global__ void __launch_bounds__(64) k_pip_merge(const uint32_t *toffsets, cons
   size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= nbuckets) return;
   uint32_t lo = toffsets[b], hi = toffsets[b + 1];
+  if (hi - lo == 1) return;                               // written by its one task's lane (k_pip_bucket_bounded)
   if (hi - lo > PIP_HEAVY) { heavy_list[atomicAdd(heavy_count, 1u)] = (uint32_t)b; return; }
   Jac acc = raw_load(&partial[lo]);
   for (uint32_t t = lo + 1; t < hi; t++) acc = jac_add(acc, raw_load(&partial[t]));
@@ -608,7 +613,7 @@ static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
   size_t base = al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-                al(ninst * W * sizeof(JacRaw)) * 129 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(256);
+                al(ninst * W * sizeof(JacRaw)) * 129 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(1024);
   if (pip_two_level(ninst, n, c)) {
     size_t ngh = ninst * W * RS_BINS * ((n + RS_TILE - 1) / RS_TILE);
     base += al((ngh + 1) * 4) * 2 + al((ngh / SCAN_TILE + 2) * 4) + al(tot * W * 4) + al(tot * W);
@@ -642,7 +647,11 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   uint32_t *heavy = (uint32_t *)p; p += al(mt / PIP_HEAVY * 4 + 8);              // [0] = count, [2..] = bucket ids
   uint32_t *tile_tmp = (uint32_t *)p; p += al((nbk / SCAN_TILE + 2) * 4);
   uint32_t *task_perm = (uint32_t *)p; p += al(mt * 4);
-  uint32_t *tl_hist = (uint32_t *)p; p += al(256);                               // [0, 17) histogram, [32, 49) cursors
+  uint32_t *tl_hist = (uint32_t *)p; p += al(1024);                              // [0, TL_CLASSES) histogram, [TL_CURSOR, ..) cursors
+  // entries per task: a few dozen points per regular bucket AND enough buckets to fill the chip with one lane each (4 waves per
+  // SIMD) -> a bucket is one task, no merge pass for it.  (2^17 terms, 82 k buckets: long tasks leave one wave per SIMD -- 0.92
+  // against 0.83 ms -- so the 16-entry tasks stay there.)
+  const uint32_t task = n / (size_t)pp.half >= 12 && nbk >= ((size_t)1 << 18) ? PIP_TASK_MAX : PIP_TASK;
   if (pip_two_level(ninst, n, c)) {
     // LDS-staged two-level counting sort: digits (no atomics) -> coarse histograms per tile -> scan -> coarse scatter ->
     // per-(segment, bin) fine sort, which also produces the bucket counts
@@ -666,24 +675,24 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
     pip_scan(st, counts, offsets, cursor, nbk, tile_tmp);
     if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
   }
-  hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk);
+  hipLaunchKernelGGL(k_pip_taskcount, dim3((nbk + 255) / 256), dim3(256), 0, st, counts, tcount, nbk, task);
   pip_scan(st, tcount, toffsets, nullptr, nbk, tile_tmp);
   {
     const int top_bits = 252 - c * (pp.W - 1);
-    const size_t tasks_per_top_bucket = (n >> top_bits) / PIP_TASK;     // uniform scalars: n / 2^top_bits entries per top bucket
+    const size_t tasks_per_top_bucket = (n >> top_bits) / task;     // uniform scalars: n / 2^top_bits entries per top bucket
     if (tasks_per_top_bucket > 64) hipLaunchKernelGGL(k_pip_taskdesc_search, dim3((mt + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
     else hipLaunchKernelGGL(k_pip_taskdesc, dim3((nbk + 255) / 256), dim3(256), 0, st, toffsets, nbk, task_bucket);
   }
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
   const bool sort_tasks = tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
   if (sort_tasks) {
-    (void)hipMemsetAsync(tl_hist, 0, 256, st);
-    hipLaunchKernelGGL(k_pip_tasklen_hist, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk, tl_hist);
+    (void)hipMemsetAsync(tl_hist, 0, 1024, st);
+    hipLaunchKernelGGL(k_pip_tasklen_hist, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk, tl_hist, task);
     hipLaunchKernelGGL(k_pip_task_scatter, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk,
-                       tl_hist, tl_hist + 32, task_perm);
+                       tl_hist, tl_hist + TL_CURSOR, task_perm, task);
   }
   hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
-                     nbk, sort_tasks ? task_perm : (const uint32_t *)nullptr, partial);
+                     nbk, sort_tasks ? task_perm : (const uint32_t *)nullptr, partial, task, buckets);
   (void)hipMemsetAsync(heavy, 0, 8, st);
   hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy);
   hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy, buckets);
