@@ -233,11 +233,11 @@ __global__ void k_coeff_ark_to_mont(Words8 *io, size_t n, int *bad) {
   for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
 }
 static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
-                        hipStream_t st, int part_slot = 12) {
+                        hipStream_t st, int part_slot = 12, int lpm = 0) {
   size_t chunks = fixed_msm_chunks(g->c, n, nb);
   void *dpart = nullptr;
   if (chunks > 1) CK(ws_get(ctx, part_slot, nb * chunks * sizeof(JacRaw), &dpart));
-  fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart);
+  fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart, lpm);
   return BPGPU_OK;
 }
 
@@ -370,6 +370,11 @@ void *bpgpu_stream(bpgpu_ctx *ctx) { return ctx ? (void *)ctx->st : nullptr; }
 int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on) {
   if (!ctx) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
+  if (on && ctx->st2 == ctx->st) {       // a single-stream context (BPGPU_SINGLE_STREAM): the un-pipelined caller gets its side stream now
+    HIPCK(ctx, hipSetDevice(ctx->device));
+    hipStream_t s2;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) == hipSuccess) ctx->st2 = s2; else (void)hipGetLastError();
+  }
   ctx->latency_mode = on != 0;
   return BPGPU_OK;
 }
@@ -1306,6 +1311,17 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
       shard_bounds(nvar, shard[0], shard[1], &vlo, &vhi);
       shard_mask(ctx->st, (Words8 *)dfix, np, slo, shi, shard[0] == 0, (Words8 *)dvar, nvar, vlo, vhi);
     }
+    // Latency mode with a second stream: the generator half needs nothing but the scalars, so it runs BESIDE the window sums,
+    // the first Horner stage and the Horner pass instead of sharing the back launch with the wave-per-proof Horner rows (which
+    // then have the SIMDs to themselves): a lone batch's chain loses the ~0.15 ms the two halves spent taking turns.
+    const bool side = fused_fixed && ctx->latency_mode && ctx->st2 != ctx->st && !shard;
+    if (side) {
+      HIPCK(ctx, hipEventRecord(ctx->ev1, ctx->st));
+      HIPCK(ctx, hipStreamWaitEvent(ctx->st2, ctx->ev1, 0));
+      { ProfScope ps(ctx, 1, ctx->st2);
+        CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st2, 23, 64)); }
+      HIPCK(ctx, hipEventRecord(ctx->ev2, ctx->st2));
+    }
     { ProfScope ps(ctx, 7, ctx->st);
       verify_wp_windows(ctx->st, v, (const uint32_t *)dvar); }
     { ProfScope ps(ctx, 9, ctx->st);
@@ -1313,7 +1329,8 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
     if (!fused_fixed) { ProfScope ps(ctx, 1, ctx->st);
       CK(msm_gens_dev(ctx, g, nb, np, (const uint32_t *)dfix, (JacRaw *)dfres, ctx->st, 23)); }
     { ProfScope ps(ctx, 10, ctx->st);
-      verify_wp_back(ctx->st, v, g->c, fused_fixed ? g->table : nullptr, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
+      verify_wp_back(ctx->st, v, g->c, fused_fixed && !side ? g->table : nullptr, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
+    if (side) HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
     { ProfScope ps(ctx, 11, ctx->st);
       verify_wp_verdict(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
     return launch_ok(ctx);

@@ -352,11 +352,12 @@ size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
 }
 template <int C>
 static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t stride,
-                         JacRaw *out, size_t nb, size_t chunks) {
+                         JacRaw *out, size_t nb, size_t chunks, int lpm) {
   constexpr int TPB = 128;
   size_t total = (2 + 2 * n) * num_windows<C>();
   if (chunks == 1 && nb >= 64 && total <= 16384) {
-    if (nb >= 1024) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    if (lpm == 64) hipLaunchKernelGGL((k_fixed_msm_small<C, 64>), dim3(nb), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
+    else if (nb >= 1024 && lpm != 32) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
     else hipLaunchKernelGGL((k_fixed_msm_small<C, 32>), dim3((nb + 1) / 2), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
     return;
   }
@@ -364,18 +365,18 @@ static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t c
   hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(chunks, nb), dim3(TPB), 0, st, table, n, cap, scalars, stride, out, per);
 }
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
-               size_t stride, JacRaw *out, size_t nb, JacRaw *partials) {
+               size_t stride, JacRaw *out, size_t nb, JacRaw *partials, int lpm) {
   if (!nb) return;
   size_t chunks = partials ? fixed_msm_chunks(c, n, nb) : 1;
   JacRaw *dst = chunks > 1 ? partials : out;
   switch (c) {
-    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
-    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks); break;
+    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
     default: return;   // rejected by the C-ABI before reaching here
   }
   if (chunks > 1) segmented_sum(st, partials, out, nb, chunks);

@@ -134,7 +134,7 @@ void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t
                    JacRaw *out, size_t nmsm, JacRaw *partials);
 size_t fixed_msm_chunks(int c, size_t n, size_t nb);
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
-               size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials);
+               size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials, int lpm = 0 /* lanes per small MSM: 32 = shorter lanes for a launch that is a link of a lone chain; 0 = by batch size */);
 
 // ---- verification tail -------------------------------------------------------------------------
 // per proof: sum of nvar variable-base results + the fixed-base partial; ok = is_identity;
