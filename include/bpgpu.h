@@ -74,7 +74,7 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
 #define BPGPU_OPT_PIPPENGER_MIN 15         /* terms from which an MSM that is not served by the window-parallel launches takes the bucket method (default 512) */
 #define BPGPU_OPT_IPP_PIPPENGER_MIN 16     /* the same for the L / R MSMs of bpgpu_ipp_round's literal schedule (default 257) */
 #define BPGPU_OPT_FIXED_LPM 17             /* lanes per fixed-base MSM in the verification's back launch: 16, 32, 64; 0 = by mode */
-#define BPGPU_OPT_GROUPS_FORM 18           /* first Horner stage: 0 = by mode, 1 = a lane, 2 = a DPP quad per group of 8 windows */
+#define BPGPU_OPT_GROUPS_FORM 18           /* first Horner stage: 0 = by mode, 1 = a lane, 2 = a DPP quad, 3 = a whole wave per group of 8 windows */
 #define BPGPU_OPT_COUNT 19
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
 int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);

@@ -283,7 +283,7 @@ static bool opt_valid(int option, int64_t value) {
     case BPGPU_OPT_PIPPENGER_MIN: return value >= 2 && value <= ((int64_t)1 << 30);
     case BPGPU_OPT_IPP_PIPPENGER_MIN: return value >= 2 && value <= ((int64_t)1 << 30);
     case BPGPU_OPT_FIXED_LPM: return value == 0 || value == 16 || value == 32 || value == 64;
-    case BPGPU_OPT_GROUPS_FORM: return value >= 0 && value <= 2;
+    case BPGPU_OPT_GROUPS_FORM: return value >= 0 && value <= 3;
     default: return value == 0 || value == 1;
   }
 }

@@ -366,6 +366,21 @@ __global__ void __launch_bounds__(64) k_verify_horner_groups4(JacRaw *winsum, si
   // (a clamped quad recomputes the last unit; only live quads store, after every load of the unit's slot 0 is done)
   if (live && role == 0) raw_store(&s[0], jact_to_jac(acc));
 }
+// stage 1 with a whole WAVE per (proof, group) (ec29_row.cuh): 28 doublings + 7 additions in ~23 us instead of ~65 us on a quad --
+// for the few groups of a small MSM or a handful of proofs, where this stage is a link of a lone chain
+__global__ void __launch_bounds__(64) k_verify_horner_groups_row(JacRaw *winsum) {
+  __builtin_amdgcn_s_setprio(2);
+  const RowK K = rowk_init();
+  JacRaw *s = winsum + (size_t)blockIdx.x * HG;
+  JacR acc = jacr_from_limbs(K, s[HG - 1].v);
+#pragma unroll 1
+  for (int i = HG - 2; i >= 0; i--) {
+#pragma unroll 1
+    for (int d = 0; d < SW; d++) acc = rdbl(K, acc);
+    acc = radd(K, acc, jacr_addend_from_limbs(K, s[i].v));
+  }
+  jacr_store(K, s[0].v, acc);      // (slot 0 was this wave's last load)
+}
 // one lane per proof over `count` partial sums `stride` slots apart, `dbl` doublings between them
 struct HornerArgs { const JacRaw *winsum; JacRaw *varsum; size_t nb; int count, stride, dbl, quad; };
 __device__ __forceinline__ void horner_body(const HornerArgs &h, size_t blk) {
@@ -517,7 +532,12 @@ void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   static_assert(num_windows<SW>() == 64, "64 window sums per proof");
   if (!wp_grouped()) return;
   WpLayout L = wp_layout(v);
-  const bool quad = v.groups_form ? v.groups_form == 2 : v.latency_mode;   // BPGPU_OPT_GROUPS_FORM: 0 = by mode, 1 = lane, 2 = quad per group
+  const bool quad = v.groups_form ? v.groups_form == 2 : v.latency_mode;   // BPGPU_OPT_GROUPS_FORM: 0 = by mode, 1 = lane, 2 = quad, 3 = wave per group of 8 windows
+  const size_t units = v.nb * (64 / HG);
+  if (v.groups_form == 3 || (v.groups_form == 0 && v.latency_mode && v.horner_form == 0 && units <= v.row_max)) {
+    hipLaunchKernelGGL(k_verify_horner_groups_row, dim3((unsigned)units), dim3(64), 0, st, L.winsum);
+    return;
+  }
   if (quad) hipLaunchKernelGGL(k_verify_horner_groups4, dim3((v.nb * (64 / HG) + 15) / 16), dim3(64), 0, st, L.winsum, v.nb);
   else hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
 }

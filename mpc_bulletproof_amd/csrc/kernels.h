@@ -65,7 +65,7 @@ struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* ve
                   int horner_form = 0;   // Horner pass: 0 = by mode, 1 = a lane, 2 = a DPP quad, 3 = a wave (row form, ec29_row.cuh) per proof -- BPGPU_OPT_HORNER_FORM
                   size_t row_max = 1536; // most proofs / groups for which latency mode takes the row form -- BPGPU_OPT_HORNER_ROW_MAX
                   int fixed_lpm = 0;     // lanes per fixed-base MSM in the back launch: 16 / 32 / 64, 0 = by mode -- BPGPU_OPT_FIXED_LPM
-                  int groups_form = 0;   // first Horner stage: 0 = by mode, 1 = a lane, 2 = a quad per group of 8 windows -- BPGPU_OPT_GROUPS_FORM
+                  int groups_form = 0;   // first Horner stage: 0 = by mode, 1 = a lane, 2 = a quad, 3 = a wave per group of 8 windows -- BPGPU_OPT_GROUPS_FORM
 };
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */
                     size_t vs_large_min = 0; /* padded_n / m from which the scalar assembly is split over the grid (0 = 4096) -- BPGPU_OPT_VS_LARGE_MIN */ };

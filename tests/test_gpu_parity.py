@@ -931,11 +931,21 @@ def test_verify_batch_launch_variants(gpu, opts, np_, fuse, wp, c):
     test_range_verify_batch(gpu, 8, 70, c)
 
 
+@pytest.mark.parametrize("horner,groups,lpm", [(1, 1, 16), (2, 2, 32), (3, 3, 64), (3, 1, 0), (2, 3, 0)])
+def test_verify_batch_horner_forms(gpu, opts, horner, groups, lpm):
+    """The Horner pass and its first stage in each of their forms -- a lane, a DPP quad (ec29_quad.cuh), a whole wave with
+    row-distributed field arithmetic (ec29_row.cuh) per proof / per group of 8 windows -- and the lanes per fixed-base MSM of the
+    back launch, selected through the per-context options in the DEFAULT mode (70 proofs, tampered ones among them): accept bits,
+    mega_check points and all MSM scalars equal the oracle's in every combination."""
+    opts(horner_form=horner, groups_form=groups, fixed_lpm=lpm)
+    test_range_verify_batch(gpu, 8, 70, 8)
+
+
 @pytest.mark.parametrize("n_bits,nb,c", [(8, 71, 8), (8, 12, 8), (64, 65, 20)])
 def test_verify_batch_latency_mode(gpu, n_bits, nb, c):
-    """bpgpu_set_latency_mode (the un-pipelined caller's setting: 1 point per table lane, 32 lanes per fixed-base MSM, a DPP
-    quad per (proof, group) in the first Horner stage): same accept bits, mega_check points and MSM scalars as the oracle.
-    An odd batch leaves half a block of quads without a unit in the quad stage."""
+    """bpgpu_set_latency_mode (the un-pipelined caller's setting: 1 point per table lane, the generator half on a side stream with
+    64 lanes per MSM, a whole wave per proof -- row-distributed arithmetic -- in both Horner stages): same accept bits, mega_check
+    points and MSM scalars as the oracle."""
     gpu.set_latency_mode(True)
     try:
         test_range_verify_batch(gpu, n_bits, nb, c)
