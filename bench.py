@@ -906,11 +906,26 @@ def main():
                     assert rc == 0, f"bph_shuffle_verify_param rc={rc}"
                     if rep == 0:
                         build_ms = pms[0]
+                # ... and the prover bound to the same circuit (Prover::use_circuit: the gadget runs for its witness only)
+                ppms = (C.c_double * 3)()
+                pruns = []
+                pproof, pplen, pcom = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))()
+                for rep in range(4):
+                    rc = host.bph_shuffle_prove_param(C.c_size_t(ks), sarr, C.c_uint64(OS_ENTROPY), C.c_size_t(1 << 15), pproof, C.byref(pplen), pcom, ppms)
+                    assert rc == 0, f"bph_shuffle_prove_param rc={rc}"
+                    assert host.bph_shuffle_verify_param(C.c_size_t(ks), pcom, pproof, C.c_size_t(pplen.value), C.c_size_t(1 << 15), C.c_size_t(1), pms) == 0
+                    if rep:
+                        pruns.append(list(ppms))
+                pmed = [sorted(r[i] for r in pruns)[1] for i in range(3)]
                 shuffle = {"workload": f"k-shuffle gadget, k = 2^14: q = {qs} constraints, n = {2 * (ks - 1)} multipliers (phase 2), m = {2 * ks}, padded n = 2^15",
                            "prove": {"value": qs / med[3] * 1e3, "unit": "R1CS constraints/s", "ms": med[3], "best_ms": min(r[3] for r in runs),
                                      "circuit_building_ms": med[2]},
                            "verify": {"value": qs / med[5] * 1e3, "unit": "R1CS constraints/s", "ms": med[5], "best_ms": min(r[5] for r in runs),
                                       "circuit_building_ms": med[4]},
+                           "prove_parametric_circuit": {"value": qs / pmed[2] * 1e3, "unit": "R1CS constraints/s", "ms": pmed[2], "circuit_building_ms": pmed[1],
+                                                        "note": "Prover::prove with the prover bound to the ParametricCircuit (Prover::use_circuit): the gadget runs for its "
+                                                                "witness only, no constraint rows are built, hashed or uploaded (bpgpu_r1cs_prover_session_polys_param); "
+                                                                "every proof verified against the same circuit; median of 3"},
                            "verify_parametric_circuit": {"value": qs / pms[2] * 1e3, "unit": "R1CS constraints/s", "ms": pms[2], "commit_calls_ms": pms[1],
                                                          "circuit_capture_ms_once_per_shape": build_ms,
                                                          "note": "Verifier::verify(proof, gens, ParametricCircuit): the gadget's 65 533 rows cross the ABI once per circuit "

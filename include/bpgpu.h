@@ -324,6 +324,11 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
                              const uint8_t *vector_keys, const uint8_t *blindings, uint8_t *commitments);
 int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
                                     uint8_t *t_coeffs, uint8_t *wV);
+/* The same for a circuit of bpgpu_circuit_create_param (second-phase constraints affine in the gadget challenges, prover.rs:383-402):
+ * gadget_challenges = nb x nchi x 32 bytes, the values the provers' transcripts produced.  The rows of such a circuit cross the ABI
+ * once per circuit shape; a prover of the 2^14-shuffle no longer builds and uploads 65 533 constraint rows per proof. */
+int bpgpu_r1cs_prover_session_polys_param(bpgpu_ctx *ctx, bpgpu_prover *session, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                          const uint8_t *gadget_challenges, uint8_t *t_coeffs, uint8_t *wV);
 /* out[i] = scalars[i] * (curve generator) -- GeneratorsChain::next (generators.rs:112-124),
  * Q = w * B (prover.rs:687), PedersenGens::commit with B = B_blinding (generators.rs:41-43,61-70) */
 int bpgpu_generator_mul(bpgpu_ctx *ctx, const uint8_t *scalars, size_t n, uint8_t *out);

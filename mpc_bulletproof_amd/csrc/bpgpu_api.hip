@@ -2668,10 +2668,22 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
   *session = s;
   return BPGPU_OK;
 }
+static int prover_session_polys_locked(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                       const uint8_t *chi, uint8_t *t_coeffs, uint8_t *wV);
 int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
                                     uint8_t *t_coeffs, uint8_t *wV) {
   if (!ctx || !s || !c || !y || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
   if (c->nchi) return BPGPU_E_ARG;
+  return prover_session_polys_locked(ctx, s, c, y, z, nullptr, t_coeffs, wV);
+}
+int bpgpu_r1cs_prover_session_polys_param(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                          const uint8_t *gadget_challenges, uint8_t *t_coeffs, uint8_t *wV) {
+  if (!ctx || !s || !c || !y || !z || !t_coeffs || (c->m && !wV)) return BPGPU_E_ARG;
+  if (!c->nchi || !gadget_challenges) return BPGPU_E_ARG;
+  return prover_session_polys_locked(ctx, s, c, y, z, gadget_challenges, t_coeffs, wV);
+}
+static int prover_session_polys_locked(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu_circuit *c, const uint8_t *y, const uint8_t *z,
+                                       const uint8_t *chi, uint8_t *t_coeffs, uint8_t *wV) {
   if (c->n != s->wn || s->polys) return BPGPU_E_LEN;     // the circuit's multipliers are the session's; one polynomial build per session
   std::lock_guard<std::mutex> lk(ctx->mu);
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -2683,20 +2695,23 @@ int bpgpu_r1cs_prover_session_polys(bpgpu_ctx *ctx, bpgpu_prover *s, const bpgpu
     return BPGPU_E_OOM;
   }
   s->n = n; s->m = m;
-  void *din, *dzp, *dout;
+  void *din, *dzp, *dout, *dchi = nullptr;
+  const size_t qz = (1 + c->nchi) * (c->q ? c->q : 1);    // a parametric circuit's z-power table carries one block per gadget challenge
   CK(ws_get(ctx, 0, 2 * nb * 32, &din));
-  CK(ws_get(ctx, 6, nb * (c->q ? c->q : 1) * 9 * 4, &dzp));
+  CK(ws_get(ctx, 6, nb * qz * 9 * 4, &dzp));
   CK(ws_get(ctx, 1, (nb * 6 + nb * m) * 32, &dout));
+  if (c->nchi) CK(ws_get(ctx, 21, nb * c->nchi * 32, &dchi));
   Words8 *dz = (Words8 *)din, *dt = (Words8 *)dout, *dwV = dt + nb * 6;
   CK(flag_reset(ctx));
   CK(h2d(ctx, s->y, y, nb * 32));
   CK(h2d(ctx, dz, z, nb * 32));
+  if (c->nchi) { CK(h2d(ctx, dchi, chi, nb * c->nchi * 32)); scalars_check(ctx->st, (const Words8 *)dchi, nb * c->nchi, ctx->d_flag); }
   scalars_check(ctx->st, s->y, nb, ctx->d_flag);
   scalars_check(ctx->st, dz, nb, ctx->d_flag);
   ProfSpan span(ctx, 17, ctx->st);
   HIPCK(ctx, hipMemcpyAsync(s->yinv, s->y, nb * 32, hipMemcpyDeviceToDevice, ctx->st));
   batch_inverse(ctx->st, s->yinv, nb, ctx->d_flag);       // y^-1, prover.rs:593 (a zero challenge raises the flag: E_ARG)
-  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp);
+  zpow_table(ctx->st, nb, c->q, dz, 8, (int32_t *)dzp, c->nchi, (const Words8 *)dchi);
   prover_polys(ctx->st, circuit_dev(c), nb, s->y, s->yinv, s->aL, s->aR, s->aO, s->sL, s->sR, (const int32_t *)dzp, s->polys, dwV);
   prover_tcoeffs(ctx->st, nb, n, s->polys, dt);
   span.close();

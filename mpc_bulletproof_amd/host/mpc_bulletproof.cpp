@@ -1073,6 +1073,11 @@ class CsCore {
   const std::vector<Scalar> *probe_chi = nullptr;
   std::vector<std::string> *probe_labels = nullptr;
   size_t probe_next = 0;
+  // a PROVER bound to a ParametricCircuit (Prover::use_circuit): the gadgets run for their witness only -- constraint rows are not
+  // stored, hashed or uploaded (the circuit holds them) -- and the gadget challenges drawn from the transcript are kept for the device
+  const ParametricCircuit *param = nullptr;
+  std::vector<Scalar> chi_drawn;
+  size_t rows_dropped = 0;
   RowStore constraints;
   // 128-bit running hash of the rows (variables + coefficients, in row order), updated as they are pushed: lock-step provers
   // must share their constraint rows, and comparing 255 x 2064 rows with the first prover's cost every batch as much as
@@ -1098,6 +1103,7 @@ class CsCore {
     rows_hash[1] = rotl(rows_hash[1] + b, 31) * 0xC2B2AE3D27D4EB4FULL;
   }
   void push_row(LinearCombination &&lc) {
+    if (param) { rows_dropped++; return; }
     const uint64_t head[4] = {lc.terms.size(), 0, 0, 0};
     hash_term(0xA5A5A5A500000000ULL, head);
     for (auto &kv : lc.terms) {
@@ -1146,6 +1152,7 @@ class CsCore {
   }
   std::array<Variable, 3> multiply(LinearCombination &&left, LinearCombination &&right) {   // prover.rs:99-125 / verifier.rs:99-120
     auto vars = new_multiplier(eval(left), eval(right));
+    if (param) { rows_dropped += 2; return vars; }      // (the two rows live in the parametric circuit)
     left.add_term(vars[0], kMinusOne);
     right.add_term(vars[1], kMinusOne);
     push_row(std::move(left));
@@ -1309,7 +1316,15 @@ Variable Prover::commit_public(const Scalar &v) { return commit(v, Scalar::one()
 void Prover::constrain(LinearCombination lc) { c_->push_row(std::move(lc)); }
 Scalar Prover::eval(const LinearCombination &lc) const { return c_->eval(lc); }
 void Prover::specify_randomized_constraints(Callback cb) { c_->deferred.push_back(std::move(cb)); }
-Scalar Prover::challenge_scalar(const std::string &label) { return c_->tr.challenge_scalar(label); }
+Scalar Prover::challenge_scalar(const std::string &label) {
+  Scalar x = c_->tr.challenge_scalar(label);
+  if (c_->param) c_->chi_drawn.push_back(x);
+  return x;
+}
+void Prover::use_circuit(const ParametricCircuit &circuit) {
+  if (c_->constraints.size() || c_->a_L.size() || !c_->deferred.empty()) throw std::invalid_argument("Prover::use_circuit: before the gadgets are added");
+  c_->param = &circuit;
+}
 bool Prover::constraints_satisfied() const {
   for (auto &lc : c_->constraints) if (c_->eval(lc) != Scalar::zero()) return false;
   return true;
@@ -1507,17 +1522,31 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   });
   // device: flattened constraints, l/r coefficient vectors, t_1..t_6 -- :587-619 (y^-1, :593, on the device too).  One
   // circuit for all provers: the constraint rows must coincide (their running hashes; BPH_CHECK_ROWS=1: row by row).
-  for (size_t p = 1; p < nb; p++)
-    if (cs[p]->rows_hash[0] != cs[0]->rows_hash[0] || cs[p]->rows_hash[1] != cs[0]->rows_hash[1] || cs[p]->rows_nnz != cs[0]->rows_nnz ||
-        cs[p]->constraints.size() != cs[0]->constraints.size())
-      throw std::invalid_argument("prove_batch: constraint rows differ between provers");
-  if (getenv("BPH_CHECK_ROWS"))
-    parallel_for(nb, [&](size_t p) {
-      if (p && !cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
-    });
+  const ParametricCircuit *param = cs[0]->param;
+  for (size_t p = 1; p < nb; p++) if (cs[p]->param != param) throw std::invalid_argument("prove_batch: provers of different circuits");
+  std::vector<uint8_t> chi_bytes;
+  if (param) {
+    // the provers were bound to a ParametricCircuit: its device circuit serves all of them; what must agree is the shape the
+    // gadgets produced (multipliers per phase, commitments, rows, challenges drawn) and the circuit's
+    const size_t nchi = param->challenge_labels().size();
+    for (size_t p = 0; p < nb; p++)
+      if (n != param->n() || n1 != param->n1() || m != param->m() || cs[p]->chi_drawn.size() != nchi || cs[p]->rows_dropped != param->num_constraints())
+        throw std::invalid_argument("prove_batch: the gadgets built on a prover do not match its ParametricCircuit");
+    chi_bytes.resize(nb * nchi * 32);
+    for (size_t p = 0; p < nb; p++) for (size_t j = 0; j < nchi; j++) cs[p]->chi_drawn[j].to_bytes_le(&chi_bytes[(p * nchi + j) * 32]);
+  } else {
+    for (size_t p = 1; p < nb; p++)
+      if (cs[p]->rows_hash[0] != cs[0]->rows_hash[0] || cs[p]->rows_hash[1] != cs[0]->rows_hash[1] || cs[p]->rows_nnz != cs[0]->rows_nnz ||
+          cs[p]->constraints.size() != cs[0]->constraints.size())
+        throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+    if (getenv("BPH_CHECK_ROWS"))
+      parallel_for(nb, [&](size_t p) {
+        if (p && !cs[p]->same_rows(*cs[0])) throw std::invalid_argument("prove_batch: constraint rows differ between provers");
+      });
+  }
   lap("prove: transcript y z, rows");
-  bpgpu_circuit *circ = circuit_cache().acquire(*cs[0], n, m);
-  struct CircuitGuard { bpgpu_circuit *c; ~CircuitGuard() { circuit_cache().release(c); } } circuit_guard{circ};
+  bpgpu_circuit *circ = param ? param->device_circuit() : circuit_cache().acquire(*cs[0], n, m);
+  struct CircuitGuard { bpgpu_circuit *c; ~CircuitGuard() { if (c) circuit_cache().release(c); } } circuit_guard{param ? nullptr : circ};
   lap("prove: circuit");
   if (!ps) {   // a circuit without multipliers in either phase cannot happen after the phase-1 call; kept for clarity
     throw std::logic_error("prove_batch: no prover session");
@@ -1525,8 +1554,10 @@ std::vector<R1CSProof> Prover::prove_batch(std::vector<Prover *> &provers, const
   std::vector<uint8_t> tco(nb * 6 * 32), wVb(nb * m * 32 + 1);
   {
     auto by = pack_scalars(y), bz = pack_scalars(z);
-    d.check(bpgpu_r1cs_prover_session_polys(d.ctx(), ps, circ, by.data(), bz.data(), tco.data(), wVb.data()),
-            "bpgpu_r1cs_prover_session_polys");
+    if (param) d.check(bpgpu_r1cs_prover_session_polys_param(d.ctx(), ps, circ, by.data(), bz.data(), chi_bytes.data(), tco.data(), wVb.data()),
+                       "bpgpu_r1cs_prover_session_polys_param");
+    else d.check(bpgpu_r1cs_prover_session_polys(d.ctx(), ps, circ, by.data(), bz.data(), tco.data(), wVb.data()),
+                 "bpgpu_r1cs_prover_session_polys");
   }
   lap("prove: prover_polys");
   auto t = unpack_scalars(tco.data(), nb * 6);   // per prover: t1 t2 t3 t4 t5 t6

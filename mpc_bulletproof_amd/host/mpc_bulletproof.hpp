@@ -403,6 +403,11 @@ class Prover : public RandomizedConstraintSystem {
   std::pair<StarkPoint, Variable> commit(const Scalar &v, const Scalar &v_blinding);   // :319-329
   // same, with the commitment V = commit(v, v_blinding) already computed (PedersenGens::commit_batch)
   Variable commit_precomputed(const Scalar &v, const Scalar &v_blinding, const StarkPoint &V);
+  // Bind this prover to a ParametricCircuit (before any gadget is added): the gadgets then run for their WITNESS only -- constraint
+  // rows are neither stored, hashed nor uploaded, the circuit's device copy serves the proof (bpgpu_r1cs_prover_session_polys_param
+  // with the gadget challenges this prover's transcript produced).  prove() checks that the gadgets produced the circuit's shape.
+  // The proof is byte for byte the one the unbound prover makes.
+  void use_circuit(const ParametricCircuit &circuit);
   R1CSProof prove(const BulletproofGens &bp_gens);                 // :412-727, blinding factors from a fresh OsRng
   R1CSProof prove(const BulletproofGens &bp_gens, Rng &rng);       // the same with the randomness injected (tests: SeededRng)
   // the same for nb provers of one circuit in lock-step (every device call batched over the provers).  `device`: the context

@@ -427,6 +427,58 @@ int bph_shuffle_prove_verify(size_t k, const uint64_t *values, uint64_t seed, si
   })
 }
 
+static ParametricCircuit *shuffle_param_circuit(size_t k, double *build_ms) {
+  static std::mutex mu;
+  static std::map<size_t, std::unique_ptr<ParametricCircuit>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto &slot = cache[k];
+  if (build_ms) *build_ms = 0;
+  if (!slot) {
+    auto t0 = std::chrono::steady_clock::now();
+    slot.reset(new ParametricCircuit(2 * k, [k](Verifier &v, const std::vector<Variable> &vars) {
+      gadgets::shuffle_gadget(v, std::vector<Variable>(vars.begin(), vars.begin() + k), std::vector<Variable>(vars.begin() + k, vars.end()));
+    }));
+    if (build_ms) *build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  }
+  return slot.get();
+}
+// Prover::prove of the k-shuffle with the prover BOUND to the ParametricCircuit (Prover::use_circuit: the gadget runs for its witness
+// only, no constraint rows are built or uploaded).  Same inputs and outputs as bph_shuffle_prove_verify's prover half; ms_out[0] =
+// the commitments (one device call), [1] = gadget / circuit building (commit calls + witness), [2] = Prover::prove.
+int bph_shuffle_prove_param(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, uint8_t *proof_out, size_t *proof_len,
+                            uint8_t *commitments_out, double ms_out[3]) {
+  GUARD({
+    const char *label = "ShuffleProofTest";
+    PedersenGens pc_gens;
+    const BulletproofGens &bp_gens = cached_gens(gens_capacity);
+    ParametricCircuit *pc = shuffle_param_circuit(k, nullptr);
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::unique_ptr<Rng> rng_owner = make_rng(seed);
+    Rng &rng = *rng_owner;
+    auto t0 = now();
+    std::vector<Scalar> vs, bls;
+    for (size_t i = 0; i < 2 * k; i++) { vs.push_back(Scalar::from(values[i])); bls.push_back(rng.scalar()); }
+    auto Vs = pc_gens.commit_batch(bp_gens, vs, bls);
+    auto t1 = now();
+    Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
+    Prover prover(pc_gens, transcript);
+    prover.use_circuit(*pc);
+    std::vector<Variable> vars;
+    for (size_t i = 0; i < 2 * k; i++) vars.push_back(prover.commit_precomputed(vs[i], bls[i], Vs[i]));
+    gadgets::shuffle_gadget(prover, std::vector<Variable>(vars.begin(), vars.begin() + k), std::vector<Variable>(vars.begin() + k, vars.end()));
+    auto t2 = now();
+    R1CSProof proof = prover.prove(bp_gens, rng);
+    auto t3 = now();
+    ms_out[0] = ms(t0, t1); ms_out[1] = ms(t1, t2); ms_out[2] = ms(t2, t3);
+    auto bytes = proof.to_flat_bytes();
+    memcpy(proof_out, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    for (size_t i = 0; i < 2 * k; i++) memcpy(commitments_out + 64 * i, Vs[i].xy.data(), 64);
+    return 0;
+  })
+}
+
 // Verifier::verify of a k-shuffle proof against a ParametricCircuit (host mirror: one device circuit per shape, cached here per k):
 // reps verifications of the same proof; ms_out[0] = building the circuit (0 when it was cached), [1] = the commit calls of one
 // verification (the transcript's dependent hash chain), [2] = median of Verifier::verify(proof, gens, circuit).
@@ -437,24 +489,10 @@ int bph_shuffle_verify_param(size_t k, const uint8_t *commitments, const uint8_t
     const char *label = "ShuffleProofTest";
     PedersenGens pc_gens;
     const BulletproofGens &bp_gens = cached_gens(gens_capacity);
-    static std::mutex mu;
-    static std::map<size_t, std::unique_ptr<ParametricCircuit>> cache;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     ms_out[0] = ms_out[1] = ms_out[2] = 0;
-    ParametricCircuit *pc;
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      auto &slot = cache[k];
-      if (!slot) {
-        auto t0 = now();
-        slot.reset(new ParametricCircuit(2 * k, [k](Verifier &v, const std::vector<Variable> &vars) {
-          gadgets::shuffle_gadget(v, std::vector<Variable>(vars.begin(), vars.begin() + k), std::vector<Variable>(vars.begin() + k, vars.end()));
-        }));
-        ms_out[0] = ms(t0, now());
-      }
-      pc = slot.get();
-    }
+    ParametricCircuit *pc = shuffle_param_circuit(k, &ms_out[0]);
     R1CSProof proof = R1CSProof::from_flat_bytes(std::vector<uint8_t>(proof_bytes, proof_bytes + proof_len));
     std::vector<StarkPoint> Vs(2 * k);
     for (size_t i = 0; i < 2 * k; i++) memcpy(Vs[i].xy.data(), commitments + 64 * i, 64);

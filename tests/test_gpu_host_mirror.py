@@ -390,6 +390,12 @@ def test_shuffle_verified_against_a_parametric_circuit(host, lgk):
     rc, proof, com = prove(xs + ys)
     assert rc == 0
     assert verify_param(proof, com) == 0
+    # the PROVER bound to the same circuit (Prover::use_circuit: gadget run for its witness only, no rows built or uploaded;
+    # bpgpu_r1cs_prover_session_polys_param): byte for byte the ordinary prover's proof under the same seeded randomness
+    arr = (C.c_uint64 * (2 * k))(*(xs + ys))
+    proof2, plen2, com2 = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * k * 64))()
+    assert host.bph_shuffle_prove_param(C.c_size_t(k), arr, C.c_uint64(777 + lgk), C.c_size_t(cap), proof2, C.byref(plen2), com2, ms3) == 0
+    assert bytes(proof2)[:plen2.value] == proof and bytes(com2) == com
     if k > 1:
         ys_bad = list(ys)
         ys_bad[0] ^= 1
