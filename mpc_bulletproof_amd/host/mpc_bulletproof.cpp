@@ -1945,6 +1945,24 @@ ParametricCircuit::ParametricCircuit(size_t m, const std::function<void(Verifier
 }
 ParametricCircuit::~ParametricCircuit() { if (circ_) bpgpu_circuit_destroy(Device::default_device().ctx(), circ_); }
 
+void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit, RankGroup &group, Device *device) {
+  if (group.size() <= 1) { verify(proof, bp_gens, circuit); return; }
+  CsCore &c = *c_;
+  std::vector<uint8_t> chi;
+  BatchInputs in = replay(proof, bp_gens, &circuit, &chi);
+  Device &d = same_gpu(device);
+  bpgpu_gens *gens = bp_gens.device_tables(c.pc_gens);
+  uint8_t part[64];
+  int rc = bpgpu_r1cs_verify_shard(d.ctx(), gens, circuit.device_circuit(), in.n1, in.k, in.points.data(), in.scalars.data(), in.challenges.data(),
+                                   chi.data(), group.rank(), group.size(), part);
+  if (rc == BPGPU_E_GENS) throw R1CSException(R1CSError::InvalidGeneratorsLength);
+  d.check(rc, "bpgpu_r1cs_verify_shard");
+  const int rc2 = combine_partials_rc(d, group, part, 1);      // (a malformed operand: the poison partial fails every rank together)
+  if (rc2 == BPGPU_E_ARG) throw R1CSException(R1CSError::FormatError);
+  d.check(rc2, "bpgpu_points_sum");
+  memcpy(c.mega.xy.data(), part, 64);
+  if (!c.mega.is_identity()) throw R1CSException(R1CSError::VerificationError);
+}
 void Verifier::verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit) {
   CsCore &c = *c_;
   Lap lap;

@@ -448,6 +448,7 @@ class Verifier : public RandomizedConstraintSystem {
   // add the gadgets -- the replay draws the gadget challenges under the circuit's labels, right after the phase separator, as the
   // gadgets' own closures would (verifier.rs:366-385), and the device takes the weights c0 + sum_j chi_j c_j.  Same verdicts.
   void verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit);
+  void verify(const R1CSProof &proof, const BulletproofGens &bp_gens, const ParametricCircuit &circuit, RankGroup &group, Device *device = nullptr);
   // The host half of verify(): the transcript replay (verifier.rs:398-455,506; inner_product_proof.rs:259-278) and
   // the operand layout of bpgpu_r1cs_verify_batch -- what a service that batches many proofs of one circuit
   // collects per proof.  Throws like verify() on identity points / bad lengths.

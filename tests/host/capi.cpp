@@ -527,10 +527,25 @@ struct CallbackGroup final : RankGroup {
   void all_gather(const uint8_t *mine, size_t bytes, uint8_t *out) override { fn(mine, bytes, out, user); }
 };
 }  // namespace
+static int shuffle_sharded(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, size_t rank, size_t world,
+                           bph_allgather_fn allgather, void *user, uint8_t *proof_out, size_t *proof_len,
+                           uint8_t *commitments_out, double ms[6], bool param);
 int bph_shuffle_prove_verify_sharded(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, size_t rank, size_t world,
                                      bph_allgather_fn allgather, void *user, uint8_t *proof_out, size_t *proof_len,
                                      uint8_t *commitments_out, double ms[6]) {
+  return shuffle_sharded(k, values, seed, gens_capacity, rank, world, allgather, user, proof_out, proof_len, commitments_out, ms, false);
+}
+// the same with prover and verifier bound to the shuffle's ParametricCircuit (every rank holds its own device copy)
+int bph_shuffle_prove_verify_sharded_param(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, size_t rank, size_t world,
+                                           bph_allgather_fn allgather, void *user, uint8_t *proof_out, size_t *proof_len,
+                                           uint8_t *commitments_out, double ms[6]) {
+  return shuffle_sharded(k, values, seed, gens_capacity, rank, world, allgather, user, proof_out, proof_len, commitments_out, ms, true);
+}
+static int shuffle_sharded(size_t k, const uint64_t *values, uint64_t seed, size_t gens_capacity, size_t rank, size_t world,
+                           bph_allgather_fn allgather, void *user, uint8_t *proof_out, size_t *proof_len,
+                           uint8_t *commitments_out, double ms[6], bool param) {
   GUARD({
+    ParametricCircuit *pc = param ? shuffle_param_circuit(k, nullptr) : nullptr;
     if (!world || rank >= world || !allgather) return -3;
     auto T0 = std::chrono::steady_clock::now();
     int li = 0;
@@ -564,6 +579,7 @@ int bph_shuffle_prove_verify_sharded(size_t k, const uint64_t *values, uint64_t 
     {
       Transcript transcript = start_transcript(K_SHUFFLE, k, (const uint8_t *)label, strlen(label));
       Prover prover(pc_gens, transcript);
+      if (pc) prover.use_circuit(*pc);
       std::vector<Variable> vars;
       for (size_t i = 0; i < 2 * k; i++) vars.push_back(prover.commit_precomputed(vs[i], bls[i], Vs[i]));
       gadgets::shuffle_gadget(prover, std::vector<Variable>(vars.begin(), vars.begin() + k),
@@ -580,10 +596,10 @@ int bph_shuffle_prove_verify_sharded(size_t k, const uint64_t *values, uint64_t 
     Verifier verifier(pc_gens, transcript);
     std::vector<Variable> vars;
     for (size_t i = 0; i < 2 * k; i++) vars.push_back(verifier.commit(Vs[i]));
-    gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + k),
-                            std::vector<Variable>(vars.begin() + k, vars.end()));
+    if (!pc) gadgets::shuffle_gadget(verifier, std::vector<Variable>(vars.begin(), vars.begin() + k),
+                                     std::vector<Variable>(vars.begin() + k, vars.end()));
     lap();
-    verifier.verify(proof, bp_gens, group);
+    if (pc) verifier.verify(proof, bp_gens, *pc, group); else verifier.verify(proof, bp_gens, group);
     lap();
     return 0;
   })

@@ -94,7 +94,14 @@ def main():
                 p2, l2, c2, m2 = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
                 rc_bad = host.bph_shuffle_prove_verify_sharded(C.c_size_t(ks), arr_bad, C.c_uint64(4242 + lg), C.c_size_t(cap), C.c_size_t(rank),
                                                                C.c_size_t(world), cb, None, p2, C.byref(l2), c2, m2)
-                shuffle[str(lg)] = {"rc": rc, "rc_bad": rc_bad, "proof": bytes(proof)[:plen.value].hex(), "prove_ms": ms[3], "verify_ms": ms[5]}
+                # the same with prover and verifier bound to the shuffle's ParametricCircuit: same proof bytes, same verdicts
+                p3, l3, c3, m3 = (C.c_uint8 * 8192)(), C.c_size_t(0), (C.c_uint8 * (2 * ks * 64))(), (C.c_double * 6)()
+                rc_p = host.bph_shuffle_prove_verify_sharded_param(C.c_size_t(ks), arr, C.c_uint64(4242 + lg), C.c_size_t(cap), C.c_size_t(rank),
+                                                                   C.c_size_t(world), cb, None, p3, C.byref(l3), c3, m3) if ks > 1 else 0
+                rc_p_bad = host.bph_shuffle_prove_verify_sharded_param(C.c_size_t(ks), arr_bad, C.c_uint64(4242 + lg), C.c_size_t(cap), C.c_size_t(rank),
+                                                                       C.c_size_t(world), cb, None, p2, C.byref(l2), c2, m2) if ks > 1 else rc_bad
+                shuffle[str(lg)] = {"rc": rc, "rc_bad": rc_bad, "proof": bytes(proof)[:plen.value].hex(), "prove_ms": ms[3], "verify_ms": ms[5],
+                                    "rc_param": rc_p, "rc_param_bad": rc_p_bad, "proof_param": (bytes(p3)[:l3.value].hex() if ks > 1 else bytes(proof)[:plen.value].hex())}
         with open(f"{out_prefix}.{rank}", "w") as f:
             json.dump({"big_host": big_host.hex(), "big_dev": big_dev.hex(), "ok": full_ok, "comb": comb.hex(), "tmax": tmax,
                        "lo": lo, "hi": hi, "ipp": ipp, "shuffle": shuffle}, f)

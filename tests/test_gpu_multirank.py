@@ -116,6 +116,8 @@ def test_one_proof_sharded_over_two_ranks_full_size(tmp_path):
         for r in res:
             s = r["shuffle"][str(lg)]
             assert s["rc"] == 0 and s["rc_bad"] != 0 and s["proof"] == single, (lg, s["rc"], s["rc_bad"])
+            # ... and with every rank's prover / verifier bound to the gadget's ParametricCircuit: the same bytes and verdicts
+            assert s["rc_param"] == 0 and s["rc_param_bad"] == s["rc_bad"] and s["proof_param"] == single, (lg, s["rc_param"], s["rc_param_bad"])
 
 
 def test_points_sum(gpu_ctx):

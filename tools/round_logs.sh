@@ -18,4 +18,4 @@ python3 tools/prof_combined.py $WL.1024 20 > gpurun_out/logs_combined_bursts.log
 # control flow of the multi-rank bench on this ONE-GPU box (two ranks share device 0 over gloo; not a measurement): the weak-scaling
 # verification legs, the combined check's all-gather and the sharded 2^14-shuffle leg
 BPGPU_BENCH_REHEARSAL=1 timeout -k 10 600 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 \
-  bench.py --gpus 2 --steps 6 --warmup 2 --window-bits 16 > gpurun_out/logs_rehearsal2.json 2> gpurun_out/logs_rehearsal2.err
+  bench.py --gpus 2 --steps 6 --warmup 2 --window-bits 16 --inflight 3 --distinct-batches 24 > gpurun_out/logs_rehearsal2.json 2> gpurun_out/logs_rehearsal2.err
