@@ -106,6 +106,8 @@ struct bpgpu_ipp {
   AffDev *mpts = nullptr;                                          // nb x 2 x (n0 + 1): contiguous MSM operands
   Words8 *msc = nullptr;                                           //   (bucket-method rounds)
   Words8 *out_xy = nullptr;                                        // nb x 2 points
+  const JacRaw *tail_partials = nullptr;                           // the last round MSM's chunk partials, when the fused round tail sums them
+  size_t tail_chunks = 0;
   int cur = 0;                                                     // index of the live a/b/G/H buffers
   bpgpu_gens *own_gens = nullptr;                                  // tables built for this session only (bpgpu_ipp_begin, one proof)
   const bpgpu_gens *gens = nullptr;                                // resident-generator mode: no G/H buffers,
@@ -2219,9 +2221,13 @@ static int ipp_round_dev(bpgpu_ctx *ctx, bpgpu_ipp *s, Words8 *out_xy) {
       void *dpart = nullptr;
       if (chunks > 1) CK(ws_get(ctx, 12, nb * 2 * chunks * sizeof(JacRaw), &dpart));
       ProfScope ps(ctx, 21, st);
-      fixed_msm_ipp(st, s->gens->c, s->gens->table, s->n0, s->gens->cap, n, (const uint32_t *)s->msc, s->sums, nb * 2, (JacRaw *)dpart);
+      // (out_xy == nullptr: the caller's fused round tail sums the chunk partials and converts the points itself)
+      const bool tail_sums = !out_xy && chunks > 1 && chunks <= 256;
+      fixed_msm_ipp(st, s->gens->c, s->gens->table, s->n0, s->gens->cap, n, (const uint32_t *)s->msc, s->sums, nb * 2, (JacRaw *)dpart, !tail_sums);
+      s->tail_partials = tail_sums ? (const JacRaw *)dpart : nullptr;
+      s->tail_chunks = tail_sums ? chunks : 0;
     }
-    if (out_xy) jac_to_boundary(st, s->sums, out_xy, nb * 2);      // (nullptr: the caller's fused round tail converts s->sums itself)
+    if (out_xy) jac_to_boundary(st, s->sums, out_xy, nb * 2);
     return launch_ok(ctx);
   }
   const AffDev *G = s->G[s->cur], *H = s->H[s->cur];
@@ -2371,7 +2377,7 @@ int bpgpu_ipp_run_fs(bpgpu_ctx *ctx, bpgpu_ipp *s, const uint8_t *states_in, uin
     Words8 *lr = (Words8 *)dlr + r * nb * 4;             // 2 points x 2 Words8 per proof
     if (s->gens) {   // resident generators: point conversion, the three transcript steps and u^-1 in ONE launch (k_ipp_round_tail)
       CK(ipp_round_dev(ctx, s, nullptr));
-      ipp_round_tail(ctx->st, nb, s->sums, (uint64_t *)dstates, lr, du, dui);
+      ipp_round_tail(ctx->st, nb, s->sums, (uint64_t *)dstates, lr, du, dui, s->tail_partials, s->tail_chunks);
     } else {
       CK(ipp_round_dev(ctx, s, lr));
       ipp_round_challenge(ctx->st, nb, (uint64_t *)dstates, lr, du);

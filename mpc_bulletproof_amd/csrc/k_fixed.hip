@@ -326,7 +326,7 @@ static void launch_fixed_ipp(hipStream_t st, const AffDev *table, size_t n0, siz
 }
 // partials: nmsm * fixed_msm_ipp_chunks(c, n0, nmsm) points (unused when that is 1)
 void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
-                   JacRaw *out, size_t nmsm, JacRaw *partials) {
+                   JacRaw *out, size_t nmsm, JacRaw *partials, bool sum_partials) {
   if (!nmsm) return;
   size_t chunks = partials ? fixed_msm_ipp_chunks(c, n0, nmsm) : 1;
   JacRaw *dst = chunks > 1 ? partials : out;
@@ -340,7 +340,7 @@ void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t
     case 20: launch_fixed_ipp<20>(st, table, n0, cap, cur, scalars, dst, nmsm, chunks); break;
     default: return;
   }
-  if (chunks > 1) segmented_sum(st, partials, out, nmsm, chunks);
+  if (chunks > 1 && sum_partials) segmented_sum(st, partials, out, nmsm, chunks);
 }
 
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane

@@ -411,15 +411,45 @@ __device__ __forceinline__ uint64_t coop_keccak_f(uint64_t a, const CoopK &k) {
 //   lane 0: u = hash_to_scalar, u^-1.
 // sums: nb x 2 points; lr_xy out: nb x 2 x 64 B; states: 4 x u64 per prover, updated; u_out, uinv_out: nb x 32 B.
 __global__ void __launch_bounds__(64) k_ipp_round_tail(size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out,
-                                                       Words8 *uinv_out) {
+                                                       Words8 *uinv_out, const JacRaw *partials, size_t chunks) {
   __shared__ uint64_t sh[2][24];          // per half: [0..3] chain state, [4..11] L x || y, [12..19] R x || y, [20..23] scratch (challenge low)
   __builtin_amdgcn_s_setprio(3);
   const int half = threadIdx.x >> 5, l = threadIdx.x & 31, base = half * 32;
   const size_t p = (size_t)blockIdx.x * 2 + half;
   const bool live = p < nb;
   uint64_t *S = sh[half];
+  // chunks > 1: the round's MSMs left `chunks` partial sums per point (k_fixed_msm_ipp_g): lanes 0..15 add up L's, lanes 16..31 R's
+  // (a strided pass and a 4-level shuffle butterfly) -- the separate block-sum launch and its wait are gone
+  Jac tot = jac_inf();
+  if (chunks > 1) {
+    const int side = l >> 4, ll = l & 15;
+    const size_t pp = live ? p : 0;
+    const JacRaw *src = partials + (2 * pp + side) * chunks;
+#pragma unroll 1
+    for (size_t i = ll; i < chunks; i += 16) tot = jac_add(tot, raw_load(&src[i]));
+#pragma unroll 1
+    for (int off = 8; off > 0; off >>= 1) {
+      Jac o;
+#pragma unroll
+      for (int t = 0; t < NL; t++) {
+        o.X.v[t] = __shfl_xor(tot.X.v[t], off, 64);
+        o.Y.v[t] = __shfl_xor(tot.Y.v[t], off, 64);
+        o.Z.v[t] = __shfl_xor(tot.Z.v[t], off, 64);
+      }
+      tot = jac_add(tot, o);
+    }
+    // lane 1 converts R: it takes lane 16's total
+    Jac r16;
+#pragma unroll
+    for (int t = 0; t < NL; t++) {
+      r16.X.v[t] = __shfl(tot.X.v[t], base + 16, 64);
+      r16.Y.v[t] = __shfl(tot.Y.v[t], base + 16, 64);
+      r16.Z.v[t] = __shfl(tot.Z.v[t], base + 16, 64);
+    }
+    if (l == 1) tot = r16;
+  }
   if (live && l < 2) {                     // L (lane 0) and R (lane 1) to canonical affine bytes
-    Jac q = raw_load(&sums[2 * p + l]);
+    Jac q = chunks > 1 ? tot : raw_load(&sums[2 * p + l]);
     if (!jac_is_inf(q) && is_zero_exact(q.Z)) q = jac_inf();
     uint32_t w[16];
     aff_to_boundary(w, jac_to_aff(q));
@@ -482,9 +512,10 @@ __global__ void __launch_bounds__(64) k_ipp_round_tail(size_t nb, const JacRaw *
     for (int j = 0; j < 4; j++) states[p * 4 + j] = S[j];
   }
 }
-void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out) {
+void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out,
+                    const JacRaw *partials, size_t chunks) {
   if (!nb) return;
-  hipLaunchKernelGGL(k_ipp_round_tail, dim3((nb + 1) / 2), dim3(64), 0, st, nb, sums, states, lr_xy, u_out, uinv_out);
+  hipLaunchKernelGGL(k_ipp_round_tail, dim3((nb + 1) / 2), dim3(64), 0, st, nb, sums, states, lr_xy, u_out, uinv_out, partials, chunks);
 }
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr, Words8 *u_out) {
   if (!nb) return;

@@ -131,7 +131,7 @@ void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars
 // L / R MSMs of an IPP round over resident generators, compact scalars (k_ipp_gens_scalars)
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm);
 void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
-                   JacRaw *out, size_t nmsm, JacRaw *partials);
+                   JacRaw *out, size_t nmsm, JacRaw *partials, bool sum_partials = true /* false: the caller sums the nmsm x chunks partials itself (k_ipp_round_tail) */);
 size_t fixed_msm_chunks(int c, size_t n, size_t nb);
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
                size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials, int lpm = 0 /* lanes per small MSM: 32 = shorter lanes for a launch that is a link of a lone chain; 0 = by batch size */);
@@ -284,7 +284,7 @@ void shard_mask(hipStream_t st, Words8 *fixed, size_t np, size_t slo, size_t shi
 void ipp_round_challenge(hipStream_t st, size_t nb, uint64_t *states, const Words8 *lr_xy, Words8 *u_out);
 // the whole tail of a round in one launch: L, R (Jacobian sums, nb x 2) -> boundary bytes, the three transcript steps on a
 // wave-cooperative Keccak, u and u^-1
-void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out);
+void ipp_round_tail(hipStream_t st, size_t nb, const JacRaw *sums, uint64_t *states, Words8 *lr_xy, Words8 *u_out, Words8 *uinv_out, const JacRaw *partials = nullptr, size_t chunks = 0 /* > 1: sums[2p + s] = sum of partials[(2p + s) * chunks + i], added up here */);
 
 // ---- wire codec of points (k_codec.hip): 32-byte compressed <-> 64-byte affine boundary form ------
 size_t sqrt_table_bytes();
