@@ -201,6 +201,18 @@ static int d2h(bpgpu_ctx *ctx, void *h, const void *d, size_t n) {
   return BPGPU_OK;
 }
 static int launch_ok(bpgpu_ctx *ctx) { HIPCK(ctx, hipGetLastError()); return BPGPU_OK; }
+// One launch that brings a batch's three operand arrays from page-locked host memory into the lane's buffers: wide, coalesced reads
+// over the bus by 256 waves (no DMA command, no cross-engine dependency), so that the chain's latency-bound kernels -- the table
+// lanes, the scalar assembly -- read HBM, not the bus.  Sizes in 16-byte words.
+__global__ void __launch_bounds__(256) k_fetch3(const uint4 *s0, uint4 *d0, size_t n0, const uint4 *s1, uint4 *d1, size_t n1,
+                                                const uint4 *s2, uint4 *d2, size_t n2) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n0 + n1 + n2; i += stride) {
+    if (i < n0) d0[i] = s0[i];
+    else if (i < n0 + n1) d1[i - n0] = s1[i - n0];
+    else d2[i - n0 - n1] = s2[i - n0 - n1];
+  }
+}
 // the device-side address of a page-locked (device-mapped) host allocation, or nullptr for pageable / unknown memory
 static const void *host_device_alias(const void *h) {
   hipPointerAttribute_t a{};
@@ -1532,7 +1544,9 @@ static int stream_lanes(bpgpu_ctx *ctx, size_t want) {
   return BPGPU_OK;
 }
 static int verify_stream_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
-                                const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, uint8_t *ok, bool on_host) {
+                                const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, uint8_t *ok, int on_host) {
+  // on_host: 0 = operands and verdicts resident; 1 = pageable host memory (staged copies on the lane's stream); 2 = device-mapped
+  // page-locked host memory (one fetch launch per batch, verdicts written in place)
   if (k >= 32) return BPGPU_E_LEN;
   if (!nb) return BPGPU_OK;
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -1548,7 +1562,14 @@ static int verify_stream_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu
     const size_t lo = ci * batch, cnt = nb - lo < batch ? nb - lo : batch;
     const uint8_t *P = points + lo * nvar * 64, *S = scalars + lo * 5 * 32, *Cc = challenges + lo * nch * 32;
     uint8_t *O = ok + lo * 4;
-    if (on_host) {       // operands and verdicts in (ideally page-locked) host memory: staged through the lane's own buffers
+    if (on_host == 2) {
+      void *dP, *dS, *dC;
+      if (!(rc = ws_get(ln, 0, batch * nvar * 64, &dP)) && !(rc = ws_get(ln, 1, batch * 5 * 32, &dS)) && !(rc = ws_get(ln, 2, batch * nch * 32, &dC))) {
+        hipLaunchKernelGGL(k_fetch3, dim3(64), dim3(256), 0, ln->st, (const uint4 *)P, (uint4 *)dP, cnt * nvar * 4, (const uint4 *)S, (uint4 *)dS, cnt * 10,
+                           (const uint4 *)Cc, (uint4 *)dC, cnt * nch * 2);
+        rc = verify_batch_dev_locked(ln, g, c, cnt, n1, k, dP, dS, dC, O, nullptr, nullptr);
+      }
+    } else if (on_host) {       // operands and verdicts in pageable host memory: staged through the lane's own buffers
       void *dP, *dS, *dC, *dok;
       (void)((rc = ws_get(ln, 0, batch * nvar * 64, &dP)) || (rc = ws_get(ln, 1, batch * 5 * 32, &dS)) ||
              (rc = ws_get(ln, 2, batch * nch * 32, &dC)) || (rc = ws_get(ln, 3, batch * 4, &dok)) ||
@@ -1573,7 +1594,7 @@ int bpgpu_r1cs_verify_stream_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgp
   if (c->nchi) return BPGPU_E_ARG;
   std::lock_guard<std::mutex> lk(ctx->mu);
   return verify_stream_locked(ctx, g, c, nb, n1, k, (const uint8_t *)points_dev, (const uint8_t *)scalars_dev,
-                              (const uint8_t *)challenges_dev, (uint8_t *)ok_dev, false);
+                              (const uint8_t *)challenges_dev, (uint8_t *)ok_dev, 0);
 }
 int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_circuit *c, size_t nb, size_t n1, size_t k,
                              const uint8_t *points, const uint8_t *scalars, const uint8_t *challenges, int32_t *ok) {
@@ -1589,17 +1610,19 @@ int bpgpu_r1cs_verify_stream(bpgpu_ctx *ctx, const bpgpu_gens *g, const bpgpu_ci
     HIPCK(ctx, hipHostMalloc(&ctx->pinned, nb * 4 + nb, hipHostMallocDefault));
     ctx->pinned_cap = nb * 4 + nb;
   }
-  // Operands in PAGE-LOCKED host memory (bpgpu_host_alloc, hipHostMalloc, hipHostRegister) are read by the kernels in place, over
-  // the bus: 2 080 bytes per proof, each read once or twice -- 8 GB/s at 4 M proofs/s --, and the verdicts are written straight
-  // into the page-locked staging.  No copy command is enqueued at all: the per-batch H2D / D2H copies on 20 lanes (four DMA
-  // commands and as many cross-engine dependencies per 1024 proofs) held the host-memory stream at 2-3 M/s against 4.1 resident.
+  // Operands in PAGE-LOCKED host memory (bpgpu_host_alloc, hipHostMalloc, hipHostRegister) are fetched by ONE kernel launch per batch
+  // on its lane (k_fetch3: wide coalesced reads over the bus -- 2 080 bytes per proof, 8 GB/s at 4 M proofs/s) and the verdicts are
+  // written straight into the page-locked staging.  No copy command is enqueued at all: the per-batch H2D / D2H copies on 20 lanes
+  // (four DMA commands and as many cross-engine dependencies per 1024 proofs) held the host-memory stream at 2-3 M/s against 4.1
+  // resident; reading the operands in place from the chain's own kernels put bus latency on its latency-bound links (3.4 M/s).
   // Pageable operands take the staged copies on each lane's stream.
   const void *dpts = host_device_alias(points), *dsc = host_device_alias(scalars), *dch = host_device_alias(challenges);
   const void *dok = host_device_alias(ctx->pinned);
   if (dpts && dsc && dch && dok)
-    CK(verify_stream_locked(ctx, g, c, nb, n1, k, (const uint8_t *)dpts, (const uint8_t *)dsc, (const uint8_t *)dch, (uint8_t *)dok, false));
+    CK(verify_stream_locked(ctx, g, c, nb, n1, k, (const uint8_t *)dpts, (const uint8_t *)dsc, (const uint8_t *)dch, (uint8_t *)dok,
+                            (((uintptr_t)dpts | (uintptr_t)dsc | (uintptr_t)dch) & 15) ? 0 : 2));   // (16-byte words; unaligned buffers are read in place)
   else
-    CK(verify_stream_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, (uint8_t *)ctx->pinned, true));
+    CK(verify_stream_locked(ctx, g, c, nb, n1, k, points, scalars, challenges, (uint8_t *)ctx->pinned, 1));
   HIPCK(ctx, hipStreamSynchronize(ctx->st));
   memcpy(ok, ctx->pinned, nb * 4);
   return BPGPU_OK;
