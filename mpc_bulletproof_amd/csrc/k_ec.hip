@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(64) k_verify_windows(const AffRaw *tab, const 
 // Horner over the 64 window sums in two stages.  Stage 1, one lane per (proof, group of 8 windows):
 // T_g = sum_{i<8} 16^i S_{8g+i} (28 doublings, 7 additions), written over S_{8g}.  Stage 2, one lane per proof:
 // sum_g 2^(32 g) T_g (224 doublings, 7 additions).  The dependency chain of a batch loses 49 of its 63 general
-// additions for 8 x 28 extra doublings per proof (+3 % instructions).  BPGPU_HORNER_GROUPS=0 selects the one-stage pass.
+// additions for 8 x 28 extra doublings per proof (+3 % instructions).
 constexpr int HG = 8;   // windows per group
 __global__ void __launch_bounds__(64) k_verify_horner_groups(JacRaw *winsum, size_t nb) {
   __builtin_amdgcn_s_setprio(2);

@@ -846,6 +846,26 @@ def test_options_setter_rejects_bad_values(gpu):
     with gpu.options(msm_wp_max=7):
         assert gpu.get_option("msm_wp_max") == 7
     assert gpu.get_option("msm_wp_max") == 1 << 15
+    for name, bad in (("horner_form", 4), ("groups_form", 4), ("fixed_lpm", 48), ("stream_batch", 0), ("stream_lanes", 65), ("pippenger_min", 1)):
+        with pytest.raises(m.BpGpuError):
+            gpu.set_option(name, bad)
+
+
+def test_options_seeded_from_the_environment_are_validated(monkeypatch):
+    """a new context's options may be seeded from the environment, through the SAME validator as bpgpu_set_option --
+    BPGPU_STREAM_BATCH=0 (a division by zero before), a negative lane count, a table_np that is not a lane shape and garbage leave
+    the defaults in force; valid values are taken."""
+    import mpc_bulletproof_amd as m
+    for k, v in (("BPGPU_STREAM_BATCH", "0"), ("BPGPU_SCREEN_BATCH", "-5"), ("BPGPU_STREAM_LANES", "0"), ("BPGPU_TABLE_NP", "3"),
+                 ("BPGPU_FIXED_LPM", "17"), ("BPGPU_HORNER_FORM", "x1"), ("BPGPU_MSM_WP_MAX", "4096"), ("BPGPU_GROUPS_FORM", "2")):
+        monkeypatch.setenv(k, v)
+    g2 = m.BpGpu(0)
+    try:
+        assert g2.get_option("stream_batch") == 1024 and g2.get_option("screen_batch") == 2560 and g2.get_option("stream_lanes") == 20
+        assert g2.get_option("table_np") == 0 and g2.get_option("fixed_lpm") == 0 and g2.get_option("horner_form") == 0
+        assert g2.get_option("msm_wp_max") == 4096 and g2.get_option("groups_form") == 2
+    finally:
+        g2.close()
 
 
 def test_circuit_from_arkworks_coefficients(gpu):
