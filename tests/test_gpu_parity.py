@@ -1202,6 +1202,27 @@ def test_ipp_create_resident_generators(gpu, n, cap, c):
         gpu.gens_destroy(g)
 
 
+def test_ipp_rounds_of_many_provers_grouped_table_walk(gpu):
+    """From 8 provers on the round MSMs of a resident-generator IPP take k_fixed_msm_ipp_g (a wave = 8 MSMs x 8 pair-lanes).
+    11 provers (a unit with clamped lanes), n = 32: L, R of every round and the final a, b equal the oracle's."""
+    sys_path_oracle()
+    nb, n, cap, c = 11, 32, 32, 8
+    Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
+    g = gpu.gens_create(Gp, Hp, B, B, c)
+    try:
+        a, b = o.random_scalars(141, nb * n), o.random_scalars(142, nb * n)
+        Gf, Hf = o.random_scalars(143, nb * n), o.random_scalars(144, nb * n)
+        w = o.random_scalars(145, nb)
+        Ls, Rs, aa, bb, _ = _ipp_create_gpu(gpu, b"innerproducttest", nb, n, None, Gf, Hf, None, None, True, a, b, gens=g, w=w)
+        for p in range(nb):
+            sl = slice(32 * n * p, 32 * n * (p + 1))
+            Q = o.point_mul(w[32 * p:32 * p + 32], B)
+            L, R, ao, bo, _ = o.ipp_create(b"innerproducttest", n, Q, Gf[sl], Hf[sl], Gp[:64 * n], Hp[:64 * n], a[sl], b[sl])
+            assert (Ls[p], Rs[p], aa[32 * p:32 * p + 32], bb[32 * p:32 * p + 32]) == (L, R, ao, bo), p
+    finally:
+        gpu.gens_destroy(g)
+
+
 def sys_path_oracle():
     import os
     import sys
