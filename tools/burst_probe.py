@@ -40,12 +40,35 @@ for c in ctxs:
 for _ in range(3000):
     step()
 torch.cuda.synchronize()
+NT = int(os.environ.get("BURST_THREADS", "0"))    # experiment: the K steps submitted from NT host threads (step j on context j % inflight)
+if NT:
+    import threading
+    go = [threading.Barrier(NT + 1), threading.Barrier(NT + 1)]
+    todo = [0]
+
+    def worker(t):
+        while True:
+            go[0].wait()
+            if todo[0] < 0:
+                return
+            for j in range(t, todo[0], NT):
+                ctxs[j % len(ctxs)].r1cs_verify_batch_dev(gens, circ, nb, n1, k, d_pts, d_sc, d_ch, d_oks[j % len(ctxs)])
+            go[1].wait()
+
+    ths = [threading.Thread(target=worker, args=(t,), daemon=True) for t in range(NT)]
+    for t in ths:
+        t.start()
 for K in [int(x) for x in os.environ.get("BURST_KS", "1,2,4,8,16,32,64,64,256,256,1024,1024,4096").split(",")]:
     cnt[0] = 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(K):
-        step()
+    if NT:
+        todo[0] = K
+        go[0].wait()
+        go[1].wait()
+    else:
+        for _ in range(K):
+            step()
     t1 = time.perf_counter()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
