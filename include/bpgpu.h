@@ -75,7 +75,9 @@ int bpgpu_set_latency_mode(bpgpu_ctx *ctx, int on);
 #define BPGPU_OPT_IPP_PIPPENGER_MIN 16     /* the same for the L / R MSMs of bpgpu_ipp_round's literal schedule (default 257) */
 #define BPGPU_OPT_FIXED_LPM 17             /* lanes per fixed-base MSM in the verification's back launch: 16, 32, 64; 0 = by mode */
 #define BPGPU_OPT_GROUPS_FORM 18           /* first Horner stage: 0 = by mode, 1 = a lane, 2 = a DPP quad, 3 = a whole wave per group of 8 windows */
-#define BPGPU_OPT_COUNT 19
+#define BPGPU_OPT_FIXED_CHUNK_GENS 19      /* generator half of the verification's back launch: 0 = by mode, -1 = FIXED_LPM lanes per proof and a butterfly; g in 1..64 = a proof
+                                            * per lane, g generators per wave, the partial sums added in the verdict launch */
+#define BPGPU_OPT_COUNT 20
 int bpgpu_set_option(bpgpu_ctx *ctx, int option, int64_t value);
 int bpgpu_get_option(bpgpu_ctx *ctx, int option, int64_t *value);
 /* synchronise and report whether an operand of the `_dev` (device-resident, asynchronous) calls issued since the last read -- or

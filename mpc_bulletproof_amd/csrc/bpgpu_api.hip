@@ -298,6 +298,7 @@ static bool opt_valid(int option, int64_t value) {
     case BPGPU_OPT_IPP_PIPPENGER_MIN: return value >= 2 && value <= ((int64_t)1 << 30);
     case BPGPU_OPT_FIXED_LPM: return value == 0 || value == 16 || value == 32 || value == 64;
     case BPGPU_OPT_GROUPS_FORM: return value >= 0 && value <= 3;
+    case BPGPU_OPT_FIXED_CHUNK_GENS: return value >= -1 && value <= 64;
     default: return value == 0 || value == 1;
   }
 }
@@ -326,7 +327,7 @@ static int ctx_create(int device, bool single, bpgpu_ctx **out) {
         {BPGPU_OPT_SCREEN_BATCH, "BPGPU_SCREEN_BATCH", 2560},         {BPGPU_OPT_HORNER_FORM, "BPGPU_HORNER_FORM", 0},
         {BPGPU_OPT_HORNER_ROW_MAX, "BPGPU_HORNER_ROW_MAX", 1536},     {BPGPU_OPT_PIPPENGER_MIN, "BPGPU_PIPPENGER_MIN", 512},
         {BPGPU_OPT_IPP_PIPPENGER_MIN, "BPGPU_IPP_PIPPENGER_MIN", 257}, {BPGPU_OPT_FIXED_LPM, "BPGPU_FIXED_LPM", 0},
-        {BPGPU_OPT_GROUPS_FORM, "BPGPU_GROUPS_FORM", 0}};
+        {BPGPU_OPT_GROUPS_FORM, "BPGPU_GROUPS_FORM", 0}, {BPGPU_OPT_FIXED_CHUNK_GENS, "BPGPU_FIXED_CHUNK_GENS", 0}};
     // the environment only SEEDS a new context's options, through the same validation as bpgpu_set_option: a value that the
     // setter would refuse (a batch size of 0, a negative lane count, ...) leaves the default in force
     for (auto &s : seed) {
@@ -608,6 +609,7 @@ static void wp_options(const bpgpu_ctx *ctx, VerifyWp &v) {   // the per-context
   v.row_max = (size_t)ctx->opt[BPGPU_OPT_HORNER_ROW_MAX];
   v.fixed_lpm = (int)ctx->opt[BPGPU_OPT_FIXED_LPM];
   v.groups_form = (int)ctx->opt[BPGPU_OPT_GROUPS_FORM];
+  v.fixed_chunk_gens = (int)ctx->opt[BPGPU_OPT_FIXED_CHUNK_GENS];
 }
 static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, const void *points, bool converted, JacRaw *dsum, bool *done,
                         int *bad = nullptr, size_t max_n = 0) {
@@ -1287,7 +1289,16 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
   VerifyDims d{nb, n1, n, np, k, m, (const Words8 *)chi, (size_t)ctx->opt[BPGPU_OPT_VS_LARGE_MIN]};
   CK(ws_get(ctx, 6, verify_scalars_scratch_ints(circuit_dev(c), d) * 4, &dzp));
   CK(ws_get(ctx, 10, nb * nvar * sizeof(JacRaw), &dvres));
-  CK(ws_get(ctx, 11, nb * sizeof(JacRaw), &dfres));
+  // (nb x parts partial sums when the generator half is walked a proof per lane: BPGPU_OPT_FIXED_CHUNK_GENS)
+  size_t fparts = 1;
+  if (fixed_msm_chunks(g->c, np, nb) == 1 && verify_wp_supported(nb, nvar, g->c, np)) {
+    VerifyWp vt{};
+    vt.nb = nb;
+    vt.latency_mode = ctx->latency_mode;
+    wp_options(ctx, vt);
+    fparts = verify_wp_fixed_parts(vt, np);
+  }
+  CK(ws_get(ctx, 11, nb * fparts * sizeof(JacRaw), &dfres));
   void *dstr;
   CK(straus_ws(ctx, 4, nb * nvar, &dstr));
   // per-proof canonicity bits of the scalar assembly (every entry is written by the kernel: no reset)
@@ -1346,7 +1357,7 @@ static int verify_batch_dev_locked(bpgpu_ctx *ctx, const bpgpu_gens *g, const bp
       verify_wp_back(ctx->st, v, g->c, fused_fixed && !side ? g->table : nullptr, np, g->cap, (const uint32_t *)dfix, (2 + 2 * np) * 8, (JacRaw *)dfres); }
     if (side) HIPCK(ctx, hipStreamWaitEvent(ctx->st, ctx->ev2, 0));
     { ProfScope ps(ctx, 11, ctx->st);
-      verify_wp_verdict(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega); }
+      verify_wp_verdict(ctx->st, v, (const JacRaw *)dfres, (int32_t *)ok, (Words8 *)mega, fused_fixed && !side ? verify_wp_fixed_parts(v, np) : 1); }
     return launch_ok(ctx);
   }
   // scalar assembly, then fixed-base part on st2 while st runs the variable-base part

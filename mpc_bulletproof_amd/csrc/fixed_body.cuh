@@ -79,6 +79,76 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
   }
   if (lane == 0 && live) raw_store(&out[b], accj);
 }
-struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb; };
+// The same MSMs with a PROOF per lane and a run of whole generators per wave (`gens_per_chunk` of the 2 + 2n): the 64 lanes of a wave
+// walk the same (generator, window) pairs, so a wave-load gathers 64 rows of ONE 2^(C-1)-row window of the table instead of rows of
+// sixteen, the scalar of a generator is loaded and recoded once for its W windows, and no lane adds up its neighbours: every lane
+// writes its partial sum (part[proof * chunks + chunk]) and the verdict launch adds the `chunks` partials of a proof densely.  The
+// chunk length sets the wave count (chunks x ceil(nb / 64)) and the dependency chain (gens_per_chunk x W additions) without a
+// butterfly whose cost grows with the lanes per MSM.
+template <int C>
+__device__ __forceinline__ void fixed_chunk_body(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride,
+                                                 JacRaw *part, size_t nb, unsigned chunks, unsigned gens_per_chunk, size_t blk) {
+  constexpr int W = num_windows<C>();
+  constexpr int HALF = 1 << (C - 1);
+  const size_t set = blk / chunks;
+  const unsigned q = (unsigned)(blk - set * chunks);
+  size_t p = set * 64 + threadIdx.x;
+  const bool live = p < nb;
+  if (!live) p = nb - 1;
+  const uint32_t *sc = scalars + p * sc_stride;
+  const size_t ngens = 2 + 2 * n, hshift = cap - n;
+  const size_t g0 = (size_t)q * gens_per_chunk;
+  const size_t g1 = g0 + gens_per_chunk < ngens ? g0 + gens_per_chunk : ngens;
+  Xyzz acc = xyzz_inf();
+  uint32_t r[9], cur[16];
+  int dcur = 0;
+  auto recode = [&](size_t g) {
+    uint32_t s[8];
+#pragma unroll
+    for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
+    recode_add_k<C>(r, s);
+  };
+  auto fetch = [&](size_t g, int w, uint32_t *dst, int &dg) {   // (g, w) are wave-uniform; only the digit differs between lanes
+    dg = recode_digit<C>(r, w);
+    if (dg != 0) {
+      const size_t row = (g < 2 + n ? g : g + hshift) * W + w;
+      const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
+      uint32_t any = 0;
+#pragma unroll
+      for (int t = 0; t < 16; t++) { dst[t] = e->w[t]; any |= dst[t]; }
+      if (any == 0) dg = 0;   // rows of an identity generator are the identity
+    }
+  };
+  size_t g = g0;
+  int w = 0;
+  if (g < g1) { recode(g); fetch(g, 0, cur, dcur); }
+#pragma unroll 1
+  while (g < g1) {
+    size_t gn = g;
+    int wn = w + 1;
+    if (wn == W) { wn = 0; gn = g + 1; }
+    uint32_t nxt[16];
+    int dnxt = 0;
+    if (gn < g1) {
+      if (wn == 0) recode(gn);   // the digit of (g, w) is already in dcur
+      fetch(gn, wn, nxt, dnxt);
+    }
+    if (dcur != 0) {
+      Aff a;
+      a.x = unpack<FP>(cur);
+      a.y = unpack<FP>(cur + 8);
+      if (dcur < 0) a.y = neg(a.y);
+      acc = xyzz_madd_nzq(acc, a);
+    }
+#pragma unroll
+    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
+    dcur = dnxt;
+    g = gn;
+    w = wn;
+  }
+  if (live) raw_store(&part[p * chunks + q], xyzz_to_jac(acc));
+}
+struct FixedSmallArgs { const AffDev *table; size_t n, cap; const uint32_t *scalars; size_t sc_stride; JacRaw *out; size_t nb;
+                        unsigned chunks = 0, gens_per_chunk = 0; /* chunks != 0: fixed_chunk_body, out = nb x chunks partial sums */ };
 
 }  // namespace bpk

@@ -440,6 +440,16 @@ __global__ void __launch_bounds__(64) k_verify_back(HornerArgs h, unsigned horne
   }
   else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - horner_blocks);
 }
+// the same launch with the generator half walked a proof per lane, a run of generators per wave (fixed_chunk_body)
+template <int C>
+__global__ void __launch_bounds__(64) k_verify_back_q(HornerArgs h, unsigned horner_blocks, FixedSmallArgs f) {
+  if (blockIdx.x < horner_blocks) {
+    if (h.quad == 2) horner_row_body(h, blockIdx.x);
+    else if (h.quad) horner4_body(h, blockIdx.x);
+    else horner_body(h, blockIdx.x);
+  }
+  else fixed_chunk_body<C>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, f.chunks, f.gens_per_chunk, blockIdx.x - horner_blocks);
+}
 // lane per proof: variable-base sum + fixed-base partial; ok = identity and every input of the proof well-formed
 __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, const JacRaw *fixed, size_t nb, const int32_t *bad_lane,
                                                        size_t lanes, const int32_t *bad_sc, int32_t *ok, Words8 *mega) {
@@ -447,6 +457,48 @@ __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, con
   size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= nb) return;
   Jac acc = jac_add(raw_load(&varsum[p]), raw_load(&fixed[p]));
+  const bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
+  int malformed = bad_sc ? bad_sc[p] : 0;
+  for (size_t l = 0; l < lanes; l++) malformed |= bad_lane[p * lanes + l];
+  ok[p] = (inf && !malformed) ? 1 : 0;
+  if (mega) {
+    uint32_t w[16];
+    if (inf) {
+#pragma unroll
+      for (int j = 0; j < 16; j++) w[j] = 0;
+    } else {
+      aff_to_boundary(w, jac_to_aff(acc));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) { mega[2 * p].w[j] = w[j]; mega[2 * p + 1].w[j] = w[8 + j]; }
+  }
+}
+// the verdict over `chunks` partial sums of the generator half per proof (k_verify_back_q): R lanes per proof add chunks / R partials
+// each, a butterfly over the R lanes, lane 0 of the proof decides
+__global__ void __launch_bounds__(64) k_verify_verdict_q(const JacRaw *varsum, const JacRaw *part, unsigned chunks, unsigned R, size_t nb,
+                                                         const int32_t *bad_lane, size_t lanes, const int32_t *bad_sc, int32_t *ok, Words8 *mega) {
+  __builtin_amdgcn_s_setprio(2);
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t p = t / R;
+  const unsigned r = (unsigned)(t - p * R);
+  const bool live = p < nb;
+  if (!live) p = nb - 1;
+  Jac acc = jac_inf();
+#pragma unroll 1
+  for (unsigned q = r; q < chunks; q += R) acc = jac_add(acc, raw_load(&part[p * chunks + q]));
+#pragma unroll 1
+  for (unsigned off = R / 2; off > 0; off >>= 1) {
+    Jac o;
+#pragma unroll
+    for (int j = 0; j < NL; j++) {
+      o.X.v[j] = __shfl_xor(acc.X.v[j], off, 64);
+      o.Y.v[j] = __shfl_xor(acc.Y.v[j], off, 64);
+      o.Z.v[j] = __shfl_xor(acc.Z.v[j], off, 64);
+    }
+    acc = jac_add(acc, o);
+  }
+  if (r != 0 || !live) return;
+  acc = jac_add(raw_load(&varsum[p]), acc);
   const bool inf = jac_is_inf(acc) || is_zero_exact(acc.Z);
   int malformed = bad_sc ? bad_sc[p] : 0;
   for (size_t l = 0; l < lanes; l++) malformed |= bad_lane[p * lanes + l];
@@ -541,8 +593,13 @@ void verify_wp_groups(hipStream_t st, const VerifyWp &v) {
   if (quad) hipLaunchKernelGGL(k_verify_horner_groups4, dim3((v.nb * (64 / HG) + 15) / 16), dim3(64), 0, st, L.winsum, v.nb);
   else hipLaunchKernelGGL(k_verify_horner_groups, dim3((v.nb * (64 / HG) + 63) / 64), dim3(64), 0, st, L.winsum, v.nb);
 }
+static size_t wp_chunk_gens(const VerifyWp &v);
 template <int C>
 static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode, int lpm_opt) {
+  if (f.chunks) {
+    hipLaunchKernelGGL((k_verify_back_q<C>), dim3(hb + (unsigned)((f.nb + 63) / 64) * f.chunks), dim3(64), 0, st, h, hb, f);
+    return;
+  }
   // lanes per fixed-base MSM: 16 = fewest instructions (4 butterfly levels), 32 = half the serial additions per lane
   // (the fixed-base lanes are the longest link of this launch once the Horner pass runs on quads); BPGPU_OPT_FIXED_LPM overrides
   const int lpm = lpm_opt == 16 || lpm_opt == 32 || lpm_opt == 64 ? lpm_opt : (f.nb >= 1024 && !latency_mode ? 16 : 32);
@@ -562,6 +619,7 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
   if (wp_grouped()) { h.count = 64 / HG; h.stride = HG; h.dbl = SW * HG; }
   const unsigned hb = (unsigned)(quad == 2 ? v.nb : (quad ? (v.nb + 15) / 16 : (v.nb + 63) / 64));
   FixedSmallArgs f{table, n, cap, fixed_scalars, sc_stride, out_fixed, v.nb};
+  if (table && verify_wp_fixed_parts(v, n) > 1) { f.chunks = (unsigned)verify_wp_fixed_parts(v, n); f.gens_per_chunk = (unsigned)wp_chunk_gens(v); }
   if (!table) {   // the generator half ran as its own launch: Horner pass only
     f.nb = 0;
     launch_back<8>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
@@ -572,8 +630,27 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
   else launch_back<20>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
 }
 const JacRaw *verify_wp_varsum(const VerifyWp &v) { return wp_layout(v).varsum; }
-void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega) {
+// generators per wave of the proof-per-lane walk of the generator half (0 = the lanes-per-proof form): by default 5 (26 runs of a
+// 64-bit range proof's 130 generators: 65 additions per lane) once the batch fills its waves -- against 16 lanes per proof and a butterfly
+// +2.4 % sustained and +5 % in a 20-step burst (profiles/r04_burst20_sweep2.log); a lone batch in latency mode keeps the lanes-per-proof form
+// (its generator half runs beside the chain on the second stream) and so does a batch of a few proofs, whose waves would be mostly dead lanes
+static size_t wp_chunk_gens(const VerifyWp &v) {
+  if (v.fixed_chunk_gens < 0) return 0;
+  if (v.fixed_chunk_gens > 0) return (size_t)v.fixed_chunk_gens;
+  return !v.latency_mode && v.nb >= 256 ? 5 : 0;
+}
+size_t verify_wp_fixed_parts(const VerifyWp &v, size_t n) {
+  const size_t g = wp_chunk_gens(v);
+  return g ? (2 + 2 * n + g - 1) / g : 1;
+}
+void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega, size_t parts) {
   WpLayout L = wp_layout(v);
+  if (parts > 1) {
+    const unsigned R = parts > 16 && v.latency_mode ? 16 : 4;   // lanes per proof: 4 keep the additions dense (a lane adds parts / 4), 16 shorten a lone batch's chain
+    hipLaunchKernelGGL(k_verify_verdict_q, dim3((unsigned)((v.nb * R + 63) / 64)), dim3(64), 0, st, L.varsum, fixed, (unsigned)parts, R, v.nb,
+                       L.t.bad_lane, L.t.lanes, v.bad_sc, ok, mega);
+    return;
+  }
   hipLaunchKernelGGL(k_verify_verdict, dim3((v.nb + 63) / 64), dim3(64), 0, st, L.varsum, fixed, v.nb, L.t.bad_lane, L.t.lanes,
                      v.bad_sc, ok, mega);
 }

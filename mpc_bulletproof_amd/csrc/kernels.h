@@ -66,6 +66,7 @@ struct VerifyWp { const AffDev *points_abi; size_t nb, nvar; void *scratch /* ve
                   size_t row_max = 1536; // most proofs / groups for which latency mode takes the row form -- BPGPU_OPT_HORNER_ROW_MAX
                   int fixed_lpm = 0;     // lanes per fixed-base MSM in the back launch: 16 / 32 / 64, 0 = by mode -- BPGPU_OPT_FIXED_LPM
                   int groups_form = 0;   // first Horner stage: 0 = by mode, 1 = a lane, 2 = a quad, 3 = a wave per group of 8 windows -- BPGPU_OPT_GROUPS_FORM
+                  int fixed_chunk_gens = 0;   // generator half of the back launch: 0 = by mode, -1 = fixed_lpm lanes per proof + butterfly; g > 0 = a proof per lane, g generators per wave, partial sums added in the verdict launch -- BPGPU_OPT_FIXED_CHUNK_GENS
 };
 struct VerifyDims { size_t nb, n1, n, padded_n, k, m; const Words8 *chi; /* nb x nchi gadget challenges (plain words) or nullptr */
                     size_t vs_large_min = 0; /* padded_n / m from which the scalar assembly is split over the grid (0 = 4096) -- BPGPU_OPT_VS_LARGE_MIN */ };
@@ -85,7 +86,10 @@ void verify_wp_windows(hipStream_t st, const VerifyWp &v, const uint32_t *var_sc
 void verify_wp_groups(hipStream_t st, const VerifyWp &v);
 void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *table, size_t n, size_t cap,
                     const uint32_t *fixed_scalars, size_t sc_stride_words, JacRaw *out_fixed);
-void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega);
+// `parts` partial sums of the generator half per proof in `fixed` (verify_wp_fixed_parts: 1 unless v.fixed_chunk_gens > 0 AND the generator
+// half rode in verify_wp_back; out_fixed of verify_wp_back must then hold nb x parts entries)
+size_t verify_wp_fixed_parts(const VerifyWp &v, size_t n);
+void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega, size_t parts = 1);
 const JacRaw *verify_wp_varsum(const VerifyWp &v);   // nb sums of the proof-point halves, valid after verify_wp_back
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)

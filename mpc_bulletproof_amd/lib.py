@@ -62,7 +62,7 @@ E_ARG, E_LEN, E_DEVICE, E_OOM, E_GENS = -1, -2, -3, -4, -5
 # bpgpu_set_option (include/bpgpu.h BPGPU_OPT_*)
 OPT = {"msm_wp_max": 1, "msm_pip2_single": 2, "verify_no_fuse": 3, "verify_window_parallel": 4, "verify_straus_np": 5,
        "ipp_literal": 6, "vs_large_min": 7, "table_np": 8, "ipp_table_max_n": 9, "stream_lanes": 10, "stream_batch": 11, "screen_batch": 12,
-       "horner_form": 13, "horner_row_max": 14, "pippenger_min": 15, "ipp_pippenger_min": 16, "fixed_lpm": 17, "groups_form": 18}
+       "horner_form": 13, "horner_row_max": 14, "pippenger_min": 15, "ipp_pippenger_min": 16, "fixed_lpm": 17, "groups_form": 18, "fixed_chunk_gens": 19}
 # bpgpu_profile_read kinds (include/bpgpu.h BPGPU_PROF_KINDS)
 PROF_NAMES = ["verify_scalars", "fixed_msm", "points_from_boundary", "straus", "verify_finalize", "transcript", "verify_msm",
               "verify_windows", "verify_front", "verify_groups", "verify_back", "verify_verdict", "combined_front_scalars_digits",

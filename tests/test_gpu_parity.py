@@ -846,7 +846,8 @@ def test_options_setter_rejects_bad_values(gpu):
     with gpu.options(msm_wp_max=7):
         assert gpu.get_option("msm_wp_max") == 7
     assert gpu.get_option("msm_wp_max") == 1 << 15
-    for name, bad in (("horner_form", 4), ("groups_form", 4), ("fixed_lpm", 48), ("stream_batch", 0), ("stream_lanes", 65), ("pippenger_min", 1)):
+    for name, bad in (("horner_form", 4), ("groups_form", 4), ("fixed_lpm", 48), ("stream_batch", 0), ("stream_lanes", 65), ("pippenger_min", 1),
+                      ("fixed_chunk_gens", -2), ("fixed_chunk_gens", 65)):
         with pytest.raises(m.BpGpuError):
             gpu.set_option(name, bad)
 
@@ -959,6 +960,17 @@ def test_verify_batch_horner_forms(gpu, opts, horner, groups, lpm):
     mega_check points and all MSM scalars equal the oracle's in every combination."""
     opts(horner_form=horner, groups_form=groups, fixed_lpm=lpm)
     test_range_verify_batch(gpu, 8, 70, 8)
+
+
+@pytest.mark.parametrize("gens,nb,c", [(-1, 70, 8), (1, 70, 8), (3, 70, 8), (5, 130, 8), (18, 65, 8), (64, 7, 8), (5, 70, 16), (0, 300, 8)])
+def test_verify_batch_generator_half_a_proof_per_lane(gpu, opts, gens, nb, c):
+    """The generator half of the back launch walked a PROOF per lane, a run of `gens` generators per wave (fixed_chunk_body), the
+    partial sums of a proof added in the verdict launch -- for runs of 1 generator (18 partials of the 8-bit gadget's 18 generators)
+    up to one run of all of them, batches that leave dead lanes in their last wave (7, 65, 70, 130 proofs), tampered proofs among them:
+    accept bits, mega_check points and all MSM scalars equal the oracle's; -1 forces the lanes-per-proof form, 0 is the default
+    rule (the proof-per-lane walk from 256 proofs on)."""
+    opts(fixed_chunk_gens=gens)
+    test_range_verify_batch(gpu, 8, nb, c)
 
 
 @pytest.mark.parametrize("n_bits,nb,c", [(8, 71, 8), (8, 12, 8), (64, 65, 20)])
@@ -1202,11 +1214,13 @@ def test_ipp_create_resident_generators(gpu, n, cap, c):
         gpu.gens_destroy(g)
 
 
-def test_ipp_rounds_of_many_provers_grouped_table_walk(gpu):
+@pytest.mark.parametrize("nb,n", [(11, 32), (70, 16)])
+def test_ipp_rounds_of_many_provers_grouped_table_walk(gpu, nb, n):
     """From 8 provers on the round MSMs of a resident-generator IPP take k_fixed_msm_ipp_g (a wave = 8 MSMs x 8 pair-lanes).
-    11 provers (a unit with clamped lanes), n = 32: L, R of every round and the final a, b equal the oracle's."""
+    11 provers (a unit with clamped lanes), n = 32, and 70 provers (eight full units and one with six live lanes), n = 16: L, R of
+    every round and the final a, b equal the oracle's."""
     sys_path_oracle()
-    nb, n, cap, c = 11, 32, 32, 8
+    cap, c = 32, 8
     Gp, Hp, B = o.gens("G", cap), o.gens("H", cap), o.generator()
     g = gpu.gens_create(Gp, Hp, B, B, c)
     try:
