@@ -85,7 +85,7 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
 // writes its partial sum (part[proof * chunks + chunk]) and the verdict launch adds the `chunks` partials of a proof densely.  The
 // chunk length sets the wave count (chunks x ceil(nb / 64)) and the dependency chain (gens_per_chunk x W additions) without a
 // butterfly whose cost grows with the lanes per MSM.
-template <int C>
+template <int C, int AHEAD>
 __device__ __forceinline__ void fixed_chunk_body(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride,
                                                  JacRaw *part, size_t nb, unsigned chunks, unsigned gens_per_chunk, size_t blk) {
   constexpr int W = num_windows<C>();
@@ -100,51 +100,53 @@ __device__ __forceinline__ void fixed_chunk_body(const AffDev *table, size_t n, 
   const size_t g0 = (size_t)q * gens_per_chunk;
   const size_t g1 = g0 + gens_per_chunk < ngens ? g0 + gens_per_chunk : ngens;
   Xyzz acc = xyzz_inf();
-  uint32_t r[9], cur[16];
-  int dcur = 0;
-  auto recode = [&](size_t g) {
-    uint32_t s[8];
+  uint32_t r[9];
+  // rows AHEAD pairs ahead of the addition: position `gc, wc` is the next pair to fetch (wave-uniform; only the digit differs between
+  // lanes), r the recoded scalar of its generator
+  uint32_t row[AHEAD + 1][16];
+  int dg[AHEAD + 1];
+  size_t gc = g0;
+  int wc = 0;
+  auto step = [&](uint32_t *dst, int &d) {
+    d = 0;
+    if (gc < g1) {
+      if (wc == 0) {
+        uint32_t s[8];
 #pragma unroll
-    for (int t = 0; t < 8; t++) s[t] = sc[g * 8 + t];
-    recode_add_k<C>(r, s);
-  };
-  auto fetch = [&](size_t g, int w, uint32_t *dst, int &dg) {   // (g, w) are wave-uniform; only the digit differs between lanes
-    dg = recode_digit<C>(r, w);
-    if (dg != 0) {
-      const size_t row = (g < 2 + n ? g : g + hshift) * W + w;
-      const AffDev *e = table + row * HALF + ((dg < 0 ? -dg : dg) - 1);
-      uint32_t any = 0;
+        for (int t = 0; t < 8; t++) s[t] = sc[gc * 8 + t];
+        recode_add_k<C>(r, s);
+      }
+      d = recode_digit<C>(r, wc);
+      if (d != 0) {
+        const size_t rw = (gc < 2 + n ? gc : gc + hshift) * W + wc;
+        const AffDev *e = table + rw * HALF + ((d < 0 ? -d : d) - 1);
+        uint32_t any = 0;
 #pragma unroll
-      for (int t = 0; t < 16; t++) { dst[t] = e->w[t]; any |= dst[t]; }
-      if (any == 0) dg = 0;   // rows of an identity generator are the identity
+        for (int t = 0; t < 16; t++) { dst[t] = e->w[t]; any |= dst[t]; }
+        if (any == 0) d = 0;   // rows of an identity generator are the identity
+      }
+      if (++wc == W) { wc = 0; gc++; }
     }
   };
-  size_t g = g0;
-  int w = 0;
-  if (g < g1) { recode(g); fetch(g, 0, cur, dcur); }
+#pragma unroll
+  for (int a = 0; a < AHEAD; a++) step(row[a], dg[a]);
+  const size_t npairs = (g1 > g0 ? g1 - g0 : 0) * W;
 #pragma unroll 1
-  while (g < g1) {
-    size_t gn = g;
-    int wn = w + 1;
-    if (wn == W) { wn = 0; gn = g + 1; }
-    uint32_t nxt[16];
-    int dnxt = 0;
-    if (gn < g1) {
-      if (wn == 0) recode(gn);   // the digit of (g, w) is already in dcur
-      fetch(gn, wn, nxt, dnxt);
-    }
-    if (dcur != 0) {
+  for (size_t it = 0; it < npairs; it++) {
+    step(row[AHEAD], dg[AHEAD]);
+    if (dg[0] != 0) {
       Aff a;
-      a.x = unpack<FP>(cur);
-      a.y = unpack<FP>(cur + 8);
-      if (dcur < 0) a.y = neg(a.y);
+      a.x = unpack<FP>(row[0]);
+      a.y = unpack<FP>(row[0] + 8);
+      if (dg[0] < 0) a.y = neg(a.y);
       acc = xyzz_madd_nzq(acc, a);
     }
 #pragma unroll
-    for (int t = 0; t < 16; t++) cur[t] = nxt[t];
-    dcur = dnxt;
-    g = gn;
-    w = wn;
+    for (int a = 0; a < AHEAD; a++) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) row[a][t] = row[a + 1][t];
+      dg[a] = dg[a + 1];
+    }
   }
   if (live) raw_store(&part[p * chunks + q], xyzz_to_jac(acc));
 }

@@ -441,14 +441,14 @@ __global__ void __launch_bounds__(64) k_verify_back(HornerArgs h, unsigned horne
   else fixed_small_body<C, LPM>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, blockIdx.x - horner_blocks);
 }
 // the same launch with the generator half walked a proof per lane, a run of generators per wave (fixed_chunk_body)
-template <int C>
+template <int C, int AHEAD>
 __global__ void __launch_bounds__(64) k_verify_back_q(HornerArgs h, unsigned horner_blocks, FixedSmallArgs f) {
   if (blockIdx.x < horner_blocks) {
     if (h.quad == 2) horner_row_body(h, blockIdx.x);
     else if (h.quad) horner4_body(h, blockIdx.x);
     else horner_body(h, blockIdx.x);
   }
-  else fixed_chunk_body<C>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, f.chunks, f.gens_per_chunk, blockIdx.x - horner_blocks);
+  else fixed_chunk_body<C, AHEAD>(f.table, f.n, f.cap, f.scalars, f.sc_stride, f.out, f.nb, f.chunks, f.gens_per_chunk, blockIdx.x - horner_blocks);
 }
 // lane per proof: variable-base sum + fixed-base partial; ok = identity and every input of the proof well-formed
 __global__ void __launch_bounds__(64) k_verify_verdict(const JacRaw *varsum, const JacRaw *fixed, size_t nb, const int32_t *bad_lane,
@@ -597,7 +597,8 @@ static size_t wp_chunk_gens(const VerifyWp &v);
 template <int C>
 static void launch_back(hipStream_t st, const HornerArgs &h, unsigned hb, const FixedSmallArgs &f, bool latency_mode, int lpm_opt) {
   if (f.chunks) {
-    hipLaunchKernelGGL((k_verify_back_q<C>), dim3(hb + (unsigned)((f.nb + 63) / 64) * f.chunks), dim3(64), 0, st, h, hb, f);
+    // (rows two and three pairs ahead of the addition instead of one: the same rate, profiles/r04_burst20_sweep2.log)
+    hipLaunchKernelGGL((k_verify_back_q<C, 1>), dim3(hb + (unsigned)((f.nb + 63) / 64) * f.chunks), dim3(64), 0, st, h, hb, f);
     return;
   }
   // lanes per fixed-base MSM: 16 = fewest instructions (4 butterfly levels), 32 = half the serial additions per lane
