@@ -999,7 +999,8 @@ def main():
         # The kernels of the window-parallel chain that consume algorithmic bytes (96 B per MSM term = 64 B point +
         # 32 B scalar) and what each reads of them; the dominant kernel = the one with the longest solo duration.
         lpm = 16 if nb >= 1024 else 32
-        names = {"verify_back": f"k_verify_back<{a.window_bits},{lpm}>", "verify_front": "k_verify_front<4>",
+        # (from 256 proofs on the generator half of the back launch is walked a proof per lane: k_verify_back_q, csrc/fixed_body.cuh)
+        names = {"verify_back": f"k_verify_back_q<{a.window_bits},1>" if nb >= 256 else f"k_verify_back<{a.window_bits},{lpm}>", "verify_front": "k_verify_front<4>",
                  "verify_windows": "k_verify_windows", "verify_scalars": "k_verify_scalars_fast", "verify_groups": "k_verify_horner_groups",
                  "verify_verdict": "k_verify_verdict"}
         bytes_per_proof = {"verify_back": (nterms - nvar) * 96, "verify_front": nvar * 64, "verify_windows": nvar * 32,
