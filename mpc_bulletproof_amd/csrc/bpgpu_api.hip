@@ -247,11 +247,11 @@ __global__ void k_coeff_ark_to_mont(Words8 *io, size_t n, int *bad) {
   for (int j = 0; j < 8; j++) io[i].w[j] = w[j];
 }
 static int msm_gens_dev(bpgpu_ctx *ctx, const bpgpu_gens *g, size_t nb, size_t n, const uint32_t *dsc, JacRaw *dres,
-                        hipStream_t st, int part_slot = 12, int lpm = 0) {
-  size_t chunks = fixed_msm_chunks(g->c, n, nb);
+                        hipStream_t st, int part_slot = 12, int lpm = 0, int kinds = 0) {
+  size_t chunks = fixed_msm_chunks(g->c, n, nb, kinds);
   void *dpart = nullptr;
   if (chunks > 1) CK(ws_get(ctx, part_slot, nb * chunks * sizeof(JacRaw), &dpart));
-  fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart, lpm);
+  fixed_msm(st, g->c, g->table, n, g->cap, dsc, (2 + 2 * n) * 8, dres, nb, (JacRaw *)dpart, lpm, kinds);
   return BPGPU_OK;
 }
 
@@ -2696,7 +2696,8 @@ int bpgpu_r1cs_prover_commit(bpgpu_ctx *ctx, const bpgpu_gens *g, bpgpu_prover *
   size_t slo = 0, shi = wn;
   if (ctx->shard_world > 1) shard_bounds(wn, ctx->shard_rank, ctx->shard_world, &slo, &shi);   // this rank's generators: partial commitments
   commit_rows(ctx->st, nb, wn, wn0, wn, s->aL, s->aR, s->aO, s->sL, s->sR, dbl, (Words8 *)drows, slo, shi, ctx->shard_rank == 0);
-  if ((rc = msm_gens_dev(ctx, g, nb * 3, wn, (const uint32_t *)drows, (JacRaw *)dres, ctx->st))) return fail(rc);
+  // (three classes of rows per prover -- A_I, A_O: bit vectors; S: dense -- so that a wave of the MSM-per-lane walk holds one class)
+  if ((rc = msm_gens_dev(ctx, g, nb * 3, wn, (const uint32_t *)drows, (JacRaw *)dres, ctx->st, 12, 0, 3))) return fail(rc);
   jac_to_boundary(ctx->st, (JacRaw *)dres, (Words8 *)dout, nb * 3);
   span.close();
   if ((rc = launch_ok(ctx))) return fail(rc);

@@ -87,12 +87,15 @@ __device__ __forceinline__ void fixed_small_body(const AffDev *table, size_t n, 
 // butterfly whose cost grows with the lanes per MSM.
 template <int C, int AHEAD>
 __device__ __forceinline__ void fixed_chunk_body(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride,
-                                                 JacRaw *part, size_t nb, unsigned chunks, unsigned gens_per_chunk, size_t blk) {
+                                                 JacRaw *part, size_t nb, unsigned chunks, unsigned gens_per_chunk, size_t blk,
+                                                 unsigned kinds = 1, unsigned kind = 0) {
+  // (kinds > 1: the MSMs come in `kinds` interleaved classes -- MSM i is of class i % kinds -- and a wave holds MSMs of ONE class:
+  // classes whose scalars are mostly zero, a prover's bit vectors, then skip the additions a dense class needs wave-uniformly)
   constexpr int W = num_windows<C>();
   constexpr int HALF = 1 << (C - 1);
   const size_t set = blk / chunks;
   const unsigned q = (unsigned)(blk - set * chunks);
-  size_t p = set * 64 + threadIdx.x;
+  size_t p = (set * 64 + threadIdx.x) * kinds + kind;
   const bool live = p < nb;
   if (!live) p = nb - 1;
   const uint32_t *sc = scalars + p * sc_stride;

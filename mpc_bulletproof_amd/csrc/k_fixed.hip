@@ -343,8 +343,29 @@ void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t
   if (chunks > 1 && sum_partials) segmented_sum(st, partials, out, nmsm, chunks);
 }
 
+// Many large MSMs over the same generators (a batch's A_I, A_O, S commitments: 3 x 256 MSMs of 2 050 terms) with an MSM per LANE and a run
+// of generators per wave (fixed_chunk_body): one table page per wave-load, the scalar recoded once per generator, no block sum -- and,
+// with the MSMs of a wave all of one class (`kinds`), the windows of a bit vector that are zero in every lane cost nothing.  In the
+// block-per-MSM kernel above a lane is a (generator, window) pair: the one window of a bit vector that is not zero keeps 4 lanes of
+// every wave adding, so A_I and A_O cost as much as the dense S.
+template <int C>
+__global__ void __launch_bounds__(64) k_fixed_msm_m(const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t sc_stride,
+                                                    JacRaw *part, size_t nb, unsigned chunks, unsigned gens_per_chunk, unsigned kinds) {
+  fixed_chunk_body<C, 1>(table, n, cap, scalars, sc_stride, part, nb, chunks, gens_per_chunk, (size_t)blockIdx.y / kinds * chunks + blockIdx.x,
+                         kinds, blockIdx.y % kinds);
+}
+static bool fixed_per_lane(size_t n, size_t nb, int kinds) { return kinds > 0 && nb >= 64 * (size_t)kinds && n >= 64; }
+static unsigned fixed_per_lane_gens(size_t n, size_t nb, int kinds) {   // ~2 048 waves of ONE class on the chip, at least 2 generators per wave
+  const size_t sets = (nb / kinds + 63) / 64;
+  size_t target = 2048 / sets;
+  if (target < 1) target = 1;
+  if (target > 1024) target = 1024;
+  const size_t g = (2 + 2 * n + target - 1) / target;
+  return (unsigned)(g < 2 ? 2 : g);
+}
 // chunks per MSM: enough blocks to fill the chip when there are few MSMs, at least 4 pairs per lane
-size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
+size_t fixed_msm_chunks(int c, size_t n, size_t nb, int kinds) {
+  if (fixed_per_lane(n, nb, kinds)) { const size_t g = fixed_per_lane_gens(n, nb, kinds); return (2 + 2 * n + g - 1) / g; }
   size_t total = (2 + 2 * n) * (252 / c + 1);
   size_t by_work = (total + 511) / 512, by_fill = (1024 + nb - 1) / (nb ? nb : 1);
   size_t ch = by_work < by_fill ? by_work : by_fill;
@@ -352,9 +373,15 @@ size_t fixed_msm_chunks(int c, size_t n, size_t nb) {
 }
 template <int C>
 static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars, size_t stride,
-                         JacRaw *out, size_t nb, size_t chunks, int lpm) {
+                         JacRaw *out, size_t nb, size_t chunks, int lpm, int kinds) {
   constexpr int TPB = 128;
   size_t total = (2 + 2 * n) * num_windows<C>();
+  if (fixed_per_lane(n, nb, kinds) && chunks > 1) {
+    const unsigned sets = (unsigned)((nb / kinds + 63) / 64);
+    hipLaunchKernelGGL((k_fixed_msm_m<C>), dim3((unsigned)chunks, sets * kinds), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb,
+                       (unsigned)chunks, fixed_per_lane_gens(n, nb, kinds), (unsigned)kinds);
+    return;
+  }
   if (chunks == 1 && nb >= 64 && total <= 16384) {
     if (lpm == 64) hipLaunchKernelGGL((k_fixed_msm_small<C, 64>), dim3(nb), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
     else if (nb >= 1024 && lpm != 32) hipLaunchKernelGGL((k_fixed_msm_small<C, 16>), dim3((nb + 3) / 4), dim3(64), 0, st, table, n, cap, scalars, stride, out, nb);
@@ -365,18 +392,18 @@ static void launch_fixed(hipStream_t st, const AffDev *table, size_t n, size_t c
   hipLaunchKernelGGL((k_fixed_msm<C, TPB>), dim3(chunks, nb), dim3(TPB), 0, st, table, n, cap, scalars, stride, out, per);
 }
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
-               size_t stride, JacRaw *out, size_t nb, JacRaw *partials, int lpm) {
+               size_t stride, JacRaw *out, size_t nb, JacRaw *partials, int lpm, int kinds) {
   if (!nb) return;
-  size_t chunks = partials ? fixed_msm_chunks(c, n, nb) : 1;
+  size_t chunks = partials ? fixed_msm_chunks(c, n, nb, kinds) : 1;
   JacRaw *dst = chunks > 1 ? partials : out;
   switch (c) {
-    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
-    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm); break;
+    case 4: launch_fixed<4>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 8: launch_fixed<8>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 10: launch_fixed<10>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 12: launch_fixed<12>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 14: launch_fixed<14>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 16: launch_fixed<16>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
+    case 20: launch_fixed<20>(st, table, n, cap, scalars, stride, dst, nb, chunks, lpm, kinds); break;
     default: return;   // rejected by the C-ABI before reaching here
   }
   if (chunks > 1) segmented_sum(st, partials, out, nb, chunks);

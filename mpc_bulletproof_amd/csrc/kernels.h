@@ -136,9 +136,12 @@ void fixed_single16(hipStream_t st, const AffDev *table, const uint32_t *scalars
 size_t fixed_msm_ipp_chunks(int c, size_t n0, size_t nmsm);
 void fixed_msm_ipp(hipStream_t st, int c, const AffDev *table, size_t n0, size_t cap, size_t cur, const uint32_t *scalars,
                    JacRaw *out, size_t nmsm, JacRaw *partials, bool sum_partials = true /* false: the caller sums the nmsm x chunks partials itself (k_ipp_round_tail) */);
-size_t fixed_msm_chunks(int c, size_t n, size_t nb);
+// kinds > 0: the nb MSMs are large, many (>= 64 per class) and come in `kinds` interleaved classes (MSM i is of class i % kinds) whose
+// scalars look alike within a class -- a batch's A_I, A_O, S rows: an MSM per lane, a run of generators per wave (k_fixed_msm_m)
+size_t fixed_msm_chunks(int c, size_t n, size_t nb, int kinds = 0);
 void fixed_msm(hipStream_t st, int c, const AffDev *table, size_t n, size_t cap, const uint32_t *scalars,
-               size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials, int lpm = 0 /* lanes per small MSM: 32 = shorter lanes for a launch that is a link of a lone chain; 0 = by batch size */);
+               size_t sc_stride_words, JacRaw *out, size_t nb, JacRaw *partials, int lpm = 0 /* lanes per small MSM: 32 = shorter lanes for a launch that is a link of a lone chain; 0 = by batch size */,
+               int kinds = 0);
 
 // ---- verification tail -------------------------------------------------------------------------
 // per proof: sum of nvar variable-base results + the fixed-base partial; ok = is_identity;
