@@ -30,7 +30,7 @@ struct bpgpu_ctx {
   int *d_flag = nullptr;          // device int: bad-input flag
   void *sqrt_tab = nullptr;       // F_p square-root tables of the point codec (built on first use)
   struct bpgpu_gens *gen_tab = nullptr;   // 16-bit-window table of the curve generator (bpgpu_generator_mul)
-  Slot ws[28];                    // grow-only workspace slots
+  Slot ws[30];                    // grow-only workspace slots
   // optional per-kernel HIP-event timing (bench.py roofline): kind -> list of (start, stop)
   bool prof = false;
   bool latency_mode = false;      // bpgpu_set_latency_mode
@@ -640,10 +640,23 @@ static int msm_wp_batch(bpgpu_ctx *ctx, size_t nb, size_t n, const void *dsc, co
   VerifyDims d{};
   verify_wp_front_launch(ctx->st, v, d, nullptr, nullptr, 0, false);
   verify_wp_windows(ctx->st, v, (const uint32_t *)sc);
-  verify_wp_groups(ctx->st, v);
-  verify_wp_back(ctx->st, v, 8, nullptr, 0, 0, nullptr, 0, nullptr);
-  if (per == 1) HIPCK(ctx, hipMemcpyAsync(dsum, verify_wp_varsum(v), nb * sizeof(JacRaw), hipMemcpyDeviceToDevice, ctx->st));
-  else segmented_sum(ctx->st, verify_wp_varsum(v), dsum, nb, per);
+  if (per == 1) {
+    verify_wp_groups(ctx->st, v);
+    verify_wp_back(ctx->st, v, 8, nullptr, 0, 0, nullptr, 0, nullptr);
+    HIPCK(ctx, hipMemcpyAsync(dsum, verify_wp_varsum(v), nb * sizeof(JacRaw), hipMemcpyDeviceToDevice, ctx->st));
+  } else {
+    // the instances' window sums are added up first: ONE pair of Horner stages per MSM (not per instance, with a sum of `per` points behind it)
+    void *dwp2;
+    CK(ws_get(ctx, 28, verify_wp_scratch_bytes(nb, G), &dwp2));
+    VerifyWp v2 = v;
+    v2.nb = nb;
+    v2.scratch = dwp2;
+    if (!verify_wp_layout_fits(v2)) { ctx->err = "internal: window-parallel scratch layout exceeds its buffer (msm, reduced)"; return BPGPU_E_DEVICE; }
+    verify_wp_reduce_instances(ctx->st, v, v2, per);
+    verify_wp_groups(ctx->st, v2);
+    verify_wp_back(ctx->st, v2, 8, nullptr, 0, 0, nullptr, 0, nullptr);
+    HIPCK(ctx, hipMemcpyAsync(dsum, verify_wp_varsum(v2), nb * sizeof(JacRaw), hipMemcpyDeviceToDevice, ctx->st));
+  }
   *done = true;
   return BPGPU_OK;
 }

@@ -483,9 +483,9 @@ __global__ void __launch_bounds__(64) k_verify_verdict_q(const JacRaw *varsum, c
   const unsigned r = (unsigned)(t - p * R);
   const bool live = p < nb;
   if (!live) p = nb - 1;
-  Jac acc = jac_inf();
+  Jac acc = r < chunks ? raw_load(&part[p * chunks + r]) : jac_inf();
 #pragma unroll 1
-  for (unsigned q = r; q < chunks; q += R) acc = jac_add(acc, raw_load(&part[p * chunks + q]));
+  for (unsigned q = r + R; q < chunks; q += R) acc = jac_add(acc, raw_load(&part[p * chunks + q]));
 #pragma unroll 1
   for (unsigned off = R / 2; off > 0; off >>= 1) {
     Jac o;
@@ -630,6 +630,27 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
   else if (c == 16) launch_back<16>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
   else launch_back<20>(st, h, hb, f, v.latency_mode, v.fixed_lpm);
 }
+// A large MSM cut into `per` instances of G points (msm_wp_batch): the 64 window sums of an MSM's instances are added up BEFORE the
+// Horner stages, so that those run once per MSM instead of once per instance with a sum of `per` results behind them (2^14 terms:
+// 1 024 Horner chains + a 1 024-point sum -> one reduction of 64 x 1 024 points + one chain).  v: the instances (v.nb = v2.nb * per),
+// v2: the MSMs; block per (MSM, window).
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_winsum_reduce(const JacRaw *in, JacRaw *out, size_t per) {
+  __shared__ int32_t smem[27 * (TPB / 2)];
+  const size_t b = blockIdx.x >> 6, w = blockIdx.x & 63;
+  Jac acc = jac_inf();
+  for (size_t i = threadIdx.x; i < per; i += TPB) acc = jac_add(acc, raw_load(&in[(b * per + i) * 64 + w]));
+  acc = block_sum<TPB>(acc, smem);
+  if (threadIdx.x == 0) raw_store(&out[b * 64 + w], acc);
+}
+void verify_wp_reduce_instances(hipStream_t st, const VerifyWp &v, const VerifyWp &v2, size_t per) {
+  const JacRaw *in = wp_layout(v).winsum;
+  JacRaw *out = wp_layout(v2).winsum;
+  const unsigned grid = (unsigned)(v2.nb * 64);
+  if (per <= 32) hipLaunchKernelGGL((k_winsum_reduce<16>), dim3(grid), dim3(16), 0, st, in, out, per);
+  else if (per <= 128) hipLaunchKernelGGL((k_winsum_reduce<64>), dim3(grid), dim3(64), 0, st, in, out, per);
+  else hipLaunchKernelGGL((k_winsum_reduce<128>), dim3(grid), dim3(128), 0, st, in, out, per);
+}
 const JacRaw *verify_wp_varsum(const VerifyWp &v) { return wp_layout(v).varsum; }
 // generators per wave of the proof-per-lane walk of the generator half (0 = the lanes-per-proof form): by default 5 (26 runs of a
 // 64-bit range proof's 130 generators: 65 additions per lane) once the batch fills its waves -- against 16 lanes per proof and a butterfly
@@ -647,7 +668,7 @@ size_t verify_wp_fixed_parts(const VerifyWp &v, size_t n) {
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega, size_t parts) {
   WpLayout L = wp_layout(v);
   if (parts > 1) {
-    const unsigned R = parts > 16 && v.latency_mode ? 16 : 4;   // lanes per proof: 4 keep the additions dense (a lane adds parts / 4), 16 shorten a lone batch's chain
+    const unsigned R = parts > 8 ? 8 : 4;   // lanes per proof: the verdict is the last link of a batch's chain -- 26 partials: 3 + 3 + 1 additions deep on 8 lanes, 6 + 2 + 1 on 4
     hipLaunchKernelGGL(k_verify_verdict_q, dim3((unsigned)((v.nb * R + 63) / 64)), dim3(64), 0, st, L.varsum, fixed, (unsigned)parts, R, v.nb,
                        L.t.bad_lane, L.t.lanes, v.bad_sc, ok, mega);
     return;

@@ -90,6 +90,8 @@ void verify_wp_back(hipStream_t st, const VerifyWp &v, int c, const AffDev *tabl
 // half rode in verify_wp_back; out_fixed of verify_wp_back must then hold nb x parts entries)
 size_t verify_wp_fixed_parts(const VerifyWp &v, size_t n);
 void verify_wp_verdict(hipStream_t st, const VerifyWp &v, const JacRaw *fixed, int32_t *ok, Words8 *mega, size_t parts = 1);
+// window sums of v's instances (v.nb = v2.nb * per consecutive ones per MSM) added up into v2's window sums: verify_wp_groups / _back then run on v2
+void verify_wp_reduce_instances(hipStream_t st, const VerifyWp &v, const VerifyWp &v2, size_t per);
 const JacRaw *verify_wp_varsum(const VerifyWp &v);   // nb sums of the proof-point halves, valid after verify_wp_back
 
 // bucket-method MSM of one large instance: out = sum_i scalars[i] * pts[i]   (k_pip.hip)
