@@ -613,7 +613,7 @@ static size_t pip_max_tasks(size_t n, size_t W, size_t nbk) { return n * W / PIP
 size_t pippenger_scratch_bytes_batch(size_t ninst, size_t n, int c) {
   size_t W = 252 / c + 1, half = (size_t)1 << (c - 1), nbk = ninst * W * half, tot = ninst * n, mt = pip_max_tasks(tot, W, nbk);
   size_t base = al(tot * W * 4) * 2 + al((nbk + 1) * 4) * 5 + al(mt * 4) + al(mt * sizeof(JacRaw)) + al(nbk * sizeof(JacRaw)) +
-                al(ninst * W * sizeof(JacRaw)) * 129 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(1024);
+                al(ninst * W * sizeof(JacRaw)) * 129 + al(mt / PIP_HEAVY * 4 + 8) + al((nbk / SCAN_TILE + 2) * 4) + al(mt * 4) + al(1280);
   if (pip_two_level(ninst, n, c)) {
     size_t ngh = ninst * W * RS_BINS * ((n + RS_TILE - 1) / RS_TILE);
     base += al((ngh + 1) * 4) * 2 + al((ngh / SCAN_TILE + 2) * 4) + al(tot * W * 4) + al(tot * W);
@@ -634,6 +634,7 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   uint32_t *keys = (uint32_t *)p; p += al(tot * W * 4);
   uint32_t *sorted = (uint32_t *)p; p += al(tot * W * 4);
   uint32_t *counts = (uint32_t *)p; p += al((nbk + 1) * 4);
+  uint32_t *zblk = (uint32_t *)p; p += al(1280);          // right behind `counts`: cleared with it by ONE fill at the head of the stream of launches
   uint32_t *offsets = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *cursor = (uint32_t *)p; p += al((nbk + 1) * 4);
   uint32_t *tcount = (uint32_t *)p; p += al((nbk + 1) * 4);
@@ -647,7 +648,9 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   uint32_t *heavy = (uint32_t *)p; p += al(mt / PIP_HEAVY * 4 + 8);              // [0] = count, [2..] = bucket ids
   uint32_t *tile_tmp = (uint32_t *)p; p += al((nbk / SCAN_TILE + 2) * 4);
   uint32_t *task_perm = (uint32_t *)p; p += al(mt * 4);
-  uint32_t *tl_hist = (uint32_t *)p; p += al(1024);                              // [0, TL_CLASSES) histogram, [TL_CURSOR, ..) cursors
+  uint32_t *tl_hist = zblk;                                                      // [0, TL_CLASSES) histogram, [TL_CURSOR, ..) cursors (1 024 bytes)
+  uint32_t *heavy_cnt = zblk + 256;                                              // count of heavy buckets (heavy[2..] = their ids)
+  (void)hipMemsetAsync(counts, 0, al((nbk + 1) * 4) + 1280, st);   // bucket counts (the top windows' buckets beyond 2^top_bits are written by nobody), task-length histogram, heavy count
   // entries per task: a few dozen points per regular bucket AND enough buckets to fill the chip with one lane each (4 waves per
   // SIMD) -> a bucket is one task, no merge pass for it.  (2^17 terms, 82 k buckets: long tasks leave one wave per SIMD -- 0.92
   // against 0.83 ms -- so the 16-entry tasks stay there.)
@@ -666,11 +669,9 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
     hipLaunchKernelGGL(k_pip_coarse_hist, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, shift_top, tiles, gh);
     pip_scan(st, gh, goff, nullptr, ngh, gtile);
     hipLaunchKernelGGL(k_pip_coarse_scatter, dim3(tiles, nseg), dim3(RS_TPB), 0, st, keys, n, pp.W, pp.half, shift, shift_top, tiles, goff, cval, cfine);
-    (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);     // (the top windows' buckets beyond 2^top_bits are written by nobody)
     hipLaunchKernelGGL(k_pip_fine_sort, dim3(RS_BINS, nseg), dim3(RS_TPB), 0, st, goff, tiles, nseg, pp.W, pp.half, shift, shift_top, cval, cfine, counts, sorted);
     pip_scan(st, counts, offsets, nullptr, nbk, tile_tmp);
   } else {
-    (void)hipMemsetAsync(counts, 0, (nbk + 1) * 4, st);
     if (tot) hipLaunchKernelGGL(k_pip_digits, dim3((tot + 255) / 256), dim3(256), 0, st, pp, scalars, n, ninst, keys, counts);
     pip_scan(st, counts, offsets, cursor, nbk, tile_tmp);
     if (tot) hipLaunchKernelGGL(k_pip_scatter, dim3((tot * W + 255) / 256), dim3(256), 0, st, pp, keys, n, ninst, cursor, sorted);
@@ -686,16 +687,14 @@ void pippenger_batch(hipStream_t st, const AffDev *pts, const uint32_t *scalars,
   // the task count is data dependent: launch the upper bound, excess lanes exit on the device-side count
   const bool sort_tasks = tot * W >= ((size_t)1 << 18);     // two short launches: worth it from ~16 k tasks on
   if (sort_tasks) {
-    (void)hipMemsetAsync(tl_hist, 0, 1024, st);
     hipLaunchKernelGGL(k_pip_tasklen_hist, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk, tl_hist, task);
     hipLaunchKernelGGL(k_pip_task_scatter, dim3((mt + TL_TILE - 1) / TL_TILE), dim3(TL_TPB), 0, st, offsets, toffsets, task_bucket, nbk,
                        tl_hist, tl_hist + TL_CURSOR, task_perm, task);
   }
   hipLaunchKernelGGL(k_pip_bucket_bounded, dim3((mt + 63) / 64), dim3(64), 0, st, pts, offsets, sorted, toffsets, task_bucket,
                      nbk, sort_tasks ? task_perm : (const uint32_t *)nullptr, partial, task, buckets);
-  (void)hipMemsetAsync(heavy, 0, 8, st);
-  hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy);
-  hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy, buckets);
+  hipLaunchKernelGGL(k_pip_merge, dim3((nbk + 63) / 64), dim3(64), 0, st, toffsets, partial, nbk, buckets, heavy + 2, heavy_cnt);
+  hipLaunchKernelGGL(k_pip_merge_heavy, dim3(mt / PIP_HEAVY + 1), dim3(PH_TPB), 0, st, toffsets, partial, heavy + 2, heavy_cnt, buckets);
   if (pp.half >= 64) {
     const int chunks = pip_window_ab_chunks(pp.half);
     hipLaunchKernelGGL(k_pip_window_a, dim3(pp.W, ninst, chunks), dim3(64), 0, st, pp, buckets, win_part, chunks);
