@@ -108,9 +108,42 @@ __global__ void __launch_bounds__(256) k_pip_scan_apply(const uint32_t *counts, 
     run += v[j];
   }
 }
+// the same with the scan of the tile sums done by every block for itself (each adds up the sums of the tiles before its own: a few
+// thousand words from L2) -- two launches instead of three while the tile sums are few
+__global__ void __launch_bounds__(256) k_pip_scan_apply2(const uint32_t *counts, const uint32_t *tile_sum, size_t nb, size_t ntiles,
+                                                         uint32_t *offsets, uint32_t *cursor) {
+  __shared__ uint32_t sm[256];
+  __shared__ uint32_t before[4];
+  uint32_t pre = 0;
+  for (size_t t = threadIdx.x; t < blockIdx.x; t += 256) pre += tile_sum[t];
+  for (int off = 32; off > 0; off >>= 1) pre += __shfl_xor(pre, off, 64);
+  if ((threadIdx.x & 63) == 0) before[threadIdx.x >> 6] = pre;
+  size_t base = (size_t)blockIdx.x * SCAN_TILE + (size_t)threadIdx.x * 8;
+  uint32_t v[8], s = 0;
+  for (int j = 0; j < 8; j++) { v[j] = base + j < nb ? counts[base + j] : 0; s += v[j]; }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    uint32_t t = threadIdx.x >= (unsigned)off ? sm[threadIdx.x - off] : 0;
+    __syncthreads();
+    sm[threadIdx.x] += t;
+    __syncthreads();
+  }
+  const uint32_t tile_off = before[0] + before[1] + before[2] + before[3];
+  uint32_t run = tile_off + (threadIdx.x ? sm[threadIdx.x - 1] : 0);
+  for (int j = 0; j < 8; j++) {
+    if (base + j < nb) { offsets[base + j] = run; if (cursor) cursor[base + j] = run; }
+    run += v[j];
+  }
+  if (blockIdx.x + 1 == ntiles && threadIdx.x == 255) offsets[nb] = tile_off + sm[255];   // the total
+}
 static void pip_scan(hipStream_t st, const uint32_t *counts, uint32_t *offsets, uint32_t *cursor, size_t nb, uint32_t *tile_tmp) {
   size_t ntiles = (nb + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(k_pip_scan_tiles, dim3(ntiles), dim3(256), 0, st, counts, nb, tile_tmp);
+  if (ntiles <= 4096) {
+    hipLaunchKernelGGL(k_pip_scan_apply2, dim3(ntiles), dim3(256), 0, st, counts, tile_tmp, nb, ntiles, offsets, cursor);
+    return;
+  }
   hipLaunchKernelGGL(k_pip_scan_top, dim3(1), dim3(1024), 0, st, tile_tmp, ntiles, offsets + nb);
   hipLaunchKernelGGL(k_pip_scan_apply, dim3(ntiles), dim3(256), 0, st, counts, tile_tmp, nb, offsets, cursor);
 }
