@@ -1465,12 +1465,15 @@ def test_verify_batch_full_size_1024x64bit(gpu):
         gpu.circuit_destroy(circ)
 
 
-def test_verify_batch_c20_benchmarked_instance(gpu):
-    """The template instances bench.py times -- 20-bit-window generator tables, nb >= 1024 (16 lanes per fixed-base MSM:
-    k_verify_back<20, 16>, k_verify_front, k_verify_windows, k_verify_verdict) -- on a batch with tampered proofs: accept
-    bits, the non-identity mega_check points and all MSM scalars of every slot equal the oracle's.  Capacity 8 keeps the
-    table at 18 generators x 13 windows x 2^19 rows x 64 B = 7.9 GB.  Also nb = 70 (32 lanes per MSM) in
+@pytest.mark.parametrize("chunk_gens", [0, -1])
+def test_verify_batch_c20_benchmarked_instance(gpu, opts, chunk_gens):
+    """The template instances bench.py times -- 20-bit-window generator tables, nb >= 1024: the generator half a proof per lane
+    (k_verify_back_q<20, 1> + k_verify_verdict_q, the default from 256 proofs on) and, forced by the option, 16 lanes per
+    fixed-base MSM (k_verify_back<20, 16> + k_verify_verdict); k_verify_front, k_verify_windows -- on a batch with tampered
+    proofs: accept bits, the non-identity mega_check points and all MSM scalars of every slot equal the oracle's.  Capacity 8
+    keeps the table at 18 generators x 13 windows x 2^19 rows x 64 B = 7.9 GB.  Also nb = 70 (32 lanes per MSM) in
     test_range_verify_batch[8-70-20]."""
+    opts(fixed_chunk_gens=chunk_gens)
     n_bits, distinct, nb = 8, 24, 1030
     recs, cap = bh.make_range_batch(n_bits, distinct, seed0=9100)
     variants = []          # (points, scalars, challenges, ok, mega, full) for clean and tampered versions of each proof
@@ -1513,8 +1516,8 @@ def test_verify_batch_c20_benchmarked_instance(gpu):
 def test_verify_batch_bench_instance_64bit_c20_default_mode(gpu, nb):
     """EXACTLY the composite bench.py times: the 64-bit gadget (padded n = 64, k = 6 -> the vs_prep fast path +
     k_verify_scalars_fast), 20-bit-window tables of the 130 generators (57 GB), nb >= 1024 in the default mode
-    (k_verify_front<4> -> k_verify_scalars_fast -> k_verify_windows -> k_verify_horner_groups -> k_verify_back<20,16> ->
-    k_verify_verdict), on a batch that holds tampered proofs: accept bits, every mega_check point (identity for the valid
+    (k_verify_front<4> -> k_verify_scalars_fast -> k_verify_windows -> k_verify_horner_groups -> k_verify_back_q<20,1> ->
+    k_verify_verdict_q), on a batch that holds tampered proofs: accept bits, every mega_check point (identity for the valid
     proofs, the oracle's non-identity point for the tampered ones) and all 154 MSM scalars of every slot in
     verifier.rs:517-532 order equal the oracle's.  nb = 1027 leaves the last 4-proof block / table wave partly empty."""
     n_bits, distinct = 64, 20
