@@ -1092,7 +1092,9 @@ def main():
                             "the issue rate of THIS instruction mix (74 % v_mad_i64_i32, a quarter-rate 64-bit multiply-add) in the doubling / addition "
                             "micro-benchmarks at 8 waves/SIMD (profiles/r01_microbench_primitives.log); the guide prices plain wave64 VALU at 2 cycles "
                             "with >= 2 waves/SIMD, which no kernel of this mix can reach.  flat_4_cycle_frac: against one instruction per 4 cycles.  "
-                            "per_kernel_solo: each kernel alone, against the SIMDs its waves occupy"}
+                            "per_kernel_solo: each kernel alone, against the SIMDs its waves occupy.  The peak is priced at 2.4 GHz; a sustained "
+                            "run of this path draws the board's 1.36 kW and is held at 2.30 GHz (profiles/r04_power_phases.log), so at the clock "
+                            "actually held a long run's frac is 4 % higher than printed"}
             if roof:
                 roof["valu_issue_frac"] = valu["frac"]
         out = {
